@@ -1,0 +1,228 @@
+/*
+ * scanrs_amd.h — C ABI of the MI355X (gfx950) implementation of scan-rs's
+ * sparse-count-matrix normalize -> PCA hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, opaque handle,
+ * create -> operate -> free, exactly the style the reference itself uses for its
+ * one native component (bhtsne/src/bindings.rs:8-31).  Each entry point names
+ * the reference interface it replaces (paths relative to 10XGenomics/scan-rs).
+ * INTEGRATION.md shows the Rust `extern "C"` block and the `DataMat` / `Dot` /
+ * `Pca` impls a maintainer would add on the reference side.
+ *
+ * Conventions
+ *  - Matrices keep the reference orientation: `rows x cols`, `storage` 0 = CSR,
+ *    1 = CSC (same u8 code as sqz/src/mat.rs:45-65). Cell Ranger's matrix is
+ *    features x barcodes.
+ *  - Dense panels are row-major, standard layout (sqz/src/prod.rs:102-106), f64
+ *    unless the name says u32.
+ *  - All functions return a status (0 = ok); they never unwind.  The message
+ *    for the calling thread's last failure is scanrs_last_error().
+ *  - Host pointers are borrowed for the duration of the call; the library owns
+ *    the device copies inside the handle.  A handle is not thread-safe;
+ *    distinct handles are independent.
+ *  - There is no CPU fallback: every compute entry point needs a gfx950 device
+ *    and fails with SCANRS_ERR_DEVICE otherwise.
+ */
+#ifndef SCANRS_AMD_H
+#define SCANRS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct scanrs_mat scanrs_mat; /* opaque: AdaptiveMat / LowRankOffset on the device */
+
+/* status codes (anyhow errors / panics / CancellationError of the reference) */
+enum {
+    SCANRS_OK = 0,
+    SCANRS_ERR_SHAPE = 1,     /* "The input matrix must be at least 2x2." / "Dimension mismatch" */
+    SCANRS_ERR_INVALID_K = 2, /* "invalid k" (bk_svd.rs:77-79) */
+    SCANRS_ERR_CANCELLED = 3, /* snoop::CancellationError (snoop/src/lib.rs:5-18) */
+    SCANRS_ERR_DEVICE = 4,    /* no gfx950 device / HIP failure / out of memory */
+    SCANRS_ERR_NUMERICAL = 5, /* LAPACK-style failure (`?` on qr()/svddc_into()) */
+    SCANRS_ERR_ARGUMENT = 6   /* null pointer, bad enum, unsupported combination */
+};
+
+/* storage flag, sqz/src/mat.rs:45-65 */
+enum { SCANRS_CSR = 0, SCANRS_CSC = 1 };
+
+/* scalar maps (`ScalarMap`, sqz/src/matrix_map.rs:269-308; closures of normalization.rs:172-176, mat.rs:995) */
+enum { SCANRS_FN_LN_1P = 2, SCANRS_FN_LOG2_1P = 3, SCANRS_FN_LOG10_1P = 4, SCANRS_FN_SQUARE = 5 };
+
+/* `enum Normalization`, scan-rs/src/normalization.rs:11-28 (same order) */
+enum {
+    SCANRS_NORM_CELLRANGER = 0,
+    SCANRS_NORM_CELLRANGER8 = 1,
+    SCANRS_NORM_SEURATLOG = 2,
+    SCANRS_NORM_BINOMIAL_DEVIANCE = 3,
+    SCANRS_NORM_BINOMIAL_PEARSON = 4,
+    SCANRS_NORM_WITH_SIZE_FACTORS = 5,
+    SCANRS_NORM_LOG_TRANSFORM = 6
+};
+
+const char *scanrs_last_error(void);
+/* 1 if a gfx950 device is usable from this process, else 0 (never fails). */
+int scanrs_device_available(void);
+const char *scanrs_version(void);
+
+/* ---- storage: sqz::AdaptiveMat (sqz/src/mat.rs:34-42) ---------------------- */
+
+/* AdaptiveMat::from_csmat (mat.rs:92-124) / hdf5-io read_adaptive_csr_matrix
+ * (hdf5-io/src/matrix.rs:119-192): take a compressed matrix by its
+ * indptr(u64)/indices(u32)/data(u32) triplet (host pointers), upload it.
+ * Indices must be ascending within each outer vector; stored zeros are dropped
+ * (AbsIter semantics, sqz/src/vec.rs:113). The map is MatrixIntoMap. */
+int scanrs_mat_create(uint64_t rows, uint64_t cols, int storage, const uint64_t *indptr, const uint32_t *indices,
+                      const uint32_t *values, scanrs_mat **out);
+/* Same, the triplet already lives in device memory (copied, not adopted). */
+int scanrs_mat_create_device(uint64_t rows, uint64_t cols, int storage, const uint64_t *d_indptr,
+                             const uint32_t *d_indices, const uint32_t *d_values, scanrs_mat **out);
+/* Drop for AdaptiveMat / LowRankOffset (Rust `Drop`, cf. bhtsne/src/lib.rs:19-23). Null is a no-op. */
+void scanrs_mat_free(scanrs_mat *m);
+
+/* AdaptiveMat::view (mat.rs:242-245): new handle sharing the storage, same map/offset. */
+int scanrs_mat_view(const scanrs_mat *m, scanrs_mat **out);
+/* AdaptiveMat::t / LowRankOffset::t (mat.rs:262-270, low_rank_offset.rs:60-65): transposed view. */
+int scanrs_mat_t(const scanrs_mat *m, scanrs_mat **out);
+
+/* rows(), cols(), nnz(), storage (mat.rs:155-180) */
+int scanrs_mat_shape(const scanrs_mat *m, uint64_t *rows, uint64_t *cols);
+int scanrs_mat_nnz(const scanrs_mat *m, uint64_t *nnz);
+int scanrs_mat_storage(const scanrs_mat *m, int *storage);
+
+/* ---- lazy maps: sqz::MatrixMap (sqz/src/matrix_map.rs) ----------------------- */
+
+/* set_map(MatrixIntoMap) (mat.rs:892-898): back to the raw counts; also drops the offset. */
+int scanrs_mat_reset_map(scanrs_mat *m);
+/* compose_map(ScaleAxis::new(Axis(axis), factors)) (mat.rs:901-913, matrix_map.rs:221-257).
+ * axis 0: factors[r] * v (length rows); axis 1: factors[c] * v (length cols). */
+int scanrs_mat_compose_scale_axis(scanrs_mat *m, int axis, const double *factors);
+/* apply(f) = compose_map(ScalarMap::new(f)) (mat.rs:925-933); f is one of SCANRS_FN_*. */
+int scanrs_mat_apply(scanrs_mat *m, int scalar_fn);
+/* LowRankOffset::new(mat, u, v) (low_rank_offset.rs:26-33): u is rows x rank, v is rank x cols. */
+int scanrs_mat_set_offset(scanrs_mat *m, uint32_t rank, const double *u, const double *v);
+
+/* center / scale / scale_and_center (mat.rs:937-1001). `given` may be null
+ * (means / std-devs are then computed on the device as the reference does). */
+int scanrs_mat_center(scanrs_mat *m, int axis, const double *given_means);
+int scanrs_mat_scale(scanrs_mat *m, int axis, const double *given_std);
+int scanrs_mat_scale_and_center(scanrs_mat *m, int axis, const double *given_scaling);
+
+/* ---- reductions (mat.rs:273-406) ------------------------------------------------ */
+
+/* sum_axis::<u32> on the raw counts (normalization.rs:159,161). axis 0 -> cols entries. */
+int scanrs_mat_sum_axis_u32(scanrs_mat *m, int axis, uint32_t *out);
+/* sum_axis::<f64> of the mapped values (offset not included, as in the reference). */
+int scanrs_mat_sum_axis_f64(scanrs_mat *m, int axis, double *out);
+int scanrs_mat_mean_axis(scanrs_mat *m, int axis, double *out);
+int scanrs_mat_mean_var_axis(scanrs_mat *m, int axis, double *mean, double *var);
+
+/* to_dense (mat.rs:188-205, low_rank_offset.rs:55-57): rows x cols f64, small matrices / tests. */
+int scanrs_mat_to_dense(scanrs_mat *m, double *out);
+
+/* ---- products: `Dot` impls (mat.rs:1074-1170, low_rank_offset.rs:68-96, prod.rs) -- */
+
+/* self.dot(rhs): rhs is cols x l, out is rows x l (includes the offset u*(v*rhs) when set). */
+int scanrs_mat_dot(scanrs_mat *m, const double *rhs, uint32_t l, double *out);
+/* lhs.dot(self): lhs is l x rows, out is l x cols. */
+int scanrs_mat_rdot(scanrs_mat *m, const double *lhs, uint32_t l, double *out);
+/* The `A = u32` instantiation tested by mat.rs:1406-1486 / benched by
+ * sqz/benches/my_benchmark.rs (identity map, wrapping integer arithmetic). */
+int scanrs_mat_dot_u32(scanrs_mat *m, const uint32_t *rhs, uint32_t l, uint32_t *out);
+int scanrs_mat_rdot_u32(scanrs_mat *m, const uint32_t *lhs, uint32_t l, uint32_t *out);
+/* Device-resident panels, padded leading dimensions (elements): d_out[rows x l] = self * d_rhs[cols x l];
+ * with `transpose` != 0: d_out[cols x l] = self^T * d_rhs[rows x l]. ld must be even. */
+int scanrs_mat_dot_device(scanrs_mat *m, int transpose, const double *d_rhs, uint32_t ld_rhs, uint32_t l, double *d_out,
+                          uint32_t ld_out);
+
+/* ---- normalization: scan-rs/src/normalization.rs ----------------------------------- */
+
+/* normalize / normalize_with_size_factor (normalization.rs:46-102) and the binomial
+ * residual maps (:232-322): installs the lazy map + rank-1 offset on the handle.
+ * size_factors (length cols) only for SCANRS_NORM_WITH_SIZE_FACTORS, else null. */
+int scanrs_normalize(scanrs_mat *m, int normalization, const uint32_t *size_factors);
+/* log_normalize_with_size_factor (normalization.rs:138-178) without the centre/scale step.
+ * umi_count_sum < 0 means None (median of the column sums). */
+int scanrs_log_normalize(scanrs_mat *m, double umi_count_sum, int log_fn, const uint32_t *size_factors);
+/* log1p_normalize_fixed_point (normalization.rs:191-213). */
+int scanrs_log1p_normalize_fixed_point(scanrs_mat *m, int log_fn, uint32_t base, uint32_t exponent);
+/* target UMI count chosen by the last (log_)normalize call: max(median(colsums), 1) (normalization.rs:162-168) */
+int scanrs_mat_target_umi(const scanrs_mat *m, double *target);
+
+/* ---- PCA: scan-rs/src/dim_red ----------------------------------------------------------- */
+
+/* snoop::CancelProgress (snoop/src/lib.rs:37-58): `cancel` points at an
+ * AtomicBool-compatible byte read with relaxed ordering between kernel launches
+ * (may be null); `progress` receives set_progress fractions (may be null). */
+typedef void (*scanrs_progress_fn)(void *ctx, double fraction);
+typedef struct {
+    const volatile uint8_t *cancel;
+    scanrs_progress_fn progress;
+    void *ctx;
+} scanrs_snoop;
+
+/* BkSvd::run_pca_cancellable / svd_bk (dim_red/bk_svd.rs:41-146).
+ * omega: optional explicit start panel in the reference's own layout
+ * ((cols x b) row-major when rows >= cols, else (b x rows)), b = min(rows, cols, ceil(k*k_multiplier));
+ * null -> generated from `seed` like SmallRng::seed_from_u64 + Uniform(-1,1).
+ * Outputs (caller-allocated, row-major): u rows x k, s k, v cols x k  (= PcaResult, dim_red/mod.rs:47). */
+int scanrs_pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
+                  const scanrs_snoop *snoop, double *u, double *s, double *v);
+/* RandSvd::run_pca / svd_rand (dim_red/rand_svd.rs:37-129). l = max(k+4, (k*l_multiplier) as usize).
+ * omega layout: (cols x l) when rows >= cols, else (l x rows). */
+int scanrs_pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
+                    double *u, double *s, double *v);
+/* Irlba::run_pca_cancellable / irlba (dim_red/irlba.rs:59-215). v0: optional start vector (length cols);
+ * null -> seeded normal. mprod (may be null) receives the "number of matrix products" (irlba.rs:212). */
+int scanrs_pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t max_iter, const double *v0,
+                     const scanrs_snoop *snoop, double *u, double *s, double *v, uint32_t *mprod);
+/* The panel the two randomized drivers draw for a given seed (count values, row-major fill order). */
+int scanrs_omega_fill(uint64_t seed, uint64_t count, double *out);
+
+/* ---- multi-GPU: one process per GPU, cells range-partitioned ----------- */
+
+/* In-place sum all-reduce of `count` elements of device memory across ranks.
+ * dtype 0 = f64, 1 = u64. Returns 0 on success. The host program supplies it
+ * (bench.py: torch.distributed over RCCL); the library calls it once per
+ * sparse product that contracts over the sharded dimension. */
+typedef int (*scanrs_allreduce_fn)(void *ctx, void *d_buf, uint64_t count, int dtype);
+/* Declare that this handle holds outer vectors [outer_begin, outer_begin + n_local) of a
+ * matrix whose sharded (outer) dimension has `outer_global` entries. The handle's own
+ * shape keeps the local count; reductions over the outer dimension become global. */
+int scanrs_mat_set_shard(scanrs_mat *m, uint32_t rank, uint32_t world, uint64_t outer_begin, uint64_t outer_global,
+                         scanrs_allreduce_fn allreduce, void *ctx);
+/* nnz-balanced contiguous partition of the outer dimension: bounds has world+1 entries. */
+int scanrs_plan_shards(const uint64_t *indptr, uint64_t n_outer, uint32_t world, uint64_t *bounds);
+
+/* ---- measurement ------------------------------------------------------------------------- */
+
+/* Per-kernel-class HIP-event timing on the handle's stream (bench.py roofline leg). */
+typedef struct {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+    double algorithmic_bytes; /* summed over launches, SURVEY.md §8d accounting */
+} scanrs_kernel_stat;
+int scanrs_profile_enable(scanrs_mat *m, int on);
+int scanrs_profile_reset(scanrs_mat *m);
+/* Fills up to `cap` entries, writes the total count to *n. */
+int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uint32_t *n);
+/* Block until all work queued on the handle's stream is done. */
+int scanrs_mat_sync(scanrs_mat *m);
+
+/* ---- host-side dense helpers (no device needed; used by the solvers where the reference calls
+ * LAPACK on k x k matrices, exposed so the CPU test-suite can check them) ------------------------- */
+/* in place upper Cholesky G = R^T R (row-major n x n); SCANRS_ERR_NUMERICAL when G is not SPD */
+int scanrs_host_chol_upper(double *g, int n);
+/* in place inverse of an upper-triangular matrix */
+int scanrs_host_inv_upper(double *r, int n);
+/* symmetric eigen-decomposition, w descending, z[i*n + j] = component i of eigenvector j */
+int scanrs_host_sym_eig(const double *a, int n, double *w, double *z);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCANRS_AMD_H */

@@ -1,0 +1,558 @@
+"""scan-rs_amd: MI355X (gfx950) implementation of scan-rs's sparse-count-matrix
+normalize -> PCA hot path, behind the C ABI of ``include/scanrs_amd.h``.
+
+This module is the Python host-side mirror used by the tests and ``bench.py``:
+same names, argument meaning and error behaviour as the reference's operator
+surface (``sqz::AdaptiveMat`` / ``LowRankOffset`` / ``scan_rs::normalization`` /
+``scan_rs::dim_red::{BkSvd, RandSvd, Irlba}``), every call going straight
+through ctypes into ``lib/libscanrs_amd.so``.  There is no CPU fallback: if the
+shared library is missing the import fails, and without a gfx950 device every
+compute call raises ``ScanrsError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libscanrs_amd.so")
+
+CSR, CSC = 0, 1
+FN_LN_1P, FN_LOG2_1P, FN_LOG10_1P, FN_SQUARE = 2, 3, 4, 5
+
+
+class Normalization:
+    """`enum Normalization` (scan-rs/src/normalization.rs:11-28) and its `FromStr` (:30-43)."""
+
+    CellRanger, CellRanger8, SeuratLog, BinomialDeviance, BinomialPearson, WithSizeFactors, LogTransform = range(7)
+    _NAMES = {
+        "cellranger": 0,
+        "cellranger8": 1,
+        "seuratlog": 2,
+        "binomialdeviance": 3,
+        "binomialpearson": 4,
+    }
+
+    @staticmethod
+    def from_str(s: str) -> int:
+        if s not in Normalization._NAMES:
+            raise ValueError(f"Normalization not recognized: {s}")
+        return Normalization._NAMES[s]
+
+
+class ScanrsError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[scanrs {code}] {msg}")
+        self.code = code
+
+
+class CancellationError(ScanrsError):
+    """snoop::CancellationError (snoop/src/lib.rs:5-18)."""
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950). scan-rs_amd has no CPU fallback."
+    )
+_lib = ctypes.CDLL(LIB_PATH)
+_lib.scanrs_last_error.restype = ctypes.c_char_p
+_lib.scanrs_version.restype = ctypes.c_char_p
+
+_PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_double)
+_ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int)
+
+
+class _Snoop(ctypes.Structure):
+    _fields_ = [("cancel", ctypes.c_void_p), ("progress", _PROGRESS_FN), ("ctx", ctypes.c_void_p)]
+
+
+class _KernelStat(ctypes.Structure):
+    _fields_ = [
+        ("name", ctypes.c_char * 48),
+        ("launches", ctypes.c_uint64),
+        ("total_ms", ctypes.c_double),
+        ("algorithmic_bytes", ctypes.c_double),
+    ]
+
+
+def _check(code: int):
+    if code != 0:
+        msg = _lib.scanrs_last_error().decode("utf-8", "replace")
+        if code == 3:
+            raise CancellationError(code, msg)
+        raise ScanrsError(code, msg)
+
+
+def device_available() -> bool:
+    return bool(_lib.scanrs_device_available())
+
+
+def version() -> str:
+    return _lib.scanrs_version().decode()
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class AtomicSnoop:
+    """`snoop::AtomicSnoop` (snoop/src/lib.rs:117-226): cancel flag + progress fraction."""
+
+    def __init__(self):
+        self._flag = (ctypes.c_uint8 * 1)(0)
+        self.progress = 0.0
+        self.history = []
+        self._cb = _PROGRESS_FN(self._on_progress)
+
+    def _on_progress(self, _ctx, frac):
+        self.progress = frac
+        self.history.append(frac)
+
+    def cancel(self):
+        self._flag[0] = 1
+
+    def is_cancelled(self):
+        return bool(self._flag[0])
+
+    def _struct(self):
+        return _Snoop(ctypes.cast(self._flag, ctypes.c_void_p), self._cb, None)
+
+
+class AdaptiveMat:
+    """Device-resident `sqz::AdaptiveMat<N, D, M>` (sqz/src/mat.rs:34-42). Once a low-rank
+    offset is installed (`center`, `scale_and_center`, `normalize`) the same object plays
+    `sqz::LowRankOffset` (sqz/src/low_rank_offset.rs:12-16)."""
+
+    def __init__(self, handle):
+        self._h = ctypes.c_void_p(handle)
+        self._keep = []  # callbacks that must outlive the handle
+
+    # -- constructors ----------------------------------------------------------------
+    @staticmethod
+    def from_csmat(rows: int, cols: int, storage: int, indptr, indices, data) -> "AdaptiveMat":
+        """`AdaptiveMat::from_csmat` (mat.rs:92-124): host indptr(u64) / indices(u32) / data(u32)."""
+        indptr = np.ascontiguousarray(indptr, dtype=np.uint64)
+        indices = np.ascontiguousarray(indices, dtype=np.uint32)
+        data = np.ascontiguousarray(data, dtype=np.uint32)
+        n_outer = rows if storage == CSR else cols
+        if indptr.shape[0] != n_outer + 1:
+            raise ScanrsError(6, "indptr length does not match the outer dimension")
+        if indices.shape[0] != data.shape[0] or (indptr.shape[0] and int(indptr[-1]) != indices.shape[0]):
+            raise ScanrsError(6, "indices/data length does not match indptr")
+        h = ctypes.c_void_p()
+        _check(
+            _lib.scanrs_mat_create(
+                ctypes.c_uint64(rows), ctypes.c_uint64(cols), ctypes.c_int(storage), _p(indptr), _p(indices), _p(data),
+                ctypes.byref(h)))
+        return AdaptiveMat(h.value)
+
+    @staticmethod
+    def from_device(rows: int, cols: int, storage: int, indptr_ptr: int, indices_ptr: int, data_ptr: int) -> "AdaptiveMat":
+        """Same triplet already in device memory (e.g. `tensor.data_ptr()`); copied, not adopted."""
+        h = ctypes.c_void_p()
+        _check(
+            _lib.scanrs_mat_create_device(
+                ctypes.c_uint64(rows), ctypes.c_uint64(cols), ctypes.c_int(storage), ctypes.c_void_p(indptr_ptr),
+                ctypes.c_void_p(indices_ptr), ctypes.c_void_p(data_ptr), ctypes.byref(h)))
+        return AdaptiveMat(h.value)
+
+    @staticmethod
+    def from_scipy(m) -> "AdaptiveMat":
+        import scipy.sparse as sp
+
+        if sp.isspmatrix_csc(m):
+            st = CSC
+        else:
+            m = m.tocsr()
+            st = CSR
+        m.sort_indices()
+        return AdaptiveMat.from_csmat(m.shape[0], m.shape[1], st, m.indptr, m.indices, m.data)
+
+    @staticmethod
+    def from_dense(dense, storage: int = CSR) -> "AdaptiveMat":
+        """`AdaptiveMat::from_dense` (mat.rs:122-150)."""
+        import scipy.sparse as sp
+
+        dense = np.asarray(dense)
+        m = sp.csr_matrix(dense) if storage == CSR else sp.csc_matrix(dense)
+        return AdaptiveMat.from_scipy(m)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            _lib.scanrs_mat_free(h)
+            self._h = ctypes.c_void_p()
+
+    # -- shape / views -----------------------------------------------------------------
+    def shape(self):
+        r, c = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(_lib.scanrs_mat_shape(self._h, ctypes.byref(r), ctypes.byref(c)))
+        return [int(r.value), int(c.value)]
+
+    def rows(self):
+        return self.shape()[0]
+
+    def cols(self):
+        return self.shape()[1]
+
+    def nnz(self):
+        n = ctypes.c_uint64()
+        _check(_lib.scanrs_mat_nnz(self._h, ctypes.byref(n)))
+        return int(n.value)
+
+    def storage(self):
+        s = ctypes.c_int()
+        _check(_lib.scanrs_mat_storage(self._h, ctypes.byref(s)))
+        return int(s.value)
+
+    def view(self) -> "AdaptiveMat":
+        h = ctypes.c_void_p()
+        _check(_lib.scanrs_mat_view(self._h, ctypes.byref(h)))
+        v = AdaptiveMat(h.value)
+        v._keep = self._keep
+        return v
+
+    def t(self) -> "AdaptiveMat":
+        h = ctypes.c_void_p()
+        _check(_lib.scanrs_mat_t(self._h, ctypes.byref(h)))
+        v = AdaptiveMat(h.value)
+        v._keep = self._keep
+        return v
+
+    # -- lazy maps --------------------------------------------------------------------------
+    def reset_map(self):
+        _check(_lib.scanrs_mat_reset_map(self._h))
+        return self
+
+    def compose_scale_axis(self, axis: int, factors):
+        """`compose_map(ScaleAxis::new(Axis(axis), factors))`."""
+        f = _f64(factors)
+        want = self.rows() if axis == 0 else self.cols()
+        if axis in (0, 1) and f.shape[0] != want:
+            raise ScanrsError(1, "Dimension mismatch")
+        _check(_lib.scanrs_mat_compose_scale_axis(self._h, ctypes.c_int(axis), _p(f)))
+        return self
+
+    def apply(self, scalar_fn: int):
+        _check(_lib.scanrs_mat_apply(self._h, ctypes.c_int(scalar_fn)))
+        return self
+
+    def set_offset(self, u, v):
+        """`LowRankOffset::new(mat, u, v)`: u rows x rank, v rank x cols."""
+        u, v = _f64(u), _f64(v)
+        r, c = self.shape()
+        if u.ndim != 2 or v.ndim != 2 or u.shape[0] != r or v.shape[1] != c or u.shape[1] != v.shape[0]:
+            raise ScanrsError(1, "Dimension mismatch")
+        _check(_lib.scanrs_mat_set_offset(self._h, ctypes.c_uint32(u.shape[1]), _p(u), _p(v)))
+        return self
+
+    def center(self, axis: int, m=None):
+        mm = None if m is None else _f64(m)
+        _check(_lib.scanrs_mat_center(self._h, ctypes.c_int(axis), _p(mm)))
+        return self
+
+    def scale(self, axis: int, s=None):
+        ss = None if s is None else _f64(s)
+        _check(_lib.scanrs_mat_scale(self._h, ctypes.c_int(axis), _p(ss)))
+        return self
+
+    def scale_and_center(self, axis: int, scaling_factors=None):
+        ss = None if scaling_factors is None else _f64(scaling_factors)
+        _check(_lib.scanrs_mat_scale_and_center(self._h, ctypes.c_int(axis), _p(ss)))
+        return self
+
+    # -- reductions ----------------------------------------------------------------------------
+    def sum_axis(self, axis: int, dtype=np.float64):
+        if axis not in (0, 1):
+            raise ScanrsError(6, "axis must be 0 or 1")
+        n = self.cols() if axis == 0 else self.rows()
+        if dtype == np.uint32:
+            out = np.zeros(n, dtype=np.uint32)
+            _check(_lib.scanrs_mat_sum_axis_u32(self._h, ctypes.c_int(axis), _p(out)))
+        else:
+            out = np.zeros(n, dtype=np.float64)
+            _check(_lib.scanrs_mat_sum_axis_f64(self._h, ctypes.c_int(axis), _p(out)))
+        return out
+
+    def mean_axis(self, axis: int):
+        n = self.cols() if axis == 0 else self.rows()
+        out = np.zeros(n)
+        _check(_lib.scanrs_mat_mean_axis(self._h, ctypes.c_int(axis), _p(out)))
+        return out
+
+    def mean_var_axis(self, axis: int):
+        n = self.cols() if axis == 0 else self.rows()
+        mean, var = np.zeros(n), np.zeros(n)
+        _check(_lib.scanrs_mat_mean_var_axis(self._h, ctypes.c_int(axis), _p(mean), _p(var)))
+        return mean, var
+
+    def to_dense(self):
+        r, c = self.shape()
+        out = np.zeros((r, c))
+        _check(_lib.scanrs_mat_to_dense(self._h, _p(out)))
+        return out
+
+    # -- products ----------------------------------------------------------------------------------
+    def dot(self, rhs):
+        """`self.dot(&rhs)` (mat.rs:1074-1112, low_rank_offset.rs:68-81)."""
+        rhs = np.asarray(rhs)
+        one_d = rhs.ndim == 1
+        if one_d:
+            rhs = rhs.reshape(-1, 1)
+        r, c = self.shape()
+        if rhs.shape[0] != c:
+            raise ScanrsError(1, "Dimension mismatch")
+        l = rhs.shape[1]
+        if rhs.dtype == np.uint32:
+            rhs_c = np.ascontiguousarray(rhs)
+            out = np.zeros((r, l), dtype=np.uint32)
+            _check(_lib.scanrs_mat_dot_u32(self._h, _p(rhs_c), ctypes.c_uint32(l), _p(out)))
+        else:
+            rhs_c = _f64(rhs)
+            out = np.zeros((r, l))
+            _check(_lib.scanrs_mat_dot(self._h, _p(rhs_c), ctypes.c_uint32(l), _p(out)))
+        return out[:, 0] if one_d else out
+
+    def rdot(self, lhs):
+        """`lhs.dot(&self)` (mat.rs:1114-1170, low_rank_offset.rs:83-96)."""
+        lhs = np.asarray(lhs)
+        one_d = lhs.ndim == 1
+        if one_d:
+            lhs = lhs.reshape(1, -1)
+        r, c = self.shape()
+        if lhs.shape[1] != r:
+            raise ScanrsError(1, "Dimension mismatch")
+        l = lhs.shape[0]
+        if lhs.dtype == np.uint32:
+            lhs_c = np.ascontiguousarray(lhs)
+            out = np.zeros((l, c), dtype=np.uint32)
+            _check(_lib.scanrs_mat_rdot_u32(self._h, _p(lhs_c), ctypes.c_uint32(l), _p(out)))
+        else:
+            lhs_c = _f64(lhs)
+            out = np.zeros((l, c))
+            _check(_lib.scanrs_mat_rdot(self._h, _p(lhs_c), ctypes.c_uint32(l), _p(out)))
+        return out[0, :] if one_d else out
+
+    def dot_device(self, transpose: bool, rhs_ptr: int, ld_rhs: int, l: int, out_ptr: int, ld_out: int):
+        _check(
+            _lib.scanrs_mat_dot_device(
+                self._h, ctypes.c_int(int(transpose)), ctypes.c_void_p(rhs_ptr), ctypes.c_uint32(ld_rhs), ctypes.c_uint32(l),
+                ctypes.c_void_p(out_ptr), ctypes.c_uint32(ld_out)))
+
+    # -- sharding / measurement ------------------------------------------------------------------------
+    def set_shard(self, rank: int, world: int, outer_begin: int, outer_global: int, allreduce=None):
+        """`allreduce(dev_ptr:int, count:int, dtype:int) -> int` sums in place across ranks (0 f64, 1 u64)."""
+        cb = None
+        if allreduce is not None:
+            def _tramp(_ctx, ptr, count, dtype, _f=allreduce):
+                try:
+                    return int(_f(int(ptr), int(count), int(dtype)) or 0)
+                except Exception:  # never unwind into C
+                    import traceback
+
+                    traceback.print_exc()
+                    return 1
+
+            cb = _ALLREDUCE_FN(_tramp)
+            self._keep.append(cb)
+        _check(
+            _lib.scanrs_mat_set_shard(
+                self._h, ctypes.c_uint32(rank), ctypes.c_uint32(world), ctypes.c_uint64(outer_begin),
+                ctypes.c_uint64(outer_global), cb if cb is not None else ctypes.cast(None, _ALLREDUCE_FN), None))
+        return self
+
+    def profile_enable(self, on: bool = True):
+        _check(_lib.scanrs_profile_enable(self._h, ctypes.c_int(int(on))))
+
+    def profile_reset(self):
+        _check(_lib.scanrs_profile_reset(self._h))
+
+    def profile_get(self):
+        arr = (_KernelStat * 64)()
+        n = ctypes.c_uint32()
+        _check(_lib.scanrs_profile_get(self._h, arr, ctypes.c_uint32(64), ctypes.byref(n)))
+        return {
+            arr[i].name.decode(): {
+                "launches": int(arr[i].launches),
+                "total_ms": float(arr[i].total_ms),
+                "algorithmic_bytes": float(arr[i].algorithmic_bytes),
+            }
+            for i in range(min(int(n.value), 64))
+        }
+
+    def sync(self):
+        _check(_lib.scanrs_mat_sync(self._h))
+
+    def target_umi(self) -> float:
+        t = ctypes.c_double()
+        _check(_lib.scanrs_mat_target_umi(self._h, ctypes.byref(t)))
+        return float(t.value)
+
+
+# ---- scan-rs/src/normalization.rs ---------------------------------------------------------------
+def normalize(mat: AdaptiveMat, norm: int) -> AdaptiveMat:
+    """`normalize(mat, norm)` (normalization.rs:46-69); consumes `mat` like the reference, returns it."""
+    _check(_lib.scanrs_normalize(mat._h, ctypes.c_int(norm), None))
+    return mat
+
+
+def normalize_with_size_factor(mat: AdaptiveMat, norm: int, size_factors=None) -> AdaptiveMat:
+    """normalization.rs:72-102."""
+    sf = None
+    if size_factors is not None:
+        sf = np.ascontiguousarray(size_factors, dtype=np.uint32)
+        if sf.shape[0] != mat.cols():
+            raise ScanrsError(1, "Size of the size factor and matrix columns dont match.")
+    _check(_lib.scanrs_normalize(mat._h, ctypes.c_int(norm), _p(sf)))
+    return mat
+
+
+def log_normalize_with_size_factor(mat: AdaptiveMat, umi_count_sum: Optional[float], log_fn: int, size_factors=None):
+    """normalization.rs:138-178 (no centre/scale)."""
+    sf = None
+    if size_factors is not None:
+        sf = np.ascontiguousarray(size_factors, dtype=np.uint32)
+        if sf.shape[0] != mat.cols():
+            raise ScanrsError(1, "Size of the size factor and matrix columns dont match.")
+    _check(
+        _lib.scanrs_log_normalize(
+            mat._h, ctypes.c_double(-1.0 if umi_count_sum is None else float(umi_count_sum)), ctypes.c_int(log_fn), _p(sf)))
+    return mat
+
+
+def log1p_normalize_fixed_point(mat: AdaptiveMat, log_fn: int, base: int, exponent: int) -> AdaptiveMat:
+    """normalization.rs:191-213."""
+    _check(_lib.scanrs_log1p_normalize_fixed_point(mat._h, ctypes.c_int(log_fn), ctypes.c_uint32(base), ctypes.c_uint32(exponent)))
+    return mat
+
+
+def binom_deviance_resid(mat: AdaptiveMat) -> AdaptiveMat:
+    return normalize(mat, Normalization.BinomialDeviance)
+
+
+def binom_pearson_resid(mat: AdaptiveMat) -> AdaptiveMat:
+    return normalize(mat, Normalization.BinomialPearson)
+
+
+# ---- scan-rs/src/dim_red ---------------------------------------------------------------------------
+def omega_fill(seed: int, count: int) -> np.ndarray:
+    out = np.zeros(count)
+    _check(_lib.scanrs_omega_fill(ctypes.c_uint64(seed), ctypes.c_uint64(count), _p(out)))
+    return out
+
+
+def _snoop_arg(snoop):
+    if snoop is None:
+        return None, None
+    s = snoop._struct()
+    return ctypes.byref(s), s
+
+
+class BkSvd:
+    """`BkSvd` (dim_red/bk_svd.rs:16-53)."""
+
+    def __init__(self, k_multiplier: float = 2.0, n_iter: int = 5):
+        self.k_multiplier, self.n_iter = k_multiplier, n_iter
+
+    def run_pca(self, matrix: AdaptiveMat, k: int, omega=None, snoop: Optional[AtomicSnoop] = None, seed: int = 0):
+        """Returns (u rows x k, s k, v cols x k) — `PcaResult` (dim_red/mod.rs:47)."""
+        r, c = matrix.shape()
+        u, s, v = np.zeros((r, max(k, 0))), np.zeros(max(k, 0)), np.zeros((c, max(k, 0)))
+        om = None if omega is None else _f64(omega)
+        sref, _keep = _snoop_arg(snoop)
+        _check(
+            _lib.scanrs_pca_bk(
+                matrix._h, ctypes.c_uint32(k), ctypes.c_double(self.k_multiplier), ctypes.c_uint32(self.n_iter),
+                ctypes.c_uint64(seed), _p(om), sref, _p(u), _p(s), _p(v)))
+        return u, s, v
+
+    run_pca_cancellable = run_pca
+
+
+class RandSvd:
+    """`RandSvd` (dim_red/rand_svd.rs:13-50)."""
+
+    def __init__(self, l_multiplier: float = 10.0, n_iter: int = 2):
+        self.l_multiplier, self.n_iter = l_multiplier, n_iter
+
+    def run_pca(self, matrix: AdaptiveMat, k: int, omega=None, seed: int = 0):
+        r, c = matrix.shape()
+        u, s, v = np.zeros((r, k)), np.zeros(k), np.zeros((c, k))
+        om = None if omega is None else _f64(omega)
+        _check(
+            _lib.scanrs_pca_rand(
+                matrix._h, ctypes.c_uint32(k), ctypes.c_double(self.l_multiplier), ctypes.c_uint32(self.n_iter),
+                ctypes.c_uint64(seed), _p(om), _p(u), _p(s), _p(v)))
+        return u, s, v
+
+
+class Irlba:
+    """`Irlba` (dim_red/irlba.rs:36-67)."""
+
+    def __init__(self, tol: float = 0.0001, max_iter: int = 50):
+        self.tol, self.max_iter = tol, max_iter
+        self.mprod = 0
+
+    def run_pca(self, matrix: AdaptiveMat, k: int, v0=None, snoop: Optional[AtomicSnoop] = None):
+        r, c = matrix.shape()
+        u, s, v = np.zeros((r, k)), np.zeros(k), np.zeros((c, k))
+        vv = None if v0 is None else _f64(v0)
+        sref, _keep = _snoop_arg(snoop)
+        mp = ctypes.c_uint32()
+        _check(
+            _lib.scanrs_pca_irlba(
+                matrix._h, ctypes.c_uint32(k), ctypes.c_double(self.tol), ctypes.c_uint32(self.max_iter), _p(vv), sref,
+                _p(u), _p(s), _p(v), ctypes.byref(mp)))
+        self.mprod = int(mp.value)
+        return u, s, v
+
+
+def plan_shards(indptr, world: int) -> np.ndarray:
+    """nnz-balanced contiguous partition of the outer dimension."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.uint64)
+    bounds = np.zeros(world + 1, dtype=np.uint64)
+    _check(_lib.scanrs_plan_shards(_p(indptr), ctypes.c_uint64(indptr.shape[0] - 1), ctypes.c_uint32(world), _p(bounds)))
+    return bounds
+
+
+# host-side dense helpers (checked by the CPU test-suite)
+def host_chol_upper(g):
+    g = _f64(g).copy()
+    _check(_lib.scanrs_host_chol_upper(_p(g), ctypes.c_int(g.shape[0])))
+    return g
+
+
+def host_inv_upper(r):
+    r = _f64(r).copy()
+    _check(_lib.scanrs_host_inv_upper(_p(r), ctypes.c_int(r.shape[0])))
+    return r
+
+
+def host_sym_eig(a):
+    a = _f64(a)
+    n = a.shape[0]
+    w, z = np.zeros(n), np.zeros((n, n))
+    _check(_lib.scanrs_host_sym_eig(_p(a), ctypes.c_int(n), _p(w), _p(z)))
+    return w, z
+
+
+EXPORTED_SYMBOLS = [
+    "scanrs_last_error", "scanrs_device_available", "scanrs_version", "scanrs_mat_create", "scanrs_mat_create_device",
+    "scanrs_mat_free", "scanrs_mat_view", "scanrs_mat_t", "scanrs_mat_shape", "scanrs_mat_nnz", "scanrs_mat_storage",
+    "scanrs_mat_reset_map", "scanrs_mat_compose_scale_axis", "scanrs_mat_apply", "scanrs_mat_set_offset",
+    "scanrs_mat_center", "scanrs_mat_scale", "scanrs_mat_scale_and_center", "scanrs_mat_sum_axis_u32",
+    "scanrs_mat_sum_axis_f64", "scanrs_mat_mean_axis", "scanrs_mat_mean_var_axis", "scanrs_mat_to_dense",
+    "scanrs_mat_dot", "scanrs_mat_rdot", "scanrs_mat_dot_u32", "scanrs_mat_rdot_u32", "scanrs_mat_dot_device",
+    "scanrs_normalize", "scanrs_log_normalize", "scanrs_log1p_normalize_fixed_point", "scanrs_mat_target_umi",
+    "scanrs_pca_bk", "scanrs_pca_rand", "scanrs_pca_irlba", "scanrs_omega_fill", "scanrs_mat_set_shard",
+    "scanrs_plan_shards", "scanrs_profile_enable", "scanrs_profile_reset", "scanrs_profile_get", "scanrs_mat_sync",
+    "scanrs_host_chol_upper", "scanrs_host_inv_upper", "scanrs_host_sym_eig",
+]

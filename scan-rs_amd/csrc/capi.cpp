@@ -1,0 +1,966 @@
+// extern "C" boundary + operator-level host logic (the sqz::AdaptiveMat / LowRankOffset /
+// scan-rs::normalization surface). See include/scanrs_amd.h for the reference citations per entry point.
+#include <algorithm>
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+
+namespace scanrs {
+
+// ---- errors ---------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+void fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    throw Failure{code};
+}
+
+template <typename F>
+static int guard(F &&f) {
+    try {
+        f();
+        return SCANRS_OK;
+    } catch (const Failure &e) {
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        set_error("out of host memory");
+        return SCANRS_ERR_DEVICE;
+    } catch (const std::exception &e) {
+        set_error("internal error: %s", e.what());
+        return SCANRS_ERR_DEVICE;
+    }
+}
+
+static bool device_ok() {
+    static int cached = -1;
+    if (cached < 0) {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+            cached = 0;
+        } else {
+            hipDeviceProp_t p;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            cached = (hipGetDeviceProperties(&p, dev) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ? 1 : 0;
+        }
+    }
+    return cached == 1;
+}
+static void need_device() {
+    if (!device_ok())
+        fail(SCANRS_ERR_DEVICE, "no gfx950 (MI355X) device is usable from this process; scanrs_amd has no CPU fallback");
+}
+
+// ---- Profile -----------------------------------------------------------------------------------
+hipEvent_t Profile::take() {
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    SCANRS_HIP(hipEventCreate(&e));
+    return e;
+}
+void Profile::begin(hipStream_t s, const char *name, double bytes) {
+    Rec r{name, take(), take(), bytes};
+    SCANRS_HIP(hipEventRecord(r.a, s));
+    pending.push_back(r);
+}
+void Profile::end(hipStream_t s) {
+    if (pending.empty()) return;
+    (void)hipEventRecord(pending.back().b, s);
+}
+void Profile::resolve() {
+    for (auto &r : pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto &st = stats[r.name];
+            st.launches++;
+            st.ms += ms;
+            st.bytes += r.bytes;
+        }
+        pool.push_back(r.a);
+        pool.push_back(r.b);
+    }
+    pending.clear();
+}
+void Profile::reset() {
+    resolve();
+    stats.clear();
+}
+Profile::~Profile() {
+    for (auto &r : pending) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : pool) (void)hipEventDestroy(e);
+}
+
+// ---- Storage -------------------------------------------------------------------------------------
+Storage::~Storage() {
+    if (stream) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipStreamDestroy(stream);
+    }
+}
+SparseCopy &Storage::copy_with_outer_rows(bool outer_rows) {
+    const bool primary_outer_rows = storage == SCANRS_CSR;
+    if (outer_rows == primary_outer_rows) return primary;
+    if (!has_other) {
+        build_transposed_copy(*this, primary, other);
+        has_other = true;
+    }
+    return other;
+}
+
+void allreduce_f64(Storage &st, double *d, uint64_t count) {
+    if (!st.shard.active()) return;
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    if (st.shard.allreduce(st.shard.ctx, d, count, 0) != 0) fail(SCANRS_ERR_DEVICE, "all-reduce callback failed");
+}
+void allreduce_u64(Storage &st, unsigned long long *d, uint64_t count) {
+    if (!st.shard.active()) return;
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    if (st.shard.allreduce(st.shard.ctx, d, count, 1) != 0) fail(SCANRS_ERR_DEVICE, "all-reduce callback failed");
+}
+// primary's outer dimension is the sharded one: base rows when CSR, base cols when CSC
+static bool base_rows_sharded(const Storage &st) { return st.shard.active() && st.storage == SCANRS_CSR; }
+static bool base_cols_sharded(const Storage &st) { return st.shard.active() && st.storage == SCANRS_CSC; }
+bool rows_sharded(const scanrs_mat *m) { return m->transposed ? base_cols_sharded(*m->st) : base_rows_sharded(*m->st); }
+bool cols_sharded(const scanrs_mat *m) { return m->transposed ? base_rows_sharded(*m->st) : base_cols_sharded(*m->st); }
+
+} // namespace scanrs
+
+using namespace scanrs;
+
+// ---- map translation ---------------------------------------------------------------------------------
+DevMap scanrs_mat::dev_map(bool outer_is_view_row) const {
+    DevMap dm;
+    memset(&dm, 0, sizeof(dm));
+    int n = 0;
+    for (const auto &op : ops) {
+        if (op.kind == OP_INTO) continue;
+        if (n >= MAX_OPS) fail(SCANRS_ERR_ARGUMENT, "map chain longer than %d links", MAX_OPS);
+        DevOp &d = dm.ops[n++];
+        d.kind = op.kind;
+        d.a = op.a ? op.a->p : nullptr;
+        d.b = op.b ? op.b->p : nullptr;
+        if (op.kind == OP_SCALE_AXIS) {
+            // ScaleAxis wants r_op (axis 0) or c_op (axis 1); (r_op, c_op) = swap ? (c_v, r_v) : (r_v, c_v)
+            const bool wants_view_row = (op.axis == 0) != op.swap;
+            d.a_outer = wants_view_row == outer_is_view_row ? 1 : 0;
+        } else if (op.kind == OP_BINOM_DEV || op.kind == OP_BINOM_PEARSON) {
+            // a = n[c_op], b = pi[r_op]
+            const bool a_wants_view_row = op.swap;
+            d.a_outer = a_wants_view_row == outer_is_view_row ? 1 : 0;
+            d.b_outer = 1 - d.a_outer;
+        }
+    }
+    dm.n = n;
+    return dm;
+}
+
+namespace scanrs {
+
+static bool map_is_raw(const scanrs_mat *m) {
+    for (const auto &op : m->ops)
+        if (op.kind != OP_INTO) return false;
+    return true;
+}
+
+// the copy whose outer dimension is the view's rows (true) or cols (false)
+static SparseCopy &copy_outer_view_rows(scanrs_mat *m, bool view_rows) {
+    return m->st->copy_with_outer_rows(view_rows != m->transposed);
+}
+
+void mat_apply(scanrs_mat *m, bool transpose, const double *dX, uint32_t ldx, uint32_t l, double *dOut, uint32_t ldo) {
+    Storage &st = *m->st;
+    const bool outer_is_view_row = !transpose;
+    SparseCopy &cp = copy_outer_view_rows(m, outer_is_view_row);
+    const DevMap map = m->dev_map(outer_is_view_row);
+    const double *off_a = nullptr, *off_w = nullptr;
+    uint32_t ldw = 0;
+    if (m->off_rank) {
+        // A R = mat R + u (v R);  A^T Y = mat^T Y + v^T (u^T Y)   (sqz/src/low_rank_offset.rs:76-95)
+        const double *B = transpose ? m->off_u->p : m->off_v->p; // n_in x rank
+        off_a = transpose ? m->off_v->p : m->off_u->p;           // n_out x rank
+        ldw = even_up(l);
+        double *w = st.scratch.get<double>("off_w", (size_t)m->off_rank * ldw);
+        launch_weighted_colsum(st, B, m->off_rank, dX, ldx, cp.n_inner, l, w, ldw);
+        off_w = w;
+    }
+    launch_spmm_f64(st, cp, map, dX, ldx, l, dOut, ldo, off_a, m->off_rank, off_w, ldw);
+    // contraction over the sharded dimension -> partial sums on every rank
+    const bool contraction_sharded = transpose ? rows_sharded(m) : cols_sharded(m);
+    if (contraction_sharded) allreduce_f64(st, dOut, (uint64_t)cp.n_outer * ldo);
+}
+
+static std::shared_ptr<DevBuf<double>> upload_vec(Storage &st, const double *h, size_t n) {
+    auto b = std::make_shared<DevBuf<double>>(std::max<size_t>(n, 1));
+    if (n) SCANRS_HIP(hipMemcpyAsync(b->p, h, n * 8, hipMemcpyHostToDevice, st.stream));
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    return b;
+}
+
+static void create_common(uint64_t rows, uint64_t cols, int storage, const uint64_t *indptr, const uint32_t *indices,
+                          const uint32_t *values, bool device_src, scanrs_mat **out) {
+    if (!out) fail(SCANRS_ERR_ARGUMENT, "null output handle");
+    *out = nullptr;
+    need_device();
+    if (storage != SCANRS_CSR && storage != SCANRS_CSC) fail(SCANRS_ERR_ARGUMENT, "storage must be 0 (CSR) or 1 (CSC)");
+    if (!indptr) fail(SCANRS_ERR_ARGUMENT, "null indptr");
+    if (rows > 0xFFFFFFFFull || cols > 0xFFFFFFFFull) fail(SCANRS_ERR_SHAPE, "dimensions must fit in u32 (AdaptiveVec limit)");
+    auto st = std::make_shared<Storage>();
+    st->rows = rows;
+    st->cols = cols;
+    st->storage = storage;
+    SCANRS_HIP(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+    SparseCopy &cp = st->primary;
+    cp.n_outer = storage == SCANRS_CSR ? rows : cols;
+    cp.n_inner = storage == SCANRS_CSR ? cols : rows;
+    const hipMemcpyKind kind = device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    cp.indptr.alloc(cp.n_outer + 1);
+    SCANRS_HIP(hipMemcpy(cp.indptr.p, indptr, (cp.n_outer + 1) * 8, kind));
+    uint64_t first = 0, last = 0;
+    SCANRS_HIP(hipMemcpy(&first, cp.indptr.p, 8, hipMemcpyDeviceToHost));
+    SCANRS_HIP(hipMemcpy(&last, cp.indptr.p + cp.n_outer, 8, hipMemcpyDeviceToHost));
+    if (first != 0) fail(SCANRS_ERR_ARGUMENT, "indptr[0] must be 0");
+    cp.nnz = last;
+    if (cp.nnz && (!indices || !values)) fail(SCANRS_ERR_ARGUMENT, "null indices/values");
+    cp.indices.alloc(std::max<uint64_t>(1, cp.nnz));
+    cp.values.alloc(std::max<uint64_t>(1, cp.nnz));
+    if (cp.nnz) {
+        SCANRS_HIP(hipMemcpy(cp.indices.p, indices, cp.nnz * 4, kind));
+        SCANRS_HIP(hipMemcpy(cp.values.p, values, cp.nnz * 4, kind));
+    }
+    uint64_t zeros = 0, bad = 0;
+    validate_copy(*st, cp, &zeros, &bad);
+    if (bad) fail(SCANRS_ERR_ARGUMENT, "indices must be in range and strictly ascending within each outer vector (%llu violations)", (unsigned long long)bad);
+    if (zeros) compact_nonzeros(*st, cp);
+    cp.build_items(st->stream);
+    auto *m = new scanrs_mat();
+    m->st = st;
+    *out = m;
+}
+
+// radix select of the k-th smallest (0-based, global rank) of a u32 device array spread over ranks
+static uint32_t select_kth(Storage &st, const uint32_t *d, uint64_t n_local, uint64_t kth) {
+    unsigned long long *hist = st.scratch.get<unsigned long long>("select_hist", 4096);
+    std::vector<unsigned long long> h(4096);
+    uint32_t prefix = 0, mask = 0;
+    const uint32_t shifts[3] = {20, 8, 0};
+    const uint32_t bits[3] = {12, 12, 8};
+    for (int pass = 0; pass < 3; pass++) {
+        launch_hist12(st, d, n_local, shifts[pass], mask, prefix, hist);
+        allreduce_u64(st, hist, 4096);
+        SCANRS_HIP(hipMemcpyAsync(h.data(), hist, 4096 * 8, hipMemcpyDeviceToHost, st.stream));
+        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        const uint32_t nb = 1u << bits[pass];
+        uint32_t bin = 0;
+        for (; bin < nb; bin++) {
+            if (kth < h[bin]) break;
+            kth -= h[bin];
+        }
+        if (bin == nb) fail(SCANRS_ERR_NUMERICAL, "median selection ran past the histogram");
+        prefix |= bin << shifts[pass];
+        mask |= (nb - 1u) << shifts[pass];
+    }
+    return prefix;
+}
+
+// median_mut (scan-rs/src/stats.rs:13-38) of a distributed u32 array; n = global count
+static bool median_u32(Storage &st, const uint32_t *d, uint64_t n_local, uint64_t n_global, uint32_t *out) {
+    if (n_global == 0) return false;
+    if (n_global % 2 == 0) {
+        const uint32_t hi = select_kth(st, d, n_local, n_global / 2);
+        const uint32_t lo = select_kth(st, d, n_local, n_global / 2 - 1);
+        *out = (uint32_t)(hi + lo) / 2u; // integer midpoint in T = u32 (wrapping add as rustc release)
+    } else {
+        *out = select_kth(st, d, n_local, n_global / 2);
+    }
+    return true;
+}
+
+static void log_normalize_impl(scanrs_mat *m, double umi_count_sum, int log_fn, const uint32_t *size_factors) {
+    // log_normalize_with_size_factor, scan-rs/src/normalization.rs:138-178
+    if (!map_is_raw(m) || m->off_rank) fail(SCANRS_ERR_ARGUMENT, "log_normalize needs the raw count matrix (AdaptiveMat<u32>)");
+    if (log_fn != OP_LN_1P && log_fn != OP_LOG2_1P && log_fn != OP_LOG10_1P) fail(SCANRS_ERR_ARGUMENT, "bad log base");
+    if (rows_sharded(m)) fail(SCANRS_ERR_ARGUMENT, "normalisation needs the barcode (column) dimension to be the sharded one");
+    Storage &st = *m->st;
+    const uint64_t ncols = m->cols();
+    SparseCopy &cp = copy_outer_view_rows(m, false); // outer = view cols (barcodes)
+    DevMap raw;
+    memset(&raw, 0, sizeof(raw));
+    uint32_t *counts = st.scratch.get<uint32_t>("norm_counts", std::max<uint64_t>(1, ncols));
+    launch_row_reduce(st, cp, raw, 0, counts, nullptr, nullptr); // matrix.sum_axis(Axis(0)) :159,161
+    double target;
+    if (umi_count_sum >= 0.0) {
+        target = umi_count_sum;
+    } else {
+        const uint64_t n_global = cols_sharded(m) ? st.shard.outer_global : ncols;
+        uint32_t med = 0;
+        target = median_u32(st, counts, ncols, n_global, &med) ? std::max((double)med, 1.0) : 1.0; // :162-168
+    }
+    m->target_umi = target;
+    const uint32_t *norm_counts = counts;
+    if (size_factors) {
+        uint32_t *sf = st.scratch.get<uint32_t>("norm_sf", std::max<uint64_t>(1, ncols));
+        if (ncols) SCANRS_HIP(hipMemcpyAsync(sf, size_factors, ncols * 4, hipMemcpyHostToDevice, st.stream));
+        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        norm_counts = sf;
+    }
+    auto scales = std::make_shared<DevBuf<double>>(std::max<uint64_t>(1, ncols));
+    launch_u32_to_scale(st, norm_counts, ncols, target, scales->p); // col_scales :169
+    MapOp sc;
+    sc.kind = OP_SCALE_AXIS;
+    sc.axis = 1;
+    sc.a = scales;
+    m->ops.push_back(sc); // compose_map(scale_cols)
+    MapOp lg;
+    lg.kind = log_fn;
+    m->ops.push_back(lg); // .apply(log1p_fn) :177
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+}
+
+// per-`axis` sums of mapped values: axis 1 -> per view row, axis 0 -> per view col; reduced across ranks
+// when the summed-over dimension is sharded.
+static void axis_sums(scanrs_mat *m, int axis, int mode, double *d_sum, double *d_sumsq) {
+    Storage &st = *m->st;
+    const bool outer_view_rows = axis == 1;
+    SparseCopy &cp = copy_outer_view_rows(m, outer_view_rows);
+    const DevMap map = m->dev_map(outer_view_rows);
+    launch_row_reduce(st, cp, map, mode, nullptr, d_sum, d_sumsq);
+    const bool contraction_sharded = outer_view_rows ? cols_sharded(m) : rows_sharded(m);
+    if (contraction_sharded) {
+        allreduce_f64(st, d_sum, cp.n_outer);
+        if (mode == 2) allreduce_f64(st, d_sumsq, cp.n_outer);
+    }
+}
+// shape()[axis] as the reference's mean_axis divides by (sqz/src/mat.rs:274), global when sharded
+static double axis_extent(const scanrs_mat *m, int axis) {
+    const bool sharded = axis == 0 ? rows_sharded(m) : cols_sharded(m);
+    if (sharded) return (double)m->st->shard.outer_global;
+    return (double)(axis == 0 ? m->rows() : m->cols());
+}
+
+static void set_offset_dev(scanrs_mat *m, uint32_t rank, std::shared_ptr<DevBuf<double>> u_rows_by_rank,
+                           std::shared_ptr<DevBuf<double>> v_cols_by_rank) {
+    m->off_rank = rank;
+    m->off_u = std::move(u_rows_by_rank);
+    m->off_v = std::move(v_cols_by_rank);
+}
+
+static void scale_and_center_impl(scanrs_mat *m, int axis, const double *given_scaling) {
+    // sqz/src/mat.rs:986-1001
+    if (axis != 0 && axis != 1) fail(SCANRS_ERR_ARGUMENT, "axis must be 0 or 1");
+    if (m->off_rank) fail(SCANRS_ERR_ARGUMENT, "matrix already carries a low-rank offset");
+    Storage &st = *m->st;
+    const uint64_t n = axis == 1 ? m->rows() : m->cols();     // number of slices
+    const uint64_t other = axis == 1 ? m->cols() : m->rows(); // local length of each slice
+    double *sum = st.scratch.get<double>("mom_sum", std::max<uint64_t>(1, n));
+    double *sumsq = st.scratch.get<double>("mom_sumsq", std::max<uint64_t>(1, n));
+    axis_sums(m, axis, given_scaling ? 1 : 2, sum, sumsq);
+    double *scale_in = nullptr;
+    if (given_scaling) {
+        scale_in = st.scratch.get<double>("mom_scale_in", std::max<uint64_t>(1, n));
+        if (n) SCANRS_HIP(hipMemcpyAsync(scale_in, given_scaling, n * 8, hipMemcpyHostToDevice, st.stream));
+        SCANRS_HIP(hipStreamSynchronize(st.stream));
+    }
+    auto neg = std::make_shared<DevBuf<double>>(std::max<uint64_t>(1, n));
+    auto inv = std::make_shared<DevBuf<double>>(std::max<uint64_t>(1, n));
+    launch_finish_moments(st, sum, sumsq, n, axis_extent(m, axis), given_scaling ? 1 : 0, scale_in, neg->p, inv->p, nullptr);
+    MapOp sc; // scale(axis, Some(s)): ScaleAxis(Axis(1 - axis), 1/s)
+    sc.kind = OP_SCALE_AXIS;
+    sc.axis = 1 - axis;
+    sc.a = inv;
+    m->ops.push_back(sc);
+    auto ones = std::make_shared<DevBuf<double>>(std::max<uint64_t>(1, other));
+    launch_fill_f64(st, ones->p, other, 1.0);
+    // center(axis, Some(means)): axis 1 -> u = -means (rows x 1), v = 1; axis 0 -> u = 1, v = -means
+    if (axis == 1)
+        set_offset_dev(m, 1, neg, ones);
+    else
+        set_offset_dev(m, 1, ones, neg);
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+}
+
+static void binom_impl(scanrs_mat *m, int kind) {
+    // binom_deviance_resid / binom_pearson_resid, scan-rs/src/normalization.rs:232-322
+    if (!map_is_raw(m) || m->off_rank) fail(SCANRS_ERR_ARGUMENT, "binomial residuals need the raw count matrix");
+    if (rows_sharded(m)) fail(SCANRS_ERR_ARGUMENT, "normalisation needs the barcode (column) dimension to be the sharded one");
+    Storage &st = *m->st;
+    const uint64_t R = m->rows(), C = m->cols();
+    auto n = std::make_shared<DevBuf<double>>(std::max<uint64_t>(1, C));
+    auto pi = std::make_shared<DevBuf<double>>(std::max<uint64_t>(1, R));
+    auto u = std::make_shared<DevBuf<double>>(std::max<uint64_t>(1, R));
+    auto v = std::make_shared<DevBuf<double>>(std::max<uint64_t>(1, C));
+    double *rowsum = st.scratch.get<double>("binom_rowsum", std::max<uint64_t>(1, R));
+    double *tot = st.scratch.get<double>("binom_total", 1);
+    axis_sums(m, 0, 1, n->p, nullptr);  // n = sum_axis::<f64>(Axis(0))
+    axis_sums(m, 1, 1, rowsum, nullptr); // sum_axis::<f64>(Axis(1))
+    launch_sum_f64(st, n->p, C, tot);
+    if (cols_sharded(m)) allreduce_f64(st, tot, 1);
+    double total = 0.0;
+    SCANRS_HIP(hipMemcpyAsync(&total, tot, 8, hipMemcpyDeviceToHost, st.stream));
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    launch_binom_uv(st, kind, n->p, C, rowsum, R, total, pi->p, u->p, v->p);
+    MapOp op;
+    op.kind = kind;
+    op.a = n;
+    op.b = pi;
+    m->ops.clear();
+    m->ops.push_back(op); // matrix.set_map(dev_resid_map)
+    set_offset_dev(m, 1, u, v);
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+}
+
+} // namespace scanrs
+
+// =================================================================================================
+extern "C" {
+
+const char *scanrs_last_error(void) { return g_err; }
+int scanrs_device_available(void) {
+    try {
+        return device_ok() ? 1 : 0;
+    } catch (...) {
+        return 0;
+    }
+}
+const char *scanrs_version(void) { return "scanrs_amd 0.1.0 (gfx950)"; }
+
+int scanrs_mat_create(uint64_t rows, uint64_t cols, int storage, const uint64_t *indptr, const uint32_t *indices,
+                      const uint32_t *values, scanrs_mat **out) {
+    return guard([&] { create_common(rows, cols, storage, indptr, indices, values, false, out); });
+}
+int scanrs_mat_create_device(uint64_t rows, uint64_t cols, int storage, const uint64_t *d_indptr, const uint32_t *d_indices,
+                             const uint32_t *d_values, scanrs_mat **out) {
+    return guard([&] { create_common(rows, cols, storage, d_indptr, d_indices, d_values, true, out); });
+}
+void scanrs_mat_free(scanrs_mat *m) { delete m; }
+
+int scanrs_mat_view(const scanrs_mat *m, scanrs_mat **out) {
+    return guard([&] {
+        if (!m || !out) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        *out = new scanrs_mat(*m);
+    });
+}
+int scanrs_mat_t(const scanrs_mat *m, scanrs_mat **out) {
+    return guard([&] {
+        if (!m || !out) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        auto *t = new scanrs_mat(*m);
+        t->transposed = !m->transposed;
+        for (auto &op : t->ops) op.swap = !op.swap; // TransposeMap (matrix_map.rs:42-80)
+        std::swap(t->off_u, t->off_v);              // LowRankOffset::t (low_rank_offset.rs:60-65)
+        *out = t;
+    });
+}
+int scanrs_mat_shape(const scanrs_mat *m, uint64_t *rows, uint64_t *cols) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        if (rows) *rows = m->rows();
+        if (cols) *cols = m->cols();
+    });
+}
+int scanrs_mat_nnz(const scanrs_mat *m, uint64_t *nnz) {
+    return guard([&] {
+        if (!m || !nnz) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        *nnz = m->st->primary.nnz;
+    });
+}
+int scanrs_mat_storage(const scanrs_mat *m, int *storage) {
+    return guard([&] {
+        if (!m || !storage) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        *storage = m->transposed ? 1 - m->st->storage : m->st->storage;
+    });
+}
+
+int scanrs_mat_reset_map(scanrs_mat *m) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        m->ops.clear();
+        m->off_rank = 0;
+        m->off_u.reset();
+        m->off_v.reset();
+    });
+}
+int scanrs_mat_compose_scale_axis(scanrs_mat *m, int axis, const double *factors) {
+    return guard([&] {
+        if (!m || !factors) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        if (axis != 0 && axis != 1) fail(SCANRS_ERR_ARGUMENT, "Only implemented for 2D arrays.");
+        if (m->off_rank) fail(SCANRS_ERR_ARGUMENT, "cannot compose a map onto a LowRankOffset");
+        MapOp op;
+        op.kind = OP_SCALE_AXIS;
+        op.axis = axis;
+        op.a = upload_vec(*m->st, factors, axis == 0 ? m->rows() : m->cols());
+        m->ops.push_back(op);
+    });
+}
+int scanrs_mat_apply(scanrs_mat *m, int scalar_fn) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        if (scalar_fn < OP_LN_1P || scalar_fn > OP_SQUARE) fail(SCANRS_ERR_ARGUMENT, "unknown scalar map");
+        if (m->off_rank) fail(SCANRS_ERR_ARGUMENT, "cannot compose a map onto a LowRankOffset");
+        MapOp op;
+        op.kind = scalar_fn;
+        m->ops.push_back(op);
+    });
+}
+int scanrs_mat_set_offset(scanrs_mat *m, uint32_t rank, const double *u, const double *v) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        if (rank == 0) {
+            set_offset_dev(m, 0, nullptr, nullptr);
+            return;
+        }
+        if (!u || !v) fail(SCANRS_ERR_ARGUMENT, "null offset factors");
+        const uint64_t R = m->rows(), C = m->cols();
+        std::vector<double> vt((size_t)C * rank); // v is rank x cols; keep cols x rank on the device
+        for (uint32_t q = 0; q < rank; q++)
+            for (uint64_t c = 0; c < C; c++) vt[c * rank + q] = v[(size_t)q * C + c];
+        set_offset_dev(m, rank, upload_vec(*m->st, u, (size_t)R * rank), upload_vec(*m->st, vt.data(), vt.size()));
+    });
+}
+
+static void host_axis_sums(scanrs_mat *m, int axis, int mode, std::vector<double> &s, std::vector<double> &s2) {
+    if (axis != 0 && axis != 1) fail(SCANRS_ERR_ARGUMENT, "axis must be 0 or 1");
+    Storage &st = *m->st;
+    const uint64_t n = axis == 1 ? m->rows() : m->cols();
+    double *sum = st.scratch.get<double>("mom_sum", std::max<uint64_t>(1, n));
+    double *sumsq = st.scratch.get<double>("mom_sumsq", std::max<uint64_t>(1, n));
+    axis_sums(m, axis, mode, sum, sumsq);
+    s.resize(n);
+    if (n) SCANRS_HIP(hipMemcpyAsync(s.data(), sum, n * 8, hipMemcpyDeviceToHost, st.stream));
+    if (mode == 2) {
+        s2.resize(n);
+        if (n) SCANRS_HIP(hipMemcpyAsync(s2.data(), sumsq, n * 8, hipMemcpyDeviceToHost, st.stream));
+    }
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+}
+
+int scanrs_mat_center(scanrs_mat *m, int axis, const double *given_means) {
+    return guard([&] { // sqz/src/mat.rs:937-962
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        if (axis != 0 && axis != 1) fail(SCANRS_ERR_ARGUMENT, "axis must be 0 or 1");
+        if (m->off_rank) fail(SCANRS_ERR_ARGUMENT, "matrix already carries a low-rank offset");
+        const uint64_t n = axis == 1 ? m->rows() : m->cols(), other = axis == 1 ? m->cols() : m->rows();
+        std::vector<double> neg(n), s, s2;
+        if (given_means) {
+            for (uint64_t i = 0; i < n; i++) neg[i] = -given_means[i];
+        } else {
+            host_axis_sums(m, axis, 1, s, s2);
+            const double ext = axis_extent(m, axis);
+            for (uint64_t i = 0; i < n; i++) neg[i] = -(s[i] / ext);
+        }
+        std::vector<double> ones(other, 1.0);
+        auto dn = upload_vec(*m->st, neg.data(), n), d1 = upload_vec(*m->st, ones.data(), other);
+        if (axis == 1)
+            set_offset_dev(m, 1, dn, d1);
+        else
+            set_offset_dev(m, 1, d1, dn);
+    });
+}
+int scanrs_mat_scale(scanrs_mat *m, int axis, const double *given_std) {
+    return guard([&] { // sqz/src/mat.rs:966-981
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        if (axis != 0 && axis != 1) fail(SCANRS_ERR_ARGUMENT, "axis must be 0 or 1");
+        if (m->off_rank) fail(SCANRS_ERR_ARGUMENT, "cannot compose a map onto a LowRankOffset");
+        const uint64_t n = axis == 1 ? m->rows() : m->cols();
+        std::vector<double> f(n), s, s2;
+        if (given_std) {
+            for (uint64_t i = 0; i < n; i++) f[i] = 1.0 / given_std[i];
+        } else {
+            host_axis_sums(m, axis, 2, s, s2);
+            const double ext = axis_extent(m, axis);
+            for (uint64_t i = 0; i < n; i++) {
+                const double mean = s[i] / ext;
+                const double d = s2[i] / ext - mean * mean;
+                f[i] = d == 0.0 ? 1.0 : 1.0 / std::sqrt(d);
+            }
+        }
+        MapOp op;
+        op.kind = OP_SCALE_AXIS;
+        op.axis = 1 - axis;
+        op.a = upload_vec(*m->st, f.data(), n);
+        m->ops.push_back(op);
+    });
+}
+int scanrs_mat_scale_and_center(scanrs_mat *m, int axis, const double *given_scaling) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        scale_and_center_impl(m, axis, given_scaling);
+    });
+}
+
+int scanrs_mat_sum_axis_u32(scanrs_mat *m, int axis, uint32_t *out) {
+    return guard([&] {
+        if (!m || !out) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        if (axis != 0 && axis != 1) fail(SCANRS_ERR_ARGUMENT, "axis must be 0 or 1");
+        if (!map_is_raw(m)) fail(SCANRS_ERR_ARGUMENT, "u32 sums are defined on the raw count matrix");
+        Storage &st = *m->st;
+        if (st.shard.active() && (axis == 1 ? cols_sharded(m) : rows_sharded(m)))
+            fail(SCANRS_ERR_ARGUMENT, "u32 sums over the sharded dimension are not supported");
+        SparseCopy &cp = copy_outer_view_rows(m, axis == 1);
+        DevMap raw;
+        memset(&raw, 0, sizeof(raw));
+        uint32_t *d = st.scratch.get<uint32_t>("sum_u32", std::max<uint64_t>(1, cp.n_outer));
+        launch_row_reduce(st, cp, raw, 0, d, nullptr, nullptr);
+        if (cp.n_outer) SCANRS_HIP(hipMemcpyAsync(out, d, cp.n_outer * 4, hipMemcpyDeviceToHost, st.stream));
+        SCANRS_HIP(hipStreamSynchronize(st.stream));
+    });
+}
+int scanrs_mat_sum_axis_f64(scanrs_mat *m, int axis, double *out) {
+    return guard([&] {
+        if (!m || !out) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        std::vector<double> s, s2;
+        host_axis_sums(m, axis, 1, s, s2);
+        if (!s.empty()) memcpy(out, s.data(), s.size() * 8);
+    });
+}
+int scanrs_mat_mean_axis(scanrs_mat *m, int axis, double *out) {
+    return guard([&] {
+        if (!m || !out) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        std::vector<double> s, s2;
+        host_axis_sums(m, axis, 1, s, s2);
+        const double ext = axis_extent(m, axis);
+        for (size_t i = 0; i < s.size(); i++) out[i] = s[i] / ext;
+    });
+}
+int scanrs_mat_mean_var_axis(scanrs_mat *m, int axis, double *mean, double *var) {
+    return guard([&] { // sqz/src/mat.rs:285-330
+        if (!m || !mean || !var) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        std::vector<double> s, s2;
+        host_axis_sums(m, axis, 2, s, s2);
+        const double ext = axis_extent(m, axis);
+        for (size_t i = 0; i < s.size(); i++) {
+            mean[i] = s[i] / ext;
+            var[i] = s2[i] / ext - mean[i] * mean[i];
+        }
+    });
+}
+
+int scanrs_mat_to_dense(scanrs_mat *m, double *out) {
+    return guard([&] {
+        if (!m || !out) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        Storage &st = *m->st;
+        const uint64_t R = m->rows(), C = m->cols();
+        if (R * C == 0) return;
+        double *d = st.scratch.get<double>("dense", R * C);
+        SCANRS_HIP(hipMemsetAsync(d, 0, R * C * 8, st.stream));
+        SparseCopy &cp = copy_outer_view_rows(m, true);
+        launch_densify(st, cp, m->dev_map(true), true, C, d);
+        SCANRS_HIP(hipMemcpyAsync(out, d, R * C * 8, hipMemcpyDeviceToHost, st.stream));
+        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        if (m->off_rank) { // u.dot(&v) + mat  (low_rank_offset.rs:55-57)
+            std::vector<double> u((size_t)R * m->off_rank), vt((size_t)C * m->off_rank);
+            SCANRS_HIP(hipMemcpy(u.data(), m->off_u->p, u.size() * 8, hipMemcpyDeviceToHost));
+            SCANRS_HIP(hipMemcpy(vt.data(), m->off_v->p, vt.size() * 8, hipMemcpyDeviceToHost));
+            for (uint64_t r = 0; r < R; r++)
+                for (uint64_t c = 0; c < C; c++) {
+                    double acc = 0.0;
+                    for (uint32_t q = 0; q < m->off_rank; q++) acc += u[r * m->off_rank + q] * vt[c * m->off_rank + q];
+                    out[r * C + c] = acc + out[r * C + c];
+                }
+        }
+    });
+}
+
+// ---- products -----------------------------------------------------------------------------------------------
+static void dot_host(scanrs_mat *m, bool transpose, const double *h_in, uint32_t l, double *h_out, bool in_is_l_by_n) {
+    // transpose = false: out[rows x l] = A * in[cols x l].   transpose = true (rdot): lhs is l x rows, out is l x cols:
+    // computed as (A^T lhs^T)^T exactly like ArrayBase::dot(&AdaptiveMat) (sqz/src/mat.rs:1124-1132).
+    Storage &st = *m->st;
+    const uint64_t n_in = transpose ? m->rows() : m->cols();
+    const uint64_t n_out = transpose ? m->cols() : m->rows();
+    if (l == 0) return;
+    const uint32_t ld = even_up(l);
+    double *dX = st.scratch.get<double>("dot_in", std::max<uint64_t>(1, n_in) * ld);
+    double *dY = st.scratch.get<double>("dot_out", std::max<uint64_t>(1, n_out) * ld);
+    SCANRS_HIP(hipMemsetAsync(dX, 0, std::max<uint64_t>(1, n_in) * ld * 8, st.stream));
+    std::vector<double> tmp;
+    const double *src = h_in;
+    if (in_is_l_by_n) {
+        tmp.resize((size_t)n_in * l);
+        for (uint32_t i = 0; i < l; i++)
+            for (uint64_t j = 0; j < n_in; j++) tmp[j * l + i] = h_in[(size_t)i * n_in + j];
+        src = tmp.data();
+    }
+    if (n_in)
+        SCANRS_HIP(hipMemcpy2DAsync(dX, (size_t)ld * 8, src, (size_t)l * 8, (size_t)l * 8, n_in, hipMemcpyHostToDevice, st.stream));
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    mat_apply(m, transpose, dX, ld, l, dY, ld);
+    std::vector<double> res((size_t)n_out * l);
+    if (n_out)
+        SCANRS_HIP(hipMemcpy2DAsync(res.data(), (size_t)l * 8, dY, (size_t)ld * 8, (size_t)l * 8, n_out, hipMemcpyDeviceToHost, st.stream));
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    if (in_is_l_by_n) {
+        for (uint64_t j = 0; j < n_out; j++)
+            for (uint32_t i = 0; i < l; i++) h_out[(size_t)i * n_out + j] = res[j * l + i];
+    } else if (!res.empty()) {
+        memcpy(h_out, res.data(), res.size() * 8);
+    }
+}
+
+int scanrs_mat_dot(scanrs_mat *m, const double *rhs, uint32_t l, double *out) {
+    return guard([&] {
+        if (!m || (!rhs && l) || (!out && l)) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        dot_host(m, false, rhs, l, out, false);
+    });
+}
+int scanrs_mat_rdot(scanrs_mat *m, const double *lhs, uint32_t l, double *out) {
+    return guard([&] {
+        if (!m || (!lhs && l) || (!out && l)) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        dot_host(m, true, lhs, l, out, true);
+    });
+}
+
+static void dot_host_u32(scanrs_mat *m, bool transpose, const uint32_t *h_in, uint32_t l, uint32_t *h_out) {
+    if (!map_is_raw(m) || m->off_rank) fail(SCANRS_ERR_ARGUMENT, "u32 products are defined on the raw count matrix");
+    Storage &st = *m->st;
+    if (st.shard.active()) fail(SCANRS_ERR_ARGUMENT, "u32 products are not sharded");
+    const uint64_t n_in = transpose ? m->rows() : m->cols();
+    const uint64_t n_out = transpose ? m->cols() : m->rows();
+    if (l == 0) return;
+    const uint32_t ld = even_up(l);
+    uint32_t *dX = st.scratch.get<uint32_t>("dotu_in", std::max<uint64_t>(1, n_in) * ld);
+    uint32_t *dY = st.scratch.get<uint32_t>("dotu_out", std::max<uint64_t>(1, n_out) * ld);
+    SCANRS_HIP(hipMemsetAsync(dX, 0, std::max<uint64_t>(1, n_in) * ld * 4, st.stream));
+    std::vector<uint32_t> tmp;
+    const uint32_t *src = h_in;
+    if (transpose) {
+        tmp.resize((size_t)n_in * l);
+        for (uint32_t i = 0; i < l; i++)
+            for (uint64_t j = 0; j < n_in; j++) tmp[j * l + i] = h_in[(size_t)i * n_in + j];
+        src = tmp.data();
+    }
+    if (n_in)
+        SCANRS_HIP(hipMemcpy2DAsync(dX, (size_t)ld * 4, src, (size_t)l * 4, (size_t)l * 4, n_in, hipMemcpyHostToDevice, st.stream));
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SparseCopy &cp = copy_outer_view_rows(m, !transpose);
+    launch_spmm_u32(st, cp, dX, ld, l, dY, ld);
+    std::vector<uint32_t> res((size_t)n_out * l);
+    if (n_out)
+        SCANRS_HIP(hipMemcpy2DAsync(res.data(), (size_t)l * 4, dY, (size_t)ld * 4, (size_t)l * 4, n_out, hipMemcpyDeviceToHost, st.stream));
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    if (transpose) {
+        for (uint64_t j = 0; j < n_out; j++)
+            for (uint32_t i = 0; i < l; i++) h_out[(size_t)i * n_out + j] = res[j * l + i];
+    } else if (!res.empty()) {
+        memcpy(h_out, res.data(), res.size() * 4);
+    }
+}
+int scanrs_mat_dot_u32(scanrs_mat *m, const uint32_t *rhs, uint32_t l, uint32_t *out) {
+    return guard([&] {
+        if (!m || (!rhs && l) || (!out && l)) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        dot_host_u32(m, false, rhs, l, out);
+    });
+}
+int scanrs_mat_rdot_u32(scanrs_mat *m, const uint32_t *lhs, uint32_t l, uint32_t *out) {
+    return guard([&] {
+        if (!m || (!lhs && l) || (!out && l)) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        dot_host_u32(m, true, lhs, l, out);
+    });
+}
+int scanrs_mat_dot_device(scanrs_mat *m, int transpose, const double *d_rhs, uint32_t ld_rhs, uint32_t l, double *d_out,
+                          uint32_t ld_out) {
+    return guard([&] {
+        if (!m || !d_rhs || !d_out) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        mat_apply(m, transpose != 0, d_rhs, ld_rhs, l, d_out, ld_out);
+    });
+}
+
+// ---- normalization -------------------------------------------------------------------------------------------
+int scanrs_log_normalize(scanrs_mat *m, double umi_count_sum, int log_fn, const uint32_t *size_factors) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        log_normalize_impl(m, umi_count_sum, log_fn, size_factors);
+    });
+}
+int scanrs_log1p_normalize_fixed_point(scanrs_mat *m, int log_fn, uint32_t base, uint32_t exponent) {
+    return guard([&] { // scan-rs/src/normalization.rs:191-213
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        if (!map_is_raw(m) || m->off_rank) fail(SCANRS_ERR_ARGUMENT, "needs the raw count matrix");
+        if (log_fn != OP_LN_1P && log_fn != OP_LOG2_1P && log_fn != OP_LOG10_1P) fail(SCANRS_ERR_ARGUMENT, "bad log base");
+        uint32_t p = 1; // fixed_point.base.pow(exponent) in u32
+        for (uint32_t i = 0; i < exponent; i++) p *= base;
+        std::vector<double> f(m->cols(), 1.0 / (double)p);
+        MapOp sc;
+        sc.kind = OP_SCALE_AXIS;
+        sc.axis = 1;
+        sc.a = upload_vec(*m->st, f.data(), f.size());
+        m->ops.push_back(sc);
+        MapOp lg;
+        lg.kind = log_fn;
+        m->ops.push_back(lg);
+        scale_and_center_impl(m, 1, nullptr);
+    });
+}
+int scanrs_normalize(scanrs_mat *m, int normalization, const uint32_t *size_factors) {
+    return guard([&] { // normalize / normalize_with_size_factor, scan-rs/src/normalization.rs:46-102
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        switch (normalization) {
+        case SCANRS_NORM_CELLRANGER:
+            log_normalize_impl(m, -1.0, OP_LOG2_1P, nullptr);
+            scale_and_center_impl(m, 1, nullptr);
+            break;
+        case SCANRS_NORM_CELLRANGER8: {
+            log_normalize_impl(m, -1.0, OP_LOG2_1P, nullptr);
+            std::vector<double> ones(m->rows(), 1.0);
+            scale_and_center_impl(m, 1, ones.data());
+            break;
+        }
+        case SCANRS_NORM_SEURATLOG:
+            log_normalize_impl(m, 10000.0, OP_LN_1P, nullptr);
+            scale_and_center_impl(m, 1, nullptr);
+            break;
+        case SCANRS_NORM_WITH_SIZE_FACTORS:
+            log_normalize_impl(m, -1.0, OP_LOG2_1P, size_factors);
+            scale_and_center_impl(m, 1, nullptr);
+            break;
+        case SCANRS_NORM_LOG_TRANSFORM: {
+            std::vector<uint32_t> ones(m->cols(), 1u);
+            log_normalize_impl(m, 1.0, OP_LOG2_1P, ones.data());
+            scale_and_center_impl(m, 1, nullptr);
+            break;
+        }
+        case SCANRS_NORM_BINOMIAL_DEVIANCE:
+            binom_impl(m, OP_BINOM_DEV);
+            break;
+        case SCANRS_NORM_BINOMIAL_PEARSON:
+            binom_impl(m, OP_BINOM_PEARSON);
+            break;
+        default:
+            fail(SCANRS_ERR_ARGUMENT, "Normalization not recognized: %d", normalization);
+        }
+    });
+}
+int scanrs_mat_target_umi(const scanrs_mat *m, double *target) {
+    return guard([&] {
+        if (!m || !target) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        *target = m->target_umi;
+    });
+}
+
+// ---- PCA ----------------------------------------------------------------------------------------------------------
+int scanrs_pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
+                  const scanrs_snoop *snoop, double *u, double *s, double *v) {
+    return guard([&] {
+        if (!m || !u || !s || !v) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        pca_bk(m, k, k_multiplier, n_iter, seed, omega, snoop, u, s, v);
+    });
+}
+int scanrs_pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
+                    double *u, double *s, double *v) {
+    return guard([&] {
+        if (!m || !u || !s || !v) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        pca_rand(m, k, l_multiplier, n_iter, seed, omega, u, s, v);
+    });
+}
+int scanrs_pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t max_iter, const double *v0, const scanrs_snoop *snoop,
+                     double *u, double *s, double *v, uint32_t *mprod) {
+    return guard([&] {
+        if (!m || !u || !s || !v) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        pca_irlba(m, nu, tol, max_iter, v0, snoop, u, s, v, mprod);
+    });
+}
+int scanrs_omega_fill(uint64_t seed, uint64_t count, double *out) {
+    return guard([&] {
+        if (!out && count) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        omega_fill(seed, count, out);
+    });
+}
+
+// ---- multi-GPU ----------------------------------------------------------------------------------------------------
+int scanrs_mat_set_shard(scanrs_mat *m, uint32_t rank, uint32_t world, uint64_t outer_begin, uint64_t outer_global,
+                         scanrs_allreduce_fn allreduce, void *ctx) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        if (world == 0 || rank >= world) fail(SCANRS_ERR_ARGUMENT, "bad rank/world");
+        if (world > 1 && !allreduce) fail(SCANRS_ERR_ARGUMENT, "an all-reduce callback is required when world > 1");
+        Storage &st = *m->st;
+        if (outer_begin + st.primary.n_outer > outer_global) fail(SCANRS_ERR_SHAPE, "shard exceeds the global extent");
+        st.shard.rank = rank;
+        st.shard.world = world;
+        st.shard.outer_begin = outer_begin;
+        st.shard.outer_global = outer_global;
+        st.shard.allreduce = allreduce;
+        st.shard.ctx = ctx;
+    });
+}
+int scanrs_plan_shards(const uint64_t *indptr, uint64_t n_outer, uint32_t world, uint64_t *bounds) {
+    return guard([&] {
+        if (!indptr || !bounds || world == 0) fail(SCANRS_ERR_ARGUMENT, "bad argument");
+        const uint64_t nnz = indptr[n_outer] - indptr[0];
+        bounds[0] = 0;
+        for (uint32_t r = 1; r < world; r++) {
+            // first outer index whose prefix reaches r/world of the nonzeros
+            const uint64_t want = indptr[0] + (uint64_t)(((long double)nnz * r) / world);
+            const uint64_t *p = std::lower_bound(indptr, indptr + n_outer + 1, want);
+            uint64_t b = (uint64_t)(p - indptr);
+            b = std::min(b, n_outer);
+            bounds[r] = std::max(b, bounds[r - 1]);
+        }
+        bounds[world] = n_outer;
+    });
+}
+
+// ---- measurement ------------------------------------------------------------------------------------------------------
+int scanrs_profile_enable(scanrs_mat *m, int on) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        m->st->prof.on = on != 0;
+    });
+}
+int scanrs_profile_reset(scanrs_mat *m) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        SCANRS_HIP(hipStreamSynchronize(m->st->stream));
+        m->st->prof.reset();
+    });
+}
+int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uint32_t *n) {
+    return guard([&] {
+        if (!m || !n) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        SCANRS_HIP(hipStreamSynchronize(m->st->stream));
+        m->st->prof.resolve();
+        uint32_t i = 0;
+        for (auto &kv : m->st->prof.stats) {
+            if (out && i < cap) {
+                memset(&out[i], 0, sizeof(out[i]));
+                strncpy(out[i].name, kv.first.c_str(), sizeof(out[i].name) - 1);
+                out[i].launches = kv.second.launches;
+                out[i].total_ms = kv.second.ms;
+                out[i].algorithmic_bytes = kv.second.bytes;
+            }
+            i++;
+        }
+        *n = i;
+    });
+}
+int scanrs_mat_sync(scanrs_mat *m) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        SCANRS_HIP(hipStreamSynchronize(m->st->stream));
+    });
+}
+
+// ---- host-only utilities exposed for the CPU test-suite (no device needed) --------------------------------------------
+int scanrs_host_chol_upper(double *g, int n) { return chol_upper(g, n) ? 0 : SCANRS_ERR_NUMERICAL; }
+int scanrs_host_inv_upper(double *r, int n) {
+    inv_upper(r, n);
+    return 0;
+}
+int scanrs_host_sym_eig(const double *a, int n, double *w, double *z) { return sym_eig(a, n, w, z) ? 0 : SCANRS_ERR_NUMERICAL; }
+
+} // extern "C"

@@ -1,0 +1,286 @@
+// Shared declarations of the scanrs_amd library (host side). gfx950 only.
+#pragma once
+#include <cstring>
+#include <cstdio>
+#include <cstdint>
+#include <cstdarg>
+#include <map>
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "scanrs_amd.h"
+
+namespace scanrs {
+
+// ---- errors: thrown inside, turned into status codes at the C boundary ----------
+struct Failure {
+    int code;
+};
+void set_error(const char *fmt, ...);
+[[noreturn]] void fail(int code, const char *fmt, ...);
+
+#define SCANRS_HIP(expr)                                                                              \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess)                                                                         \
+            ::scanrs::fail(SCANRS_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                           __FILE__, __LINE__);                                                       \
+    } while (0)
+
+// ---- device memory ------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p;
+            n = o.n;
+            o.p = nullptr;
+            o.n = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        if (count) SCANRS_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+    }
+    void ensure(size_t count) {
+        if (count > n) alloc(count);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+// Grow-only named scratch buffers: nothing is hipMalloc'ed inside the solver loops after
+// the first pass over them.
+struct Scratch {
+    std::map<std::string, DevBuf<char>> bufs;
+    template <typename T>
+    T *get(const std::string &key, size_t count) {
+        auto &b = bufs[key];
+        size_t bytes = count * sizeof(T);
+        if (bytes > b.n) {
+            b.alloc(bytes + bytes / 8 + 256);
+            SCANRS_HIP(hipMemset(b.p, 0, b.n)); // padding columns of panels start out as zeros
+        }
+        return reinterpret_cast<T *>(b.p);
+    }
+    void clear() { bufs.clear(); }
+};
+
+// ---- per-kernel-class timing (scanrs_profile_*) -------------------------------------
+struct Profile {
+    bool on = false;
+    struct Rec {
+        std::string name;
+        hipEvent_t a, b;
+        double bytes;
+    };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    struct Stat {
+        uint64_t launches = 0;
+        double ms = 0, bytes = 0;
+    };
+    std::map<std::string, Stat> stats;
+    hipEvent_t take();
+    void begin(hipStream_t s, const char *name, double bytes);
+    void end(hipStream_t s);
+    void resolve();
+    void reset();
+    ~Profile();
+};
+
+// ---- sparse storage -------------------------------------------------------------------
+// One wave works one item: a run of at most ITEM_NNZ nonzeros of one outer vector.
+// Outer vectors longer than that are cut into several items whose partial results go
+// through a slab and are summed in item order (deterministic, no float atomics).
+constexpr uint32_t ITEM_NNZ = 8192;
+constexpr uint32_t NO_SLAB = 0xFFFFFFFFu;
+
+struct Item {
+    uint64_t start; // offset of the first nonzero in indices/values
+    uint32_t row;   // outer vector id
+    uint32_t len;   // number of nonzeros
+    uint32_t slab;  // slab row for the partial result, NO_SLAB when the item is the whole vector
+    uint32_t _pad;
+};
+
+struct MultiRow {
+    uint32_t row;
+    uint32_t first_slab;
+    uint32_t count;
+    uint32_t _pad;
+};
+
+// A compressed orientation: n_outer vectors over n_inner positions.
+struct SparseCopy {
+    uint64_t n_outer = 0, n_inner = 0, nnz = 0;
+    DevBuf<uint64_t> indptr;
+    DevBuf<uint32_t> indices, values;
+    DevBuf<Item> items;
+    DevBuf<MultiRow> multi;
+    uint32_t n_items = 0, n_multi = 0, n_slab = 0;
+    void build_items(hipStream_t s);
+};
+
+struct ShardInfo {
+    uint32_t rank = 0, world = 1;
+    uint64_t outer_begin = 0, outer_global = 0;
+    scanrs_allreduce_fn allreduce = nullptr;
+    void *ctx = nullptr;
+    bool active() const { return world > 1; }
+};
+
+// Storage shared by a handle and its views (AdaptiveMat::view / t share `&[AdaptiveVec]`).
+struct Storage {
+    uint64_t rows = 0, cols = 0;
+    int storage = SCANRS_CSR; // orientation of `primary`: CSR -> outer = rows
+    SparseCopy primary;
+    SparseCopy other; // the transposed orientation, built on first use
+    bool has_other = false;
+    hipStream_t stream = nullptr;
+    Scratch scratch;
+    Profile prof;
+    ShardInfo shard; // sharding of primary's outer dimension
+    ~Storage();
+    // the copy whose outer dimension is the base matrix's rows (true) or cols (false)
+    SparseCopy &copy_with_outer_rows(bool outer_rows);
+};
+
+// ---- lazy map (sqz::MatrixMap chain) ------------------------------------------------------
+enum { OP_INTO = 0, OP_SCALE_AXIS = 1, OP_LN_1P = 2, OP_LOG2_1P = 3, OP_LOG10_1P = 4, OP_SQUARE = 5, OP_BINOM_DEV = 6, OP_BINOM_PEARSON = 7 };
+constexpr int MAX_OPS = 8;
+
+struct MapOp {
+    int kind = OP_INTO;
+    int axis = 0;
+    bool swap = false; // under an odd number of TransposeMap wrappers
+    std::shared_ptr<DevBuf<double>> a, b;
+};
+
+// what the kernels see (by value)
+struct DevOp {
+    int kind;
+    int a_outer; // index `a` by the outer (1) or inner (0) position of the copy being walked
+    int b_outer;
+    int _pad;
+    const double *a;
+    const double *b;
+};
+struct DevMap {
+    int n;
+    int _pad;
+    DevOp ops[MAX_OPS];
+};
+
+struct Panel {
+    double *p = nullptr;
+    uint64_t rows = 0;
+    uint32_t l = 0, ld = 0;
+};
+inline uint32_t even_up(uint32_t x) { return (x + 1u) & ~1u; }
+
+} // namespace scanrs
+
+// The opaque handle of the C ABI.
+struct scanrs_mat {
+    std::shared_ptr<scanrs::Storage> st;
+    bool transposed = false; // this view is the base matrix transposed
+    std::vector<scanrs::MapOp> ops;
+    uint32_t off_rank = 0;
+    std::shared_ptr<scanrs::DevBuf<double>> off_u; // rows x rank (view coordinates)
+    std::shared_ptr<scanrs::DevBuf<double>> off_v; // rank x cols
+    double target_umi = 0.0;
+
+    uint64_t rows() const { return transposed ? st->cols : st->rows; }
+    uint64_t cols() const { return transposed ? st->rows : st->cols; }
+    // is the (view) outer dimension that contracts in V*x sharded?  (see Storage::shard)
+    scanrs::DevMap dev_map(bool outer_is_view_row) const;
+};
+
+namespace scanrs {
+
+// ---- kernels.hip launchers ----------------------------------------------------------------
+// out[n_outer x l] = S * X (+ a * w) where S is `cp` seen through `map`.
+// off_a: n_outer x rank (row-major) or null; off_w: rank x l (ld = ldw).
+void launch_spmm_f64(Storage &st, const SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
+                     double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw);
+void launch_spmm_u32(Storage &st, const SparseCopy &cp, const uint32_t *X, uint32_t ldx, uint32_t l, uint32_t *out,
+                     uint32_t ldo);
+// per-outer-vector reductions. mode 0: sum of raw u32 counts; 1: sum of mapped values; 2: sum and sum of squares.
+void launch_row_reduce(Storage &st, const SparseCopy &cp, const DevMap &map, int mode, uint32_t *out_u32, double *out_sum,
+                       double *out_sumsq);
+// w[rank x l] (ld ldw) = B^T X, B: n x rank row-major, X: n x l (ld ldx)
+void launch_weighted_colsum(Storage &st, const double *B, uint32_t rank, const double *X, uint32_t ldx, uint64_t n,
+                            uint32_t l, double *w, uint32_t ldw);
+// C[n x m] (row-major, ld = m) = X^T Y over `rows` rows (f64 MFMA, slab + ordered reduce)
+void launch_gram(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *Y, uint32_t ldy, uint32_t m,
+                 uint64_t rows, double *C);
+// Out[rows x m] = beta * Cin + alpha * X[rows x n] * W[n x m]   (W device, row-major ld = ldw). Cin may equal Out.
+void launch_gemm_nn(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *W, uint32_t ldw, uint32_t m,
+                    uint64_t rows, double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo);
+void launch_copy_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows, uint32_t l);
+void launch_fill_f64(Storage &st, double *p, uint64_t n, double v);
+void launch_finish_moments(Storage &st, const double *sum, const double *sumsq, uint64_t n, double m, int given_scale,
+                           const double *scale_in, double *mean_over_scale_neg, double *inv_scale, double *scale_out);
+void launch_u32_to_scale(Storage &st, const uint32_t *counts, uint64_t n, double target, double *out);
+void launch_hist12(Storage &st, const uint32_t *v, uint64_t n, uint32_t shift, uint32_t prefix_mask, uint32_t prefix,
+                   unsigned long long *hist);
+void launch_sum_f64(Storage &st, const double *x, uint64_t n, double *out);
+void validate_copy(Storage &st, const SparseCopy &cp, uint64_t *zeros, uint64_t *bad);
+void launch_densify(Storage &st, const SparseCopy &cp, const DevMap &map, bool outer_is_view_row, uint64_t cols_v,
+                    double *out);
+void launch_binom_uv(Storage &st, int kind, const double *n, uint64_t ncols, const double *rowsum, uint64_t nrows,
+                     double total, double *pi, double *u, double *v);
+// build `dst` = transpose of `src` (stable: inner vectors keep ascending outer order)
+void build_transposed_copy(Storage &st, const SparseCopy &src, SparseCopy &dst);
+// drop stored zeros, compact (device). Returns new nnz.
+void compact_nonzeros(Storage &st, SparseCopy &cp);
+
+// ---- host_linalg.cpp --------------------------------------------------------------------------
+// Upper Cholesky G = R^T R of an n x n SPD matrix (row-major, in place: upper triangle = R). false if not SPD.
+bool chol_upper(double *g, int n);
+// in place inverse of an upper-triangular matrix
+void inv_upper(double *r, int n);
+// symmetric eigen-decomposition: on return w[0..n) descending, z row-major with z[i*n + j] = component i of vector j.
+bool sym_eig(const double *a, int n, double *w, double *z);
+
+// ---- solver.cpp ------------------------------------------------------------------------------------
+struct PcaOut {
+    double *u, *s, *v; // host buffers
+};
+int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
+           const scanrs_snoop *snoop, double *u, double *s, double *v);
+int pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, uint64_t seed, const double *omega, double *u,
+             double *s, double *v);
+int pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t max_iter, const double *v0, const scanrs_snoop *snoop,
+              double *u, double *s, double *v, uint32_t *mprod);
+void omega_fill(uint64_t seed, uint64_t count, double *out);
+
+// operator-level helpers shared by capi.cpp and solver.cpp
+// out[rows_v x l] = V * X  (transpose: out[cols_v x l] = V^T * X), offsets and shard reduction included.
+void mat_apply(scanrs_mat *m, bool transpose, const double *dX, uint32_t ldx, uint32_t l, double *dOut, uint32_t ldo);
+void allreduce_f64(Storage &st, double *d, uint64_t count);
+void allreduce_u64(Storage &st, unsigned long long *d, uint64_t count);
+// is the view-row dimension the sharded one?
+bool rows_sharded(const scanrs_mat *m);
+bool cols_sharded(const scanrs_mat *m);
+
+} // namespace scanrs

@@ -1,0 +1,200 @@
+// Small dense factorizations on the host (the k x k side of the solvers). They stand where the
+// reference calls LAPACK through ndarray-linalg on matrices of order <= 5b (scan-rs/src/dim_red/
+// bk_svd.rs:94-139): Cholesky + triangular inverse for the CholeskyQR panels, and a symmetric
+// eigensolver (Householder tridiagonalisation + implicit-shift QL) for the projected Gram matrix.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <vector>
+
+#include "common.hpp"
+
+namespace scanrs {
+
+bool chol_upper(double *g, int n) {
+    // row-oriented: R[i][j], j >= i, G = R^T R
+    for (int i = 0; i < n; i++) {
+        double *ri = g + (size_t)i * n;
+        for (int k = 0; k < i; k++) {
+            const double *rk = g + (size_t)k * n;
+            const double f = rk[i];
+            if (f != 0.0)
+                for (int j = i; j < n; j++) ri[j] -= f * rk[j];
+        }
+        const double d = ri[i];
+        if (!(d > 0.0) || !std::isfinite(d)) return false;
+        const double s = std::sqrt(d), inv = 1.0 / s;
+        ri[i] = s;
+        for (int j = i + 1; j < n; j++) ri[j] *= inv;
+        for (int j = 0; j < i; j++) ri[j] = 0.0;
+    }
+    return true;
+}
+
+void inv_upper(double *r, int n) {
+    // X = R^{-1}, upper triangular; solve R X = I column block by row recurrences, bottom-up.
+    std::vector<double> x((size_t)n * n, 0.0);
+    for (int i = n - 1; i >= 0; i--) {
+        double *xi = x.data() + (size_t)i * n;
+        const double *ri = r + (size_t)i * n;
+        const double inv = 1.0 / ri[i];
+        xi[i] = 1.0;
+        for (int k = i + 1; k < n; k++) {
+            const double f = ri[k];
+            if (f == 0.0) continue;
+            const double *xk = x.data() + (size_t)k * n;
+            for (int j = k; j < n; j++) xi[j] -= f * xk[j];
+        }
+        for (int j = i; j < n; j++) xi[j] *= inv;
+    }
+    std::copy(x.begin(), x.end(), r);
+}
+
+// Symmetric eigenproblem A = Z diag(w) Z^T.
+// 1) Householder reduction A -> T (tridiagonal), reflectors applied row-wise so every inner loop is
+//    unit-stride; 2) accumulate Q; 3) implicit QL with Wilkinson shifts on (d, e), rotating rows of Q^T.
+bool sym_eig(const double *a_in, int n, double *w, double *z) {
+    if (n == 0) return true;
+    std::vector<double> A(a_in, a_in + (size_t)n * n);
+    std::vector<double> d(n), e(n, 0.0), tau(n, 0.0);
+    std::vector<double> V((size_t)n * n, 0.0); // reflector k stored in row k (entries k+1..n-1)
+    std::vector<double> p(n), v(n);
+
+    for (int k = 0; k < n - 2; k++) {
+        // x = A[k+1.., k] (use row k by symmetry)
+        double *ak = A.data() + (size_t)k * n;
+        double scale = 0.0;
+        for (int i = k + 1; i < n; i++) scale = std::max(scale, std::fabs(ak[i]));
+        if (scale == 0.0) {
+            tau[k] = 0.0;
+            e[k] = 0.0;
+            continue;
+        }
+        double nrm2 = 0.0;
+        for (int i = k + 1; i < n; i++) {
+            v[i] = ak[i] / scale;
+            nrm2 += v[i] * v[i];
+        }
+        const double alpha = v[k + 1];
+        double beta = std::sqrt(nrm2);
+        if (alpha > 0) beta = -beta;
+        // H = I - tau v v^T with v[k+1] = 1
+        const double v0 = alpha - beta;
+        tau[k] = (beta - alpha) / beta;
+        for (int i = k + 2; i < n; i++) v[i] /= v0;
+        v[k + 1] = 1.0;
+        e[k] = beta * scale;
+        // p = tau * A22 v
+        for (int i = k + 1; i < n; i++) {
+            const double *ai = A.data() + (size_t)i * n;
+            double s = 0.0;
+            for (int j = k + 1; j < n; j++) s += ai[j] * v[j];
+            p[i] = tau[k] * s;
+        }
+        double pv = 0.0;
+        for (int i = k + 1; i < n; i++) pv += p[i] * v[i];
+        const double half = 0.5 * tau[k] * pv;
+        for (int i = k + 1; i < n; i++) p[i] -= half * v[i]; // w
+        for (int i = k + 1; i < n; i++) {
+            double *ai = A.data() + (size_t)i * n;
+            const double vi = v[i], pi = p[i];
+            for (int j = k + 1; j < n; j++) ai[j] -= vi * p[j] + pi * v[j];
+        }
+        double *vk = V.data() + (size_t)k * n;
+        for (int i = k + 1; i < n; i++) vk[i] = v[i];
+    }
+    for (int i = 0; i < n; i++) d[i] = A[(size_t)i * n + i];
+    if (n >= 2) e[n - 2] = A[(size_t)(n - 2) * n + (n - 1)];
+
+    // Qt = (H_0 H_1 ... H_{n-3})^T, built by applying reflectors to the identity from the last to the first.
+    // We keep Qt row-major where row j of Qt is eigenvector-basis column j of Q, i.e. Qt[j][i] = Q[i][j].
+    std::vector<double> Qt((size_t)n * n, 0.0);
+    for (int i = 0; i < n; i++) Qt[(size_t)i * n + i] = 1.0;
+    // Q = H_0 ... H_{n-3}; Q^T = H_{n-3} ... H_0. Apply to columns: Q^T <- Q^T (built as product), do
+    // Q <- H_k Q for k = n-3..0 on Q stored as rows of Q (row-major Q), then transpose into Qt.
+    {
+        std::vector<double> Q((size_t)n * n, 0.0);
+        for (int i = 0; i < n; i++) Q[(size_t)i * n + i] = 1.0;
+        std::vector<double> s(n);
+        for (int k = n - 3; k >= 0; k--) {
+            if (tau[k] == 0.0) continue;
+            const double *vk = V.data() + (size_t)k * n;
+            // s = v^T Q (over rows k+1..n-1), Q -= tau v s^T
+            std::fill(s.begin(), s.end(), 0.0);
+            for (int i = k + 1; i < n; i++) {
+                const double vi = vk[i];
+                const double *qi = Q.data() + (size_t)i * n;
+                for (int j = k + 1; j < n; j++) s[j] += vi * qi[j];
+            }
+            for (int i = k + 1; i < n; i++) {
+                const double f = tau[k] * vk[i];
+                double *qi = Q.data() + (size_t)i * n;
+                for (int j = k + 1; j < n; j++) qi[j] -= f * s[j];
+            }
+        }
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < n; j++) Qt[(size_t)j * n + i] = Q[(size_t)i * n + j];
+    }
+
+    // implicit QL; e[i] couples d[i] and d[i+1]
+    const double eps = 2.220446049250313e-16;
+    for (int l = 0; l < n; l++) {
+        int iter = 0;
+        int m;
+        do {
+            for (m = l; m < n - 1; m++) {
+                const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
+                if (std::fabs(e[m]) <= eps * dd) break;
+            }
+            if (m != l) {
+                if (iter++ == 200) return false;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = std::hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
+                double s = 1.0, c = 1.0, pp = 0.0;
+                int i;
+                for (i = m - 1; i >= l; i--) {
+                    double f = s * e[i];
+                    const double b = c * e[i];
+                    r = std::hypot(f, g);
+                    e[i + 1] = r;
+                    if (r == 0.0) {
+                        d[i + 1] -= pp;
+                        e[m] = 0.0;
+                        break;
+                    }
+                    s = f / r;
+                    c = g / r;
+                    g = d[i + 1] - pp;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    pp = s * r;
+                    d[i + 1] = g + pp;
+                    g = c * r - b;
+                    double *zi = Qt.data() + (size_t)i * n;
+                    double *zi1 = Qt.data() + (size_t)(i + 1) * n;
+                    for (int k2 = 0; k2 < n; k2++) {
+                        f = zi1[k2];
+                        zi1[k2] = s * zi[k2] + c * f;
+                        zi[k2] = c * zi[k2] - s * f;
+                    }
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= pp;
+                e[l] = g;
+                e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    // sort descending
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return d[x] > d[y]; });
+    for (int j = 0; j < n; j++) {
+        w[j] = d[order[j]];
+        const double *src = Qt.data() + (size_t)order[j] * n;
+        for (int i = 0; i < n; i++) z[(size_t)i * n + j] = src[i];
+    }
+    return true;
+}
+
+} // namespace scanrs

@@ -1,0 +1,974 @@
+// HIP kernels for gfx950 (MI355X) + their launchers.
+//
+// Sparse side (replaces sqz/src/prod.rs and the axis reductions of sqz/src/mat.rs:273-406):
+//   spmm_gather_kernel   out[o,:] = sum_j f(v_j, o, i_j) * X[i_j,:]      (CSR kernel prod.rs:123-148;
+//                        the CSC scatter prod.rs:190-214 is served by the same gather run on the
+//                        transposed copy of the matrix, so no float atomics are needed)
+//   row_reduce_kernel    per-outer-vector sum / sum of squares of mapped values
+// Dense side (replaces the ndarray / LAPACK calls of scan-rs/src/dim_red/*.rs):
+//   gram_kernel          C = X^T Y, tall-skinny, v_mfma_f64_16x16x4_f64
+//   gemm_nn_kernel       Out = beta*C + alpha * X W, tall-skinny times small, same MFMA
+//
+// Wave = 64 lanes everywhere. One wave works one `Item` (<= ITEM_NNZ nonzeros of one outer vector).
+#include "common.hpp"
+
+#include <algorithm>
+#include <rocprim/rocprim.hpp>
+
+namespace scanrs {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+
+// ---------------------------------------------------------------------------------------------
+// MatrixMap evaluation: the flattened ComposedMap chain (sqz/src/matrix_map.rs:189-192), one
+// nonzero per lane. `outer`/`inner` are positions in the copy being walked.
+__device__ __forceinline__ double a_ln_a_over_b(double a, double b) { return a == 0.0 ? 0.0 : a * log(a / b); }
+
+__device__ __forceinline__ double eval_map(const DevMap &m, uint32_t v, uint32_t outer, uint32_t inner) {
+    double x = (double)v;
+    for (int i = 0; i < m.n; i++) {
+        const DevOp &op = m.ops[i];
+        switch (op.kind) {
+        case OP_SCALE_AXIS:
+            x = op.a[op.a_outer ? outer : inner] * x;
+            break;
+        case OP_LN_1P:
+            x = log(x + 1.0);
+            break;
+        case OP_LOG2_1P:
+            x = log2(x + 1.0);
+            break;
+        case OP_LOG10_1P:
+            x = log10(x + 1.0);
+            break;
+        case OP_SQUARE:
+            x = x * x;
+            break;
+        case OP_BINOM_DEV: { // BinomDevMap::map, scan-rs/src/normalization.rs:279-296
+            double n = op.a[op.a_outer ? outer : inner], pi = op.b[op.b_outer ? outer : inner];
+            double mu = n * pi;
+            double d = x - mu;
+            double sign = (d != d) ? d : (signbit(d) ? -1.0 : 1.0);
+            double inner2 = 2.0 * (a_ln_a_over_b(x, mu) + a_ln_a_over_b(n - x, n - mu));
+            double residual = sign * sqrt(fmax(inner2, 0.0));
+            double zero_term = -(sqrt(2.0 * n * log(1.0 / (1.0 - pi))));
+            x = residual - zero_term;
+            break;
+        }
+        case OP_BINOM_PEARSON: { // BinomPearsonMap::map, normalization.rs:338-347
+            double n = op.a[op.a_outer ? outer : inner], pi = op.b[op.b_outer ? outer : inner];
+            double mu = n * pi;
+            double residual = (x - mu) / sqrt(mu * (1.0 - pi));
+            double zero_term = -sqrt(n * pi / (1.0 - pi));
+            x = residual - zero_term;
+            break;
+        }
+        default:
+            break;
+        }
+    }
+    return x;
+}
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sparse x dense gather product. Lanes own column pairs of the panel (16-B loads, a whole panel row
+// is one coalesced read); the 64 nonzeros of a chunk are loaded one per lane, mapped in parallel
+// (one log per lane, not per column) and then broadcast one by one with v_readlane.
+template <typename T>
+struct Vec2;
+template <>
+struct Vec2<double> {
+    typedef d2 type;
+};
+template <>
+struct Vec2<uint32_t> {
+    typedef u2 type;
+};
+
+template <typename T>
+__device__ __forceinline__ T bcast(T v, uint32_t lane);
+template <>
+__device__ __forceinline__ double bcast<double>(double v, uint32_t lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, (int)lane);
+    hi = __builtin_amdgcn_readlane(hi, (int)lane);
+    return __hiloint2double(hi, lo);
+}
+template <>
+__device__ __forceinline__ uint32_t bcast<uint32_t>(uint32_t v, uint32_t lane) {
+    return rdlane(v, lane);
+}
+
+template <typename T>
+__device__ __forceinline__ T mul_add(T a, T b, T c);
+template <>
+__device__ __forceinline__ double mul_add<double>(double a, double b, double c) {
+    return fma(a, b, c);
+}
+template <>
+__device__ __forceinline__ uint32_t mul_add<uint32_t>(uint32_t a, uint32_t b, uint32_t c) {
+    return c + a * b;
+}
+
+template <typename T, int NACC>
+__global__ __launch_bounds__(256) void spmm_gather_kernel(const uint32_t *__restrict__ indices,
+                                                          const uint32_t *__restrict__ values,
+                                                          const Item *__restrict__ items, uint32_t n_items, DevMap map,
+                                                          const T *__restrict__ X, uint32_t ldx, uint32_t l,
+                                                          T *__restrict__ out, uint32_t ldo, T *__restrict__ slab,
+                                                          const double *__restrict__ off_a, uint32_t rank,
+                                                          const double *__restrict__ off_w, uint32_t ldw) {
+    typedef typename Vec2<T>::type V2;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wid >= n_items) return;
+    const Item it = items[wid];
+    const uint32_t row = rfl(it.row);
+    const uint32_t len = rfl(it.len);
+    const uint32_t slab_row = rfl(it.slab);
+    const uint64_t start = ((uint64_t)rfl((uint32_t)(it.start >> 32)) << 32) | rfl((uint32_t)it.start);
+    const uint32_t *__restrict__ ind = indices + start;
+    const uint32_t *__restrict__ val = values + start;
+
+    uint32_t col[NACC];
+    bool act[NACC];
+    V2 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+        col[a] = (a * 64u + lane) * 2u;
+        act[a] = col[a] < l;
+        acc[a] = (V2){(T)0, (T)0};
+    }
+
+    for (uint32_t base = 0; base < len; base += 64u) {
+        const uint32_t p = base + lane;
+        uint32_t idx = 0;
+        T f = (T)0;
+        if (p < len) {
+            idx = ind[p];
+            if constexpr (sizeof(T) == 8) {
+                f = eval_map(map, val[p], row, idx);
+            } else {
+                f = val[p];
+            }
+        }
+        const uint32_t n = min(64u, len - base);
+        uint32_t j = 0;
+        for (; j + 8u <= n; j += 8u) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                const uint32_t g = rdlane(idx, j + u);
+                const T fv = bcast<T>(f, j + u);
+                const T *__restrict__ xr = X + (size_t)g * ldx;
+#pragma unroll
+                for (int a = 0; a < NACC; a++) {
+                    if (act[a]) {
+                        const V2 x = *reinterpret_cast<const V2 *>(xr + col[a]);
+                        acc[a].x = mul_add<T>(fv, x.x, acc[a].x);
+                        acc[a].y = mul_add<T>(fv, x.y, acc[a].y);
+                    }
+                }
+            }
+        }
+        for (; j < n; j++) {
+            const uint32_t g = rdlane(idx, j);
+            const T fv = bcast<T>(f, j);
+            const T *__restrict__ xr = X + (size_t)g * ldx;
+#pragma unroll
+            for (int a = 0; a < NACC; a++) {
+                if (act[a]) {
+                    const V2 x = *reinterpret_cast<const V2 *>(xr + col[a]);
+                    acc[a].x = mul_add<T>(fv, x.x, acc[a].x);
+                    acc[a].y = mul_add<T>(fv, x.y, acc[a].y);
+                }
+            }
+        }
+    }
+
+    if (slab_row == NO_SLAB) {
+#pragma unroll
+        for (int a = 0; a < NACC; a++) {
+            if (act[a]) {
+                V2 r = acc[a];
+                if constexpr (sizeof(T) == 8) {
+                    // LowRankOffset: res += u.dot(&v.dot(rhs))  (sqz/src/low_rank_offset.rs:76-80)
+                    for (uint32_t q = 0; q < rank; q++) {
+                        const double aq = off_a[(size_t)row * rank + q];
+                        r.x += aq * off_w[(size_t)q * ldw + col[a]];
+                        r.y += aq * off_w[(size_t)q * ldw + col[a] + 1];
+                    }
+                }
+                *reinterpret_cast<V2 *>(out + (size_t)row * ldo + col[a]) = r;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int a = 0; a < NACC; a++)
+            if (act[a]) *reinterpret_cast<V2 *>(slab + (size_t)slab_row * ldo + col[a]) = acc[a];
+    }
+}
+
+// Ordered sum of the partial rows of outer vectors that were cut into several items.
+template <typename T, int NACC>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const MultiRow *__restrict__ multi, uint32_t n_multi,
+                                                          const T *__restrict__ slab, uint32_t l, T *__restrict__ out,
+                                                          uint32_t ldo, const double *__restrict__ off_a, uint32_t rank,
+                                                          const double *__restrict__ off_w, uint32_t ldw) {
+    typedef typename Vec2<T>::type V2;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wid >= n_multi) return;
+    const MultiRow mr = multi[wid];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+        const uint32_t col = (a * 64u + lane) * 2u;
+        if (col >= l) continue;
+        V2 r = (V2){(T)0, (T)0};
+        for (uint32_t i = 0; i < mr.count; i++) {
+            const V2 x = *reinterpret_cast<const V2 *>(slab + (size_t)(mr.first_slab + i) * ldo + col);
+            r.x += x.x;
+            r.y += x.y;
+        }
+        if constexpr (sizeof(T) == 8) {
+            for (uint32_t q = 0; q < rank; q++) {
+                const double aq = off_a[(size_t)mr.row * rank + q];
+                r.x += aq * off_w[(size_t)q * ldw + col];
+                r.y += aq * off_w[(size_t)q * ldw + col + 1];
+            }
+        }
+        *reinterpret_cast<V2 *>(out + (size_t)mr.row * ldo + col) = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Axis reductions (sum_axis / mean_var_axis, sqz/src/mat.rs:285-406) as per-outer-vector sums.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+    return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void row_reduce_kernel(const uint32_t *__restrict__ indices,
+                                                         const uint32_t *__restrict__ values,
+                                                         const Item *__restrict__ items, uint32_t n_items, DevMap map,
+                                                         uint32_t *__restrict__ out_u32, double *__restrict__ out_sum,
+                                                         double *__restrict__ out_sumsq, uint32_t *__restrict__ slab_u32,
+                                                         double *__restrict__ slab_f64) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wid >= n_items) return;
+    const Item it = items[wid];
+    const uint32_t *__restrict__ ind = indices + it.start;
+    const uint32_t *__restrict__ val = values + it.start;
+    if constexpr (MODE == 0) {
+        uint32_t s = 0;
+        for (uint32_t p = lane; p < it.len; p += 64u) s += val[p];
+        s = wave_sum_u32(s);
+        if (lane == 0) {
+            if (it.slab == NO_SLAB)
+                out_u32[it.row] = s;
+            else
+                slab_u32[it.slab] = s;
+        }
+    } else {
+        double s = 0.0, s2 = 0.0;
+        for (uint32_t p = lane; p < it.len; p += 64u) {
+            const double x = eval_map(map, val[p], it.row, ind[p]);
+            s += x;
+            if constexpr (MODE == 2) s2 = fma(x, x, s2);
+        }
+        s = wave_sum(s);
+        if constexpr (MODE == 2) s2 = wave_sum(s2);
+        if (lane == 0) {
+            if (it.slab == NO_SLAB) {
+                out_sum[it.row] = s;
+                if constexpr (MODE == 2) out_sumsq[it.row] = s2;
+            } else {
+                slab_f64[2 * (size_t)it.slab] = s;
+                if constexpr (MODE == 2) slab_f64[2 * (size_t)it.slab + 1] = s2;
+            }
+        }
+    }
+}
+
+template <int MODE>
+__global__ void row_reduce_finish_kernel(const MultiRow *__restrict__ multi, uint32_t n_multi,
+                                         const uint32_t *__restrict__ slab_u32, const double *__restrict__ slab_f64,
+                                         uint32_t *__restrict__ out_u32, double *__restrict__ out_sum,
+                                         double *__restrict__ out_sumsq) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_multi) return;
+    const MultiRow mr = multi[i];
+    if constexpr (MODE == 0) {
+        uint32_t s = 0;
+        for (uint32_t k = 0; k < mr.count; k++) s += slab_u32[mr.first_slab + k];
+        out_u32[mr.row] = s;
+    } else {
+        double s = 0.0, s2 = 0.0;
+        for (uint32_t k = 0; k < mr.count; k++) {
+            s += slab_f64[2 * (size_t)(mr.first_slab + k)];
+            if constexpr (MODE == 2) s2 += slab_f64[2 * (size_t)(mr.first_slab + k) + 1];
+        }
+        out_sum[mr.row] = s;
+        if constexpr (MODE == 2) out_sumsq[mr.row] = s2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// w[q,:] = sum_i B[i,q] * X[i,:]   (the `v.dot(rhs)` / `lhs.dot(u)` of low_rank_offset.rs:76-95)
+__global__ __launch_bounds__(256) void weighted_colsum_partial_kernel(const double *__restrict__ B, uint32_t rank,
+                                                                      const double *__restrict__ X, uint32_t ldx,
+                                                                      uint64_t n, uint32_t l, uint64_t rows_per_block,
+                                                                      double *__restrict__ partial) {
+    const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_block;
+    const uint64_t r1 = min(n, r0 + rows_per_block);
+    for (uint32_t q = 0; q < rank; q++) {
+        for (uint32_t c = threadIdx.x; c < l; c += blockDim.x) {
+            double s = 0.0;
+            for (uint64_t i = r0; i < r1; i++) s = fma(B[i * rank + q], X[i * ldx + c], s);
+            partial[((size_t)blockIdx.x * rank + q) * l + c] = s;
+        }
+    }
+}
+__global__ void weighted_colsum_finish_kernel(const double *__restrict__ partial, uint32_t nblocks, uint32_t rank,
+                                              uint32_t l, double *__restrict__ w, uint32_t ldw) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rank * l) return;
+    const uint32_t q = e / l, c = e % l;
+    double s = 0.0;
+    for (uint32_t b = 0; b < nblocks; b++) s += partial[((size_t)b * rank + q) * l + c];
+    w[(size_t)q * ldw + c] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tall-skinny dense kernels on v_mfma_f64_16x16x4_f64.
+// Operand maps (cdna_hip_programming.md §3): lane l gives A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
+// the 4 results of lane l are D[row = (l>>4) + 4*reg][col = l&15].
+
+// C = X^T Y over a slice of rows; one wave per (32x32 tile of C, row slice).
+__global__ __launch_bounds__(64) void gram_kernel(const double *__restrict__ X, uint32_t ldx, uint32_t n,
+                                                  const double *__restrict__ Y, uint32_t ldy, uint32_t m, uint64_t rows,
+                                                  uint64_t rows_per_split, uint32_t tiles_m,
+                                                  double *__restrict__ slab) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t li = lane & 15u, lk = lane >> 4;
+    const uint32_t i0 = (blockIdx.x / tiles_m) * 32u, j0 = (blockIdx.x % tiles_m) * 32u;
+    const uint64_t r0 = (uint64_t)blockIdx.y * rows_per_split;
+    const uint64_t r1 = min(rows, r0 + rows_per_split);
+    const bool ai0 = i0 + li < n, ai1 = i0 + 16u + li < n;
+    const bool bj0 = j0 + li < m, bj1 = j0 + 16u + li < m;
+    d4 acc00 = {0, 0, 0, 0}, acc01 = {0, 0, 0, 0}, acc10 = {0, 0, 0, 0}, acc11 = {0, 0, 0, 0};
+    for (uint64_t r = r0; r < r1; r += 8u) {
+        double a0[2], a1[2], b0[2], b1[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint64_t rr = r + 4u * h + lk;
+            const bool v = rr < r1;
+            const double *xr = X + rr * ldx + i0 + li;
+            const double *yr = Y + rr * ldy + j0 + li;
+            a0[h] = (v && ai0) ? xr[0] : 0.0;
+            a1[h] = (v && ai1) ? xr[16] : 0.0;
+            b0[h] = (v && bj0) ? yr[0] : 0.0;
+            b1[h] = (v && bj1) ? yr[16] : 0.0;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            acc00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[h], b0[h], acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[h], b1[h], acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[h], b0[h], acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[h], b1[h], acc11, 0, 0, 0);
+        }
+    }
+    double *__restrict__ dst = slab + (size_t)blockIdx.y * n * m;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const uint32_t ra = i0 + lk + 4u * reg, rb = ra + 16u;
+        const uint32_t ca = j0 + li, cb = ca + 16u;
+        if (ra < n && ca < m) dst[(size_t)ra * m + ca] = acc00[reg];
+        if (ra < n && cb < m) dst[(size_t)ra * m + cb] = acc01[reg];
+        if (rb < n && ca < m) dst[(size_t)rb * m + ca] = acc10[reg];
+        if (rb < n && cb < m) dst[(size_t)rb * m + cb] = acc11[reg];
+    }
+}
+__global__ void gram_finish_kernel(const double *__restrict__ slab, uint32_t splits, uint64_t nm,
+                                   double *__restrict__ C) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nm) return;
+    double s = 0.0;
+    for (uint32_t k = 0; k < splits; k++) s += slab[(size_t)k * nm + e];
+    C[e] = s;
+}
+
+// Out = beta*Cin + alpha * X W. One wave per 16 rows x 64 columns. The k index is permuted inside a
+// 16-deep step (lane group lk owns k0+4*lk .. +3) so that each lane reads 32 contiguous bytes of X.
+template <int NJ>
+__global__ __launch_bounds__(256) void gemm_nn_kernel(const double *__restrict__ X, uint32_t ldx, uint32_t n,
+                                                      const double *__restrict__ W, uint32_t ldw, uint32_t m,
+                                                      uint64_t rows, double alpha, double beta,
+                                                      const double *Cin, uint32_t ldc, double *Out,
+                                                      uint32_t ldo) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t li = lane & 15u, lk = lane >> 4;
+    const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u;
+    if (r0 >= rows) return;
+    const uint32_t j0 = blockIdx.y * 16u * NJ;
+    const uint64_t ra = r0 + li;
+    const bool rv = ra < rows;
+    const double *__restrict__ xrow = X + ra * ldx;
+    d4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) acc[j] = (d4){0, 0, 0, 0};
+    bool cv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) cv[j] = j0 + 16u * j + li < m;
+
+    for (uint32_t k0 = 0; k0 < n; k0 += 16u) {
+        const uint32_t kb = k0 + 4u * lk;
+        double xa[4];
+        if (rv && kb + 3u < n) {
+            const d2 p = *reinterpret_cast<const d2 *>(xrow + kb);
+            const d2 q = *reinterpret_cast<const d2 *>(xrow + kb + 2);
+            xa[0] = p.x;
+            xa[1] = p.y;
+            xa[2] = q.x;
+            xa[3] = q.y;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; s++) xa[s] = (rv && kb + s < n) ? xrow[kb + s] : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const uint32_t kk = kb + s;
+            const bool kv = kk < n;
+            const double *__restrict__ wr = W + (size_t)kk * ldw + j0 + li;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+                const double b = (kv && cv[j]) ? wr[16 * j] : 0.0;
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[s], b, acc[j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const uint64_t rr = r0 + lk + 4u * reg;
+        if (rr >= rows) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            if (!cv[j]) continue;
+            const uint32_t cc = j0 + 16u * j + li;
+            double r = alpha * acc[j][reg];
+            if (beta != 0.0) r = fma(beta, Cin[rr * ldc + cc], r);
+            Out[rr * ldo + cc] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small element-wise helpers
+__global__ void copy_cols_kernel(const double *__restrict__ src, uint32_t lds, double *__restrict__ dst, uint32_t ldd,
+                                 uint64_t rows, uint32_t l) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * l) return;
+    const uint64_t r = e / l;
+    const uint32_t c = (uint32_t)(e % l);
+    dst[r * ldd + c] = src[r * lds + c];
+}
+__global__ void fill_kernel(double *p, uint64_t n, double v) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) p[e] = v;
+}
+// scale_and_center finishing step, sqz/src/mat.rs:993-1000 + :966-981 + :946 (neg_means)
+__global__ void finish_moments_kernel(const double *__restrict__ sum, const double *__restrict__ sumsq, uint64_t n,
+                                      double m, int given_scale, const double *__restrict__ scale_in,
+                                      double *__restrict__ neg_mean_over_scale, double *__restrict__ inv_scale,
+                                      double *__restrict__ scale_out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double mean = sum[i] / m;
+    double sc;
+    if (given_scale) {
+        sc = scale_in[i];
+    } else {
+        const double d = sumsq[i] / m - mean * mean;
+        sc = d <= 0.0 ? 1.0 : sqrt(d);
+    }
+    if (neg_mean_over_scale) neg_mean_over_scale[i] = -(mean / sc);
+    if (inv_scale) inv_scale[i] = 1.0 / sc;
+    if (scale_out) scale_out[i] = sc;
+}
+// col_scales = target / count  (scan-rs/src/normalization.rs:169)
+__global__ void u32_to_scale_kernel(const uint32_t *__restrict__ counts, uint64_t n, double target,
+                                    double *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = target / (double)counts[i];
+}
+// 12-bit digit histogram of the values matching a prefix: the counting step of the radix select that
+// stands in for median_mut's sort (scan-rs/src/stats.rs:13-38).
+__global__ __launch_bounds__(256) void hist12_kernel(const uint32_t *__restrict__ v, uint64_t n, uint32_t shift,
+                                                     uint32_t prefix_mask, uint32_t prefix,
+                                                     unsigned long long *__restrict__ hist) {
+    __shared__ uint32_t h[4096];
+    for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t x = v[i];
+        if ((x & prefix_mask) == prefix) atomicAdd(&h[(x >> shift) & 0xFFFu], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+// to_dense (sqz/src/mat.rs:188-205): scatter mapped nonzeros into a zeroed rows_v x cols_v array.
+__global__ __launch_bounds__(256) void densify_kernel(const uint32_t *__restrict__ indices,
+                                                      const uint32_t *__restrict__ values,
+                                                      const Item *__restrict__ items, uint32_t n_items, DevMap map,
+                                                      int outer_is_view_row, uint64_t cols_v, double *__restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wid >= n_items) return;
+    const Item it = items[wid];
+    for (uint32_t p = lane; p < it.len; p += 64u) {
+        const uint32_t in = indices[it.start + p];
+        const double x = eval_map(map, values[it.start + p], it.row, in);
+        const uint64_t r = outer_is_view_row ? it.row : in, c = outer_is_view_row ? in : it.row;
+        out[r * cols_v + c] = x;
+    }
+}
+// pi, u, v of binom_deviance_resid / binom_pearson_resid (scan-rs/src/normalization.rs:232-322)
+__global__ void binom_rows_kernel(int kind, const double *__restrict__ rowsum, uint64_t nrows, double total,
+                                  double *__restrict__ pi, double *__restrict__ u) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows) return;
+    const double x = rowsum[i] / total;
+    pi[i] = x;
+    u[i] = kind == OP_BINOM_DEV ? sqrt(log(1.0 / (1.0 - x))) : sqrt(x / (1.0 - x));
+}
+__global__ void binom_cols_kernel(int kind, const double *__restrict__ n, uint64_t ncols, double *__restrict__ v) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncols) return;
+    v[i] = kind == OP_BINOM_DEV ? -sqrt(2.0 * n[i]) : -sqrt(n[i]);
+}
+__global__ void sum_f64_kernel(const double *__restrict__ x, uint64_t n, double *__restrict__ out) {
+    // single block, fixed order: deterministic total (fit_multinomial_model, normalization.rs:224)
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) s += x[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (uint32_t w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// transpose helpers
+__global__ void pack_outer_kernel(const uint64_t *__restrict__ indptr, uint64_t n_outer,
+                                  const uint32_t *__restrict__ values, uint64_t nnz,
+                                  unsigned long long *__restrict__ packed) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    // upper_bound(indptr, p) - 1
+    uint64_t lo = 0, hi = n_outer;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi + 1) >> 1;
+        if (indptr[mid] <= p)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    packed[p] = ((unsigned long long)lo << 32) | values[p];
+}
+__global__ void unpack_kernel(const unsigned long long *__restrict__ packed, uint64_t nnz, uint32_t *__restrict__ ind,
+                              uint32_t *__restrict__ val) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nnz) return;
+    const unsigned long long x = packed[p];
+    ind[p] = (uint32_t)(x >> 32);
+    val[p] = (uint32_t)x;
+}
+__global__ void lower_bound_kernel(const uint32_t *__restrict__ keys, uint64_t nnz, uint64_t n_inner,
+                                   uint64_t *__restrict__ indptr) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_inner) return;
+    uint64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < i)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    indptr[i] = lo;
+}
+// validation: count stored zeros and non-ascending neighbours
+__global__ void validate_kernel(const uint64_t *__restrict__ indptr, uint64_t n_outer,
+                                const uint32_t *__restrict__ indices, const uint32_t *__restrict__ values,
+                                uint64_t n_inner, unsigned long long *__restrict__ counters) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_outer) return;
+    unsigned long long zeros = 0, bad = 0;
+    const uint64_t a = indptr[o], b = indptr[o + 1];
+    if (b < a) bad++;
+    for (uint64_t p = a; p < b; p++) {
+        if (values[p] == 0) zeros++;
+        if (indices[p] >= n_inner) bad++;
+        if (p > a && indices[p] <= indices[p - 1]) bad++;
+    }
+    if (zeros) atomicAdd(&counters[0], zeros);
+    if (bad) atomicAdd(&counters[1], bad);
+}
+
+// =============================================================================================
+// launchers
+static inline dim3 grid1(uint64_t n, uint32_t block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+struct ProfScope {
+    Storage &st;
+    ProfScope(Storage &s, const char *name, double bytes) : st(s) {
+        if (st.prof.on) st.prof.begin(st.stream, name, bytes);
+    }
+    ~ProfScope() {
+        if (st.prof.on) st.prof.end(st.stream);
+    }
+};
+
+template <typename T>
+static void launch_spmm_t(Storage &st, const SparseCopy &cp, const DevMap &map, const T *X, uint32_t ldx, uint32_t l,
+                          T *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w,
+                          uint32_t ldw) {
+    if (l == 0 || cp.n_outer == 0) return;
+    if ((ldx & 1u) || (ldo & 1u)) fail(SCANRS_ERR_ARGUMENT, "panel leading dimensions must be even");
+    // column chunks of at most 512 (4 accumulator pairs per lane)
+    for (uint32_t c0 = 0; c0 < l; c0 += 512u) {
+        const uint32_t lc = std::min(512u, l - c0);
+        const uint32_t nacc = (lc + 127u) / 128u;
+        T *slab = nullptr;
+        if (cp.n_slab) slab = st.scratch.get<T>("spmm_slab", (size_t)cp.n_slab * ldo);
+        const dim3 grid((cp.n_items + 3u) / 4u), block(256);
+        // algorithmic bytes: nnz*(4+4) + (n_outer+1)*8 + in panel + out panel
+        const double bytes = (double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 +
+                             (double)cp.n_inner * lc * sizeof(T) + (double)cp.n_outer * lc * sizeof(T);
+        const double *offw = off_w ? off_w + c0 : nullptr;
+        {
+            ProfScope ps(st, sizeof(T) == 8 ? "spmm_gather_f64" : "spmm_gather_u32", bytes);
+#define SCANRS_SPMM(NA)                                                                                              \
+    hipLaunchKernelGGL((spmm_gather_kernel<T, NA>), grid, block, 0, st.stream, cp.indices.p, cp.values.p, cp.items.p, \
+                       cp.n_items, map, X + c0, ldx, lc, out + c0, ldo, slab ? slab + c0 : nullptr, off_a, rank, offw, \
+                       ldw)
+            switch (nacc) {
+            case 1: SCANRS_SPMM(1); break;
+            case 2: SCANRS_SPMM(2); break;
+            case 3: SCANRS_SPMM(3); break;
+            default: SCANRS_SPMM(4); break;
+            }
+#undef SCANRS_SPMM
+        }
+        if (cp.n_multi) {
+            ProfScope ps(st, "slab_reduce", (double)cp.n_slab * lc * sizeof(T));
+            const dim3 g2((cp.n_multi + 3u) / 4u);
+#define SCANRS_SLAB(NA)                                                                                            \
+    hipLaunchKernelGGL((slab_reduce_kernel<T, NA>), g2, block, 0, st.stream, cp.multi.p, cp.n_multi, slab + c0, lc, \
+                       out + c0, ldo, off_a, rank, offw, ldw)
+            switch (nacc) {
+            case 1: SCANRS_SLAB(1); break;
+            case 2: SCANRS_SLAB(2); break;
+            case 3: SCANRS_SLAB(3); break;
+            default: SCANRS_SLAB(4); break;
+            }
+#undef SCANRS_SLAB
+        }
+    }
+    SCANRS_HIP(hipGetLastError());
+}
+
+void launch_spmm_f64(Storage &st, const SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
+                     double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw) {
+    launch_spmm_t<double>(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
+}
+void launch_spmm_u32(Storage &st, const SparseCopy &cp, const uint32_t *X, uint32_t ldx, uint32_t l, uint32_t *out,
+                     uint32_t ldo) {
+    DevMap map;
+    memset(&map, 0, sizeof(map));
+    launch_spmm_t<uint32_t>(st, cp, map, X, ldx, l, out, ldo, nullptr, 0, nullptr, 0);
+}
+
+void launch_row_reduce(Storage &st, const SparseCopy &cp, const DevMap &map, int mode, uint32_t *out_u32, double *out_sum,
+                       double *out_sumsq) {
+    if (cp.n_outer == 0) return;
+    uint32_t *slab_u32 = nullptr;
+    double *slab_f64 = nullptr;
+    if (cp.n_slab) {
+        slab_u32 = st.scratch.get<uint32_t>("rr_slab_u32", cp.n_slab);
+        slab_f64 = st.scratch.get<double>("rr_slab_f64", 2 * (size_t)cp.n_slab);
+    }
+    const dim3 grid((cp.n_items + 3u) / 4u), block(256);
+    const double bytes = (double)cp.nnz * (mode == 0 ? 4.0 : 8.0) + (double)(cp.n_outer + 1) * 8.0 +
+                         (double)cp.n_outer * (mode == 0 ? 4.0 : (mode == 1 ? 8.0 : 16.0));
+    {
+        ProfScope ps(st, mode == 0 ? "row_reduce_u32" : (mode == 1 ? "row_reduce_sum" : "row_reduce_moments"), bytes);
+        if (mode == 0)
+            hipLaunchKernelGGL((row_reduce_kernel<0>), grid, block, 0, st.stream, cp.indices.p, cp.values.p, cp.items.p,
+                               cp.n_items, map, out_u32, out_sum, out_sumsq, slab_u32, slab_f64);
+        else if (mode == 1)
+            hipLaunchKernelGGL((row_reduce_kernel<1>), grid, block, 0, st.stream, cp.indices.p, cp.values.p, cp.items.p,
+                               cp.n_items, map, out_u32, out_sum, out_sumsq, slab_u32, slab_f64);
+        else
+            hipLaunchKernelGGL((row_reduce_kernel<2>), grid, block, 0, st.stream, cp.indices.p, cp.values.p, cp.items.p,
+                               cp.n_items, map, out_u32, out_sum, out_sumsq, slab_u32, slab_f64);
+    }
+    if (cp.n_multi) {
+        const dim3 g2 = grid1(cp.n_multi, 256);
+        if (mode == 0)
+            hipLaunchKernelGGL((row_reduce_finish_kernel<0>), g2, block, 0, st.stream, cp.multi.p, cp.n_multi, slab_u32,
+                               slab_f64, out_u32, out_sum, out_sumsq);
+        else if (mode == 1)
+            hipLaunchKernelGGL((row_reduce_finish_kernel<1>), g2, block, 0, st.stream, cp.multi.p, cp.n_multi, slab_u32,
+                               slab_f64, out_u32, out_sum, out_sumsq);
+        else
+            hipLaunchKernelGGL((row_reduce_finish_kernel<2>), g2, block, 0, st.stream, cp.multi.p, cp.n_multi, slab_u32,
+                               slab_f64, out_u32, out_sum, out_sumsq);
+    }
+    SCANRS_HIP(hipGetLastError());
+}
+
+void launch_weighted_colsum(Storage &st, const double *B, uint32_t rank, const double *X, uint32_t ldx, uint64_t n,
+                            uint32_t l, double *w, uint32_t ldw) {
+    if (rank == 0 || l == 0) return;
+    uint32_t nblocks = (uint32_t)std::min<uint64_t>(1024, (n + 255) / 256);
+    if (nblocks == 0) nblocks = 1;
+    const uint64_t rpb = (n + nblocks - 1) / nblocks;
+    double *partial = st.scratch.get<double>("wcs_partial", (size_t)nblocks * rank * l);
+    ProfScope ps(st, "weighted_colsum", (double)n * l * 8.0 + (double)n * rank * 8.0);
+    hipLaunchKernelGGL(weighted_colsum_partial_kernel, dim3(nblocks), dim3(256), 0, st.stream, B, rank, X, ldx, n, l, rpb,
+                       partial);
+    hipLaunchKernelGGL(weighted_colsum_finish_kernel, grid1((uint64_t)rank * l, 256), dim3(256), 0, st.stream, partial,
+                       nblocks, rank, l, w, ldw);
+    SCANRS_HIP(hipGetLastError());
+}
+
+void launch_gram(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *Y, uint32_t ldy, uint32_t m,
+                 uint64_t rows, double *C) {
+    if (n == 0 || m == 0) return;
+    const uint32_t tiles_n = (n + 31u) / 32u, tiles_m = (m + 31u) / 32u;
+    const uint64_t tiles = (uint64_t)tiles_n * tiles_m;
+    // aim for ~8k waves, at least 64 rows per slice
+    uint64_t splits = std::max<uint64_t>(1, std::min<uint64_t>((rows + 63) / 64, (8192 + tiles - 1) / tiles));
+    splits = std::min<uint64_t>(splits, 1024);
+    uint64_t rps = (rows + splits - 1) / splits;
+    rps = (rps + 7) & ~7ull;
+    if (rps == 0) rps = 8;
+    splits = std::max<uint64_t>(1, (rows + rps - 1) / rps);
+    double *slab = st.scratch.get<double>("gram_slab", (size_t)splits * n * m);
+    {
+        ProfScope ps(st, "gram_mfma_f64", (double)rows * (n + (X == Y && n == m ? 0 : m)) * 8.0 + (double)n * m * 8.0);
+        hipLaunchKernelGGL(gram_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(64), 0, st.stream, X, ldx, n, Y, ldy,
+                           m, rows, rps, tiles_m, slab);
+        hipLaunchKernelGGL(gram_finish_kernel, grid1((uint64_t)n * m, 256), dim3(256), 0, st.stream, slab,
+                           (uint32_t)splits, (uint64_t)n * m, C);
+    }
+    SCANRS_HIP(hipGetLastError());
+}
+
+void launch_gemm_nn(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *W, uint32_t ldw, uint32_t m,
+                    uint64_t rows, double alpha, double beta, const double *Cin, uint32_t ldc, double *Out,
+                    uint32_t ldo) {
+    if (rows == 0 || m == 0) return;
+    if (ldx & 1u) fail(SCANRS_ERR_ARGUMENT, "gemm: ldx must be even");
+    const uint64_t waves = (rows + 15) / 16;
+    ProfScope ps(st, "gemm_nn_mfma_f64", (double)rows * (n + m) * 8.0 + (double)n * m * 8.0);
+    const dim3 block(256);
+    if (m <= 16) {
+        hipLaunchKernelGGL((gemm_nn_kernel<1>), dim3((unsigned)((waves + 3) / 4), (m + 15u) / 16u), block, 0, st.stream, X,
+                           ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
+    } else if (m <= 32) {
+        hipLaunchKernelGGL((gemm_nn_kernel<2>), dim3((unsigned)((waves + 3) / 4), (m + 31u) / 32u), block, 0, st.stream, X,
+                           ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
+    } else {
+        hipLaunchKernelGGL((gemm_nn_kernel<4>), dim3((unsigned)((waves + 3) / 4), (m + 63u) / 64u), block, 0, st.stream, X,
+                           ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
+    }
+    SCANRS_HIP(hipGetLastError());
+}
+
+void launch_copy_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows,
+                      uint32_t l) {
+    if (rows == 0 || l == 0) return;
+    hipLaunchKernelGGL(copy_cols_kernel, grid1(rows * l, 256), dim3(256), 0, st.stream, src, lds, dst, ldd, rows, l);
+    SCANRS_HIP(hipGetLastError());
+}
+void launch_fill_f64(Storage &st, double *p, uint64_t n, double v) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(fill_kernel, grid1(n, 256), dim3(256), 0, st.stream, p, n, v);
+    SCANRS_HIP(hipGetLastError());
+}
+void launch_finish_moments(Storage &st, const double *sum, const double *sumsq, uint64_t n, double m, int given_scale,
+                           const double *scale_in, double *neg_mean_over_scale, double *inv_scale, double *scale_out) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(finish_moments_kernel, grid1(n, 256), dim3(256), 0, st.stream, sum, sumsq, n, m, given_scale,
+                       scale_in, neg_mean_over_scale, inv_scale, scale_out);
+    SCANRS_HIP(hipGetLastError());
+}
+void launch_u32_to_scale(Storage &st, const uint32_t *counts, uint64_t n, double target, double *out) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(u32_to_scale_kernel, grid1(n, 256), dim3(256), 0, st.stream, counts, n, target, out);
+    SCANRS_HIP(hipGetLastError());
+}
+void launch_hist12(Storage &st, const uint32_t *v, uint64_t n, uint32_t shift, uint32_t prefix_mask, uint32_t prefix,
+                   unsigned long long *hist) {
+    SCANRS_HIP(hipMemsetAsync(hist, 0, 4096 * sizeof(unsigned long long), st.stream));
+    if (n) {
+        const unsigned blocks = (unsigned)std::min<uint64_t>(1024, (n + 255) / 256);
+        hipLaunchKernelGGL(hist12_kernel, dim3(blocks), dim3(256), 0, st.stream, v, n, shift, prefix_mask, prefix, hist);
+    }
+    SCANRS_HIP(hipGetLastError());
+}
+void launch_densify(Storage &st, const SparseCopy &cp, const DevMap &map, bool outer_is_view_row, uint64_t cols_v,
+                    double *out) {
+    if (cp.n_items == 0) return;
+    hipLaunchKernelGGL(densify_kernel, dim3((cp.n_items + 3u) / 4u), dim3(256), 0, st.stream, cp.indices.p, cp.values.p,
+                       cp.items.p, cp.n_items, map, outer_is_view_row ? 1 : 0, cols_v, out);
+    SCANRS_HIP(hipGetLastError());
+}
+void launch_binom_uv(Storage &st, int kind, const double *n, uint64_t ncols, const double *rowsum, uint64_t nrows,
+                     double total, double *pi, double *u, double *v) {
+    if (nrows) hipLaunchKernelGGL(binom_rows_kernel, grid1(nrows, 256), dim3(256), 0, st.stream, kind, rowsum, nrows, total, pi, u);
+    if (ncols) hipLaunchKernelGGL(binom_cols_kernel, grid1(ncols, 256), dim3(256), 0, st.stream, kind, n, ncols, v);
+    SCANRS_HIP(hipGetLastError());
+}
+void launch_sum_f64(Storage &st, const double *x, uint64_t n, double *out) {
+    hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(256), 0, st.stream, x, n, out);
+    SCANRS_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------
+// storage management
+void SparseCopy::build_items(hipStream_t s) {
+    std::vector<uint64_t> h(n_outer + 1);
+    if (n_outer + 1) SCANRS_HIP(hipMemcpyAsync(h.data(), indptr.p, (n_outer + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    SCANRS_HIP(hipStreamSynchronize(s));
+    std::vector<Item> its;
+    std::vector<MultiRow> mr;
+    its.reserve(n_outer + nnz / ITEM_NNZ + 1);
+    uint32_t slab = 0;
+    for (uint64_t o = 0; o < n_outer; o++) {
+        const uint64_t a = h[o], b = h[o + 1];
+        const uint64_t len = b - a;
+        if (len <= ITEM_NNZ) {
+            its.push_back(Item{a, (uint32_t)o, (uint32_t)len, NO_SLAB, 0});
+        } else {
+            const uint32_t pieces = (uint32_t)((len + ITEM_NNZ - 1) / ITEM_NNZ);
+            mr.push_back(MultiRow{(uint32_t)o, slab, pieces, 0});
+            for (uint32_t k = 0; k < pieces; k++) {
+                const uint64_t s0 = a + (uint64_t)k * ITEM_NNZ;
+                const uint64_t ln = std::min<uint64_t>(ITEM_NNZ, b - s0);
+                its.push_back(Item{s0, (uint32_t)o, (uint32_t)ln, slab++, 0});
+            }
+        }
+    }
+    n_items = (uint32_t)its.size();
+    n_multi = (uint32_t)mr.size();
+    n_slab = slab;
+    items.alloc(its.size());
+    multi.alloc(mr.size());
+    if (!its.empty()) SCANRS_HIP(hipMemcpyAsync(items.p, its.data(), its.size() * sizeof(Item), hipMemcpyHostToDevice, s));
+    if (!mr.empty()) SCANRS_HIP(hipMemcpyAsync(multi.p, mr.data(), mr.size() * sizeof(MultiRow), hipMemcpyHostToDevice, s));
+    SCANRS_HIP(hipStreamSynchronize(s));
+}
+
+void validate_copy(Storage &st, const SparseCopy &cp, uint64_t *zeros, uint64_t *bad) {
+    DevBuf<unsigned long long> c(2);
+    SCANRS_HIP(hipMemsetAsync(c.p, 0, 2 * sizeof(unsigned long long), st.stream));
+    if (cp.n_outer)
+        hipLaunchKernelGGL(validate_kernel, grid1(cp.n_outer, 256), dim3(256), 0, st.stream, cp.indptr.p, cp.n_outer,
+                           cp.indices.p, cp.values.p, cp.n_inner, c.p);
+    unsigned long long h[2];
+    SCANRS_HIP(hipMemcpyAsync(h, c.p, sizeof(h), hipMemcpyDeviceToHost, st.stream));
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    *zeros = h[0];
+    *bad = h[1];
+}
+
+void compact_nonzeros(Storage &st, SparseCopy &cp) {
+    // Rare path (AbsIter skips stored zeros, sqz/src/vec.rs:113): rebuild on the host.
+    std::vector<uint64_t> ip(cp.n_outer + 1);
+    std::vector<uint32_t> ind(cp.nnz), val(cp.nnz);
+    SCANRS_HIP(hipMemcpy(ip.data(), cp.indptr.p, ip.size() * 8, hipMemcpyDeviceToHost));
+    if (cp.nnz) {
+        SCANRS_HIP(hipMemcpy(ind.data(), cp.indices.p, cp.nnz * 4, hipMemcpyDeviceToHost));
+        SCANRS_HIP(hipMemcpy(val.data(), cp.values.p, cp.nnz * 4, hipMemcpyDeviceToHost));
+    }
+    std::vector<uint64_t> np(cp.n_outer + 1, 0);
+    uint64_t w = 0;
+    for (uint64_t o = 0; o < cp.n_outer; o++) {
+        np[o] = w;
+        for (uint64_t p = ip[o]; p < ip[o + 1]; p++)
+            if (val[p] != 0) {
+                ind[w] = ind[p];
+                val[w] = val[p];
+                w++;
+            }
+    }
+    np[cp.n_outer] = w;
+    cp.nnz = w;
+    SCANRS_HIP(hipMemcpy(cp.indptr.p, np.data(), np.size() * 8, hipMemcpyHostToDevice));
+    if (w) {
+        SCANRS_HIP(hipMemcpy(cp.indices.p, ind.data(), w * 4, hipMemcpyHostToDevice));
+        SCANRS_HIP(hipMemcpy(cp.values.p, val.data(), w * 4, hipMemcpyHostToDevice));
+    }
+    (void)st;
+}
+
+void build_transposed_copy(Storage &st, const SparseCopy &src, SparseCopy &dst) {
+    dst.n_outer = src.n_inner;
+    dst.n_inner = src.n_outer;
+    dst.nnz = src.nnz;
+    dst.indptr.alloc(dst.n_outer + 1);
+    dst.indices.alloc(std::max<uint64_t>(1, dst.nnz));
+    dst.values.alloc(std::max<uint64_t>(1, dst.nnz));
+    const uint64_t nnz = src.nnz;
+    if (nnz == 0) {
+        SCANRS_HIP(hipMemsetAsync(dst.indptr.p, 0, (dst.n_outer + 1) * 8, st.stream));
+        dst.build_items(st.stream);
+        return;
+    }
+    {
+        // stable LSD radix sort of (inner index, (outer id, value)): inner vectors come out with
+        // ascending outer ids, the order the reference's CSC kernel accumulates in (prod.rs:190-214).
+        DevBuf<uint32_t> keys_a(nnz), keys_b(nnz);
+        DevBuf<unsigned long long> vals_a(nnz), vals_b(nnz);
+        SCANRS_HIP(hipMemcpyAsync(keys_a.p, src.indices.p, nnz * 4, hipMemcpyDeviceToDevice, st.stream));
+        hipLaunchKernelGGL(pack_outer_kernel, grid1(nnz, 256), dim3(256), 0, st.stream, src.indptr.p, src.n_outer,
+                           src.values.p, nnz, vals_a.p);
+        unsigned end_bit = 1;
+        while (end_bit < 32 && (1ull << end_bit) < src.n_inner) end_bit++;
+        rocprim::double_buffer<uint32_t> kb(keys_a.p, keys_b.p);
+        rocprim::double_buffer<unsigned long long> vb(vals_a.p, vals_b.p);
+        size_t tmp_bytes = 0;
+        SCANRS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kb, vb, (size_t)nnz, 0u, end_bit, st.stream));
+        DevBuf<char> tmp(std::max<size_t>(tmp_bytes, 16));
+        SCANRS_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kb, vb, (size_t)nnz, 0u, end_bit, st.stream));
+        hipLaunchKernelGGL(unpack_kernel, grid1(nnz, 256), dim3(256), 0, st.stream, vb.current(), nnz, dst.indices.p,
+                           dst.values.p);
+        hipLaunchKernelGGL(lower_bound_kernel, grid1(dst.n_outer + 1, 256), dim3(256), 0, st.stream, kb.current(), nnz,
+                           dst.n_outer, dst.indptr.p);
+        SCANRS_HIP(hipGetLastError());
+        SCANRS_HIP(hipStreamSynchronize(st.stream));
+    }
+    dst.build_items(st.stream);
+}
+
+} // namespace scanrs

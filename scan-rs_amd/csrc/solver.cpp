@@ -1,0 +1,585 @@
+// Truncated-SVD drivers on device panels: svd_bk, svd_rand, irlba of scan-rs/src/dim_red/.
+//
+// The reference is generic over `T: DataMat + Dot<...>` (dim_red/bk_svd.rs:41-46); here T is the device
+// handle and the two products are mat_apply(.., transpose = false / true, ..). Panels that the reference
+// keeps as (b x m) row-major are held transposed, long-dimension-major (m x b), because that is the layout
+// the gather product reads one coalesced row per nonzero from.
+//
+// Dense steps: `.qr()?.0` (dgeqrf + dorgqr through ndarray-linalg) becomes block Gram-Schmidt +
+// CholeskyQR with re-orthogonalisation — any orthonormal basis of the same column space gives the same
+// Rayleigh-Ritz values, see DESIGN.md — and `svddc_into` of the 5b x n projection becomes an
+// eigendecomposition of its 5b x 5b Gram matrix (only the top k triplets are returned by the reference).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+
+namespace scanrs {
+
+// ---- rand-family generator for the seeded start panel ("parity unpinned", see oracle/scanrs_oracle.py) -----
+struct SmallRng {
+    uint64_t s[4];
+    explicit SmallRng(uint64_t seed) {
+        uint64_t state = seed;
+        for (int i = 0; i < 4; i++) {
+            state += 0x9E3779B97F4A7C15ull;
+            uint64_t z = state;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            s[i] = z ^ (z >> 31);
+        }
+    }
+    static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+    uint64_t next() {
+        const uint64_t result = rotl(s[0] + s[3], 23) + s[0];
+        const uint64_t t = s[1] << 17;
+        s[2] ^= s[0];
+        s[3] ^= s[1];
+        s[1] ^= s[2];
+        s[0] ^= s[3];
+        s[2] ^= t;
+        s[3] = rotl(s[3], 45);
+        return result;
+    }
+    double uniform_m1_1() { // Uniform::new(-1.0, 1.0): [1,2) mantissa trick, then * 2 + (-1)
+        const uint64_t bits = (next() >> 12) | 0x3FF0000000000000ull;
+        double v12;
+        memcpy(&v12, &bits, 8);
+        return (v12 - 1.0) * 2.0 + (-1.0);
+    }
+    double normal() { // Box-Muller on the same stream (the reference's ziggurat is not reproduced)
+        double u1, u2;
+        do {
+            u1 = ((double)(next() >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+        } while (u1 <= 0.0);
+        u2 = ((double)(next() >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+        return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    }
+};
+
+void omega_fill(uint64_t seed, uint64_t count, double *out) {
+    SmallRng rng(seed);
+    for (uint64_t i = 0; i < count; i++) out[i] = rng.uniform_m1_1();
+}
+
+// ---- snoop -------------------------------------------------------------------------------------------------
+static void progress_check(const scanrs_snoop *sn, double p) {
+    // CancelProgress::set_progress_check (snoop/src/lib.rs:45-57)
+    if (!sn) return;
+    if (sn->cancel && __atomic_load_n(sn->cancel, __ATOMIC_RELAXED)) fail(SCANRS_ERR_CANCELLED, "cancellation error");
+    if (sn->progress) sn->progress(sn->ctx, p);
+}
+
+// ---- panel helpers --------------------------------------------------------------------------------------------
+struct Ctx {
+    scanrs_mat *m;
+    Storage &st;
+    hipStream_t s;
+    explicit Ctx(scanrs_mat *mm) : m(mm), st(*mm->st), s(mm->st->stream) {}
+    double *dev(const char *key, size_t count) { return st.scratch.get<double>(key, count); }
+    void sync() { SCANRS_HIP(hipStreamSynchronize(s)); }
+    void h2d(double *d, const double *h, size_t n) {
+        SCANRS_HIP(hipMemcpyAsync(d, h, n * 8, hipMemcpyHostToDevice, s));
+        sync(); // host staging buffers are pageable and reused
+    }
+    void d2h(double *h, const double *d, size_t n) {
+        SCANRS_HIP(hipMemcpyAsync(h, d, n * 8, hipMemcpyDeviceToHost, s));
+        sync();
+    }
+};
+
+// upload a compact host matrix (rows x l) into a padded device panel
+static void upload_panel(Ctx &c, const double *h, uint64_t rows, uint32_t l, double *d, uint32_t ld) {
+    if (rows == 0 || l == 0) return;
+    SCANRS_HIP(hipMemcpy2DAsync(d, (size_t)ld * 8, h, (size_t)l * 8, (size_t)l * 8, rows, hipMemcpyHostToDevice, c.s));
+    c.sync();
+}
+static void download_panel(Ctx &c, const double *d, uint32_t ld, uint64_t rows, uint32_t l, double *h) {
+    if (rows == 0 || l == 0) return;
+    SCANRS_HIP(hipMemcpy2DAsync(h, (size_t)l * 8, d, (size_t)ld * 8, (size_t)l * 8, rows, hipMemcpyDeviceToHost, c.s));
+    c.sync();
+}
+
+// Gram matrix of two panels that live on the same side; reduced across ranks when that side is sharded.
+static void gram_host(Ctx &c, const double *X, uint32_t ldx, uint32_t n, const double *Y, uint32_t ldy, uint32_t m,
+                      uint64_t rows, bool sharded_rows, std::vector<double> &out) {
+    double *dC = c.dev("gram_out", (size_t)n * m);
+    launch_gram(c.st, X, ldx, n, Y, ldy, m, rows, dC);
+    if (sharded_rows) allreduce_f64(c.st, dC, (uint64_t)n * m);
+    out.resize((size_t)n * m);
+    c.d2h(out.data(), dC, out.size());
+}
+
+// Out = beta * Out + alpha * X * W with a host W (n x m, row-major)
+static void gemm_hostw(Ctx &c, const double *X, uint32_t ldx, uint32_t n, const std::vector<double> &W, uint32_t m,
+                       uint64_t rows, double alpha, double beta, double *Out, uint32_t ldo, const char *wkey = "gemm_w") {
+    double *dW = c.dev(wkey, (size_t)n * m);
+    c.h2d(dW, W.data(), (size_t)n * m);
+    launch_gemm_nn(c.st, X, ldx, n, dW, m, m, rows, alpha, beta, Out, ldo, Out, ldo);
+}
+
+// Orthonormalise the columns of P (rows x n, ld) in place: iterated CholeskyQR, with a diagonal shift
+// when the Gram matrix is numerically singular (shifted CholeskyQR). tmp: same size as P.
+static void orth_cholqr(Ctx &c, double *P, double *tmp, uint32_t ld, uint32_t n, uint64_t rows, bool sharded_rows) {
+    std::vector<double> G, R;
+    for (int pass = 0; pass < 8; pass++) {
+        gram_host(c, P, ld, n, P, ld, n, rows, sharded_rows, G);
+        double err = 0.0, dmax = 0.0;
+        for (uint32_t i = 0; i < n; i++)
+            for (uint32_t j = 0; j < n; j++) {
+                const double g = G[(size_t)i * n + j];
+                if (!std::isfinite(g)) fail(SCANRS_ERR_NUMERICAL, "orthonormalisation: non-finite Gram matrix");
+                err = std::max(err, std::fabs(g - (i == j ? 1.0 : 0.0)));
+                if (i == j) dmax = std::max(dmax, g);
+            }
+        if (pass >= 1 && err < 5e-14 * std::sqrt((double)n)) return;
+        R = G;
+        double shift = 0.0;
+        int tries = 0;
+        while (!chol_upper(R.data(), (int)n)) {
+            // shifted CholeskyQR (Fukaya et al. 2020): G + s I, s ~ 11 (rows n + n(n+1)) u ||X||^2
+            shift = shift == 0.0 ? 11.0 * ((double)rows * n + (double)n * (n + 1)) * 1.1e-16 * dmax : shift * 100.0;
+            if (++tries > 12 || !(dmax > 0.0)) fail(SCANRS_ERR_NUMERICAL, "orthonormalisation: Cholesky failed");
+            R = G;
+            for (uint32_t i = 0; i < n; i++) R[(size_t)i * n + i] += shift;
+        }
+        inv_upper(R.data(), (int)n);
+        double *dW = c.dev("orth_w", (size_t)n * n);
+        c.h2d(dW, R.data(), (size_t)n * n);
+        launch_gemm_nn(c.st, P, ld, n, dW, n, n, rows, 1.0, 0.0, nullptr, 0, tmp, ld);
+        SCANRS_HIP(hipMemcpyAsync(P, tmp, (size_t)rows * ld * 8, hipMemcpyDeviceToDevice, c.s));
+    }
+    fail(SCANRS_ERR_NUMERICAL, "orthonormalisation did not converge");
+}
+
+// Orthonormalise block `Bj` (rows x b, ld ldb) against the first `nprev` columns of Q (ld ldq) and
+// within itself; rounds of (project, CholeskyQR) until the projection is at rounding level.
+static void orth_against(Ctx &c, const double *Q, uint32_t ldq, uint32_t nprev, double *Bj, double *tmp, uint32_t ldb,
+                         uint32_t b, uint64_t rows, bool sharded_rows) {
+    std::vector<double> C;
+    for (int round = 0; round < 4; round++) {
+        if (nprev) {
+            gram_host(c, Q, ldq, nprev, Bj, ldb, b, rows, sharded_rows, C);
+            double cmax = 0.0;
+            for (double x : C) cmax = std::max(cmax, std::fabs(x));
+            if (round >= 1 && cmax < 1e-14) return;
+            gemm_hostw(c, Q, ldq, nprev, C, b, rows, -1.0, 1.0, Bj, ldb);
+        }
+        orth_cholqr(c, Bj, tmp, ldb, b, rows, sharded_rows);
+        if (!nprev) return;
+    }
+}
+
+// Which side of the view is long / sharded
+static bool dim_sharded_rows(const scanrs_mat *m) { return rows_sharded(m); }
+static bool dim_sharded_cols(const scanrs_mat *m) { return cols_sharded(m); }
+
+// Rayleigh-Ritz finish shared by svd_bk and svd_rand: given an orthonormal Q on side S (dimension ds,
+// q columns), T = op(Q) on the other side (dimension dt), return the top-k triplets.
+//   side_S_vectors = Q * E, side_T_vectors = T * E * Sigma^-1, sigma = sqrt(eig(T^T T)).
+static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint64_t ds, const double *T, uint32_t ldt,
+                        uint64_t dt, bool t_sharded, uint32_t k, double *hS, double *hSigma, double *hT) {
+    std::vector<double> G;
+    gram_host(c, T, ldt, q, T, ldt, q, dt, t_sharded, G);
+    for (uint32_t i = 0; i < q; i++) // symmetrise against rounding asymmetry
+        for (uint32_t j = i + 1; j < q; j++) {
+            const double a = 0.5 * (G[(size_t)i * q + j] + G[(size_t)j * q + i]);
+            G[(size_t)i * q + j] = G[(size_t)j * q + i] = a;
+        }
+    std::vector<double> w(q), Z((size_t)q * q);
+    if (!sym_eig(G.data(), (int)q, w.data(), Z.data())) fail(SCANRS_ERR_NUMERICAL, "eigensolver did not converge");
+    std::vector<double> E((size_t)q * k), Es((size_t)q * k);
+    for (uint32_t j = 0; j < k; j++) {
+        const double sig = std::sqrt(std::max(w[j], 0.0));
+        hSigma[j] = sig;
+        const double inv = sig > 0.0 ? 1.0 / sig : 0.0;
+        for (uint32_t i = 0; i < q; i++) {
+            E[(size_t)i * k + j] = Z[(size_t)i * q + j];
+            Es[(size_t)i * k + j] = Z[(size_t)i * q + j] * inv;
+        }
+    }
+    const uint32_t ldk = even_up(k);
+    double *dS = c.dev("ritz_s", (size_t)ds * ldk);
+    double *dT = c.dev("ritz_t", (size_t)dt * ldk);
+    double *dE = c.dev("ritz_e", (size_t)q * k);
+    c.h2d(dE, E.data(), E.size());
+    launch_gemm_nn(c.st, Q, ldq, q, dE, k, k, ds, 1.0, 0.0, nullptr, 0, dS, ldk);
+    double *dEs = c.dev("ritz_es", (size_t)q * k);
+    c.h2d(dEs, Es.data(), Es.size());
+    launch_gemm_nn(c.st, T, ldt, q, dEs, k, k, dt, 1.0, 0.0, nullptr, 0, dT, ldk);
+    download_panel(c, dS, ldk, ds, k, hS);
+    download_panel(c, dT, ldk, dt, k, hT);
+}
+
+int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
+           const scanrs_snoop *snoop, double *u, double *s, double *v) {
+    Ctx c(m);
+    const uint64_t M = m->rows(), N = m->cols();
+    // global extents decide the branch and the validation, as the reference sees the whole matrix
+    const uint64_t Mg = dim_sharded_rows(m) ? c.st.shard.outer_global : M;
+    const uint64_t Ng = dim_sharded_cols(m) ? c.st.shard.outer_global : N;
+    if (Mg < 2 || Ng < 2) fail(SCANRS_ERR_SHAPE, "The input matrix must be at least 2x2.");
+    if (k > std::min(Mg, Ng)) fail(SCANRS_ERR_INVALID_K, "invalid k");
+    if (k == 0 || n_iter == 0) fail(SCANRS_ERR_ARGUMENT, "k and n_iter must be positive");
+    uint32_t b = (uint32_t)std::ceil((double)k * k_multiplier); // bk_svd.rs:49
+    b = (uint32_t)std::min<uint64_t>(std::min(Mg, Ng), b);     // bk_svd.rs:81
+    if (b < k) fail(SCANRS_ERR_INVALID_K, "invalid k");
+
+    const bool rows_ge = Mg >= Ng; // bk_svd.rs:89 `if m >= n`
+    // S = the side the Krylov panel lives on (the shorter one): cols when m >= n, rows otherwise.
+    const uint64_t ds = rows_ge ? N : M, dt = rows_ge ? M : N;
+    const bool s_sharded = rows_ge ? dim_sharded_cols(m) : dim_sharded_rows(m);
+    const bool t_sharded = rows_ge ? dim_sharded_rows(m) : dim_sharded_cols(m);
+    if (s_sharded) fail(SCANRS_ERR_ARGUMENT, "shard the longer dimension of the matrix, not the shorter one");
+    // op S->T: A*X when m >= n (X on the cols side), A^T*X otherwise
+    const bool to_t_transpose = !rows_ge;
+
+    const uint32_t ldb = even_up(b), q = b * n_iter, ldq = even_up(q);
+    if ((uint64_t)q > ds) fail(SCANRS_ERR_INVALID_K, "block size times iterations exceeds the matrix dimension");
+    double *P = c.dev("bk_P", (size_t)ds * ldb);
+    double *Ptmp = c.dev("bk_Ptmp", (size_t)ds * ldb);
+    double *Y = c.dev("bk_Y", (size_t)dt * ldb);
+    double *K = c.dev("bk_K", (size_t)ds * ldq);
+    SCANRS_HIP(hipMemsetAsync(P, 0, (size_t)ds * ldb * 8, c.s));
+    SCANRS_HIP(hipMemsetAsync(K, 0, (size_t)ds * ldq * 8, c.s));
+
+    { // start panel: m >= n -> (n x b) as is; n > m -> reference holds (b x m), we hold its transpose
+        std::vector<double> h((size_t)ds * b);
+        if (rows_ge) {
+            if (omega)
+                memcpy(h.data(), omega, h.size() * 8);
+            else
+                omega_fill(seed, h.size(), h.data());
+        } else {
+            std::vector<double> t((size_t)b * ds);
+            if (omega)
+                memcpy(t.data(), omega, t.size() * 8);
+            else
+                omega_fill(seed, t.size(), t.data());
+            for (uint32_t i = 0; i < b; i++)
+                for (uint64_t j = 0; j < ds; j++) h[j * b + i] = t[(size_t)i * ds + j];
+        }
+        upload_panel(c, h.data(), ds, b, P, ldb);
+    }
+
+    for (uint32_t i = 0; i < n_iter; i++) {
+        // m >= n: B = qr((A B)^T A)^T .Q  (bk_svd.rs:94);  n > m: T = (B A)^T; B = qr(A T).Q^T  (bk_svd.rs:122-123)
+        mat_apply(m, to_t_transpose, P, ldb, b, Y, ldb);
+        mat_apply(m, !to_t_transpose, Y, ldb, b, P, ldb);
+        orth_cholqr(c, P, Ptmp, ldb, b, ds, false);
+        launch_copy_cols(c.st, P, ldb, K + (size_t)i * b, ldq, ds, b);
+        c.sync();
+        progress_check(snoop, (double)i / (double)n_iter * 0.8);
+    }
+    // Q = qr(K).Q: block i is already orthonormal; orthogonalise it against blocks < i.
+    {
+        double *Bj = c.dev("bk_Bj", (size_t)ds * ldb);
+        for (uint32_t i = 1; i < n_iter; i++) {
+            launch_copy_cols(c.st, K + (size_t)i * b, ldq, Bj, ldb, ds, b);
+            orth_against(c, K, ldq, i * b, Bj, Ptmp, ldb, b, ds, false);
+            launch_copy_cols(c.st, Bj, ldb, K + (size_t)i * b, ldq, ds, b);
+        }
+        c.sync();
+    }
+    progress_check(snoop, 0.82);
+    double *T = c.dev("bk_T", (size_t)dt * ldq);
+    mat_apply(m, to_t_transpose, K, ldq, q, T, ldq);
+    c.sync();
+    progress_check(snoop, 0.93);
+    // m >= n: T = A Q (m x q): U = T E S^-1, V = Q E.   n > m: T^T = A^T Q (n x q): U = Q E, V = T E S^-1.
+    if (rows_ge)
+        ritz_finish(c, K, ldq, q, ds, T, ldq, dt, t_sharded, k, v, s, u);
+    else
+        ritz_finish(c, K, ldq, q, ds, T, ldq, dt, t_sharded, k, u, s, v);
+    progress_check(snoop, 1.0);
+    return SCANRS_OK;
+}
+
+int pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, uint64_t seed, const double *omega, double *u,
+             double *s, double *v) {
+    Ctx c(m);
+    const uint64_t M = m->rows(), N = m->cols();
+    const uint64_t Mg = dim_sharded_rows(m) ? c.st.shard.outer_global : M;
+    const uint64_t Ng = dim_sharded_cols(m) ? c.st.shard.outer_global : N;
+    if (Mg < 2 || Ng < 2) fail(SCANRS_ERR_SHAPE, "The input matrix must be at least 2x2.");
+    if (k > std::min(Mg, Ng)) fail(SCANRS_ERR_INVALID_K, "invalid k");
+    if (k == 0) fail(SCANRS_ERR_ARGUMENT, "k must be positive");
+    const uint32_t l = (uint32_t)std::max<uint64_t>(k + 4, (uint64_t)((double)k * l_multiplier)); // rand_svd.rs:46
+    if ((uint64_t)l > std::min(Mg, Ng)) fail(SCANRS_ERR_INVALID_K, "projection width exceeds the matrix dimension");
+    const bool rows_ge = Mg >= Ng;
+    // m >= n: Omega on the cols side (n x l); Q ends on the rows side.  n > m: Omega (l x m), Q ends on the cols side.
+    const uint64_t d_om = rows_ge ? N : M, d_q = rows_ge ? M : N;
+    const bool om_sharded = rows_ge ? dim_sharded_cols(m) : dim_sharded_rows(m);
+    const bool q_sharded = rows_ge ? dim_sharded_rows(m) : dim_sharded_cols(m);
+    const bool om_to_q_transpose = !rows_ge; // A*X when m >= n
+    const uint32_t ldl = even_up(l);
+    double *Om = c.dev("rs_Om", (size_t)d_om * ldl);
+    double *Qp = c.dev("rs_Q", (size_t)d_q * ldl);
+    double *tmp = c.dev("rs_tmp", (size_t)std::max(d_om, d_q) * ldl);
+    SCANRS_HIP(hipMemsetAsync(Om, 0, (size_t)d_om * ldl * 8, c.s));
+    {
+        if (om_sharded && !omega) fail(SCANRS_ERR_ARGUMENT, "a sharded start panel must be passed explicitly");
+        std::vector<double> h((size_t)d_om * l);
+        if (rows_ge) {
+            if (omega)
+                memcpy(h.data(), omega, h.size() * 8);
+            else
+                omega_fill(seed, h.size(), h.data());
+        } else {
+            std::vector<double> t((size_t)l * d_om);
+            if (omega)
+                memcpy(t.data(), omega, t.size() * 8);
+            else
+                omega_fill(seed, t.size(), t.data());
+            for (uint32_t i = 0; i < l; i++)
+                for (uint64_t j = 0; j < d_om; j++) h[j * l + i] = t[(size_t)i * d_om + j];
+        }
+        upload_panel(c, h.data(), d_om, l, Om, ldl);
+    }
+    // Q = qr(A Omega).Q   (rand_svd.rs:87 / :109)
+    mat_apply(m, om_to_q_transpose, Om, ldl, l, Qp, ldl);
+    orth_cholqr(c, Qp, tmp, ldl, l, d_q, q_sharded);
+    for (uint32_t it = 0; it < n_iter; it++) { // rand_svd.rs:89-92 / :111-114
+        mat_apply(m, !om_to_q_transpose, Qp, ldl, l, Om, ldl);
+        orth_cholqr(c, Om, tmp, ldl, l, d_om, om_sharded);
+        mat_apply(m, om_to_q_transpose, Om, ldl, l, Qp, ldl);
+        orth_cholqr(c, Qp, tmp, ldl, l, d_q, q_sharded);
+    }
+    // B = Q^T A  (l x n)  resp. B = A Q: its transpose/ itself lives on the Omega side
+    mat_apply(m, !om_to_q_transpose, Qp, ldl, l, Om, ldl);
+    c.sync();
+    if (rows_ge)
+        ritz_finish(c, Qp, ldl, l, d_q, Om, ldl, d_om, om_sharded, k, u, s, v);
+    else
+        ritz_finish(c, Qp, ldl, l, d_q, Om, ldl, d_om, om_sharded, k, v, s, u);
+    return SCANRS_OK;
+}
+
+// ---- IRLBA (scan-rs/src/dim_red/irlba.rs:71-215), vectors on the device, small B on the host -----------------
+namespace {
+struct Vecs {
+    Ctx &c;
+    explicit Vecs(Ctx &cc) : c(cc) {}
+};
+} // namespace
+
+// y <- y - X (X^T y) for the first j columns of X (rows x ldx); irlba.rs:19-22
+static void orthog_dev(Ctx &c, double *y, const double *X, uint32_t ldx, uint32_t j, uint64_t rows, bool sharded) {
+    if (j == 0) return;
+    std::vector<double> dotv;
+    gram_host(c, X, ldx, j, y, 2, 1, rows, sharded, dotv);
+    gemm_hostw(c, X, ldx, j, dotv, 1, rows, -1.0, 1.0, y, 2, "irlba_w");
+}
+static double norm_dev(Ctx &c, const double *y, uint64_t rows, bool sharded) {
+    std::vector<double> g;
+    gram_host(c, y, 2, 1, y, 2, 1, rows, sharded, g);
+    return std::sqrt(g[0]);
+}
+static double invcheck(double x) { // irlba.rs:25-33
+    const double eps2 = 2.0 * 2.220446049250313e-16;
+    return x > eps2 ? 1.0 / x : 0.0;
+}
+// dst[:, col] (ld) <- alpha * src (ld 2)
+static void set_col(Ctx &c, double *dst, uint32_t ld, uint32_t col, const double *src, uint64_t rows, double alpha) {
+    std::vector<double> a(1, alpha);
+    double *dW = c.dev("irlba_a", 1);
+    c.h2d(dW, a.data(), 1);
+    launch_gemm_nn(c.st, src, 2, 1, dW, 1, 1, rows, 1.0, 0.0, nullptr, 0, dst + col, ld);
+}
+static void get_col(Ctx &c, const double *src, uint32_t ld, uint32_t col, double *dst, uint64_t rows) {
+    launch_copy_cols(c.st, src + col, ld, dst, 2, rows, 1);
+}
+
+// tiny dense SVD of the m_b x m_b matrix B via the eigen-decomposition of B^T B and B B^T is not accurate
+// enough for the residual test; use one-sided Jacobi (Hestenes) instead: B = U S V^T.
+static void small_svd(std::vector<double> B, int n, std::vector<double> &U, std::vector<double> &S, std::vector<double> &Vt) {
+    // work on columns of A = B (n x n), V = I
+    std::vector<double> V((size_t)n * n, 0.0);
+    for (int i = 0; i < n; i++) V[(size_t)i * n + i] = 1.0;
+    auto col = [&](std::vector<double> &Mx, int j, int i) -> double & { return Mx[(size_t)i * n + j]; };
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double a = 0, b = 0, g = 0;
+                for (int i = 0; i < n; i++) {
+                    a += col(B, p, i) * col(B, p, i);
+                    b += col(B, q, i) * col(B, q, i);
+                    g += col(B, p, i) * col(B, q, i);
+                }
+                if (g == 0.0 || std::fabs(g) <= 1e-300) continue;
+                off = std::max(off, std::fabs(g) / std::sqrt(std::max(a * b, 1e-300)));
+                if (std::fabs(g) <= 1e-16 * std::sqrt(a * b)) continue;
+                const double zeta = (b - a) / (2.0 * g);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+                for (int i = 0; i < n; i++) {
+                    const double x = col(B, p, i), y = col(B, q, i);
+                    col(B, p, i) = cs * x - sn * y;
+                    col(B, q, i) = sn * x + cs * y;
+                    const double vx = col(V, p, i), vy = col(V, q, i);
+                    col(V, p, i) = cs * vx - sn * vy;
+                    col(V, q, i) = sn * vx + cs * vy;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    std::vector<double> sv(n);
+    std::vector<int> ord(n);
+    for (int j = 0; j < n; j++) {
+        double a = 0;
+        for (int i = 0; i < n; i++) a += col(B, j, i) * col(B, j, i);
+        sv[j] = std::sqrt(a);
+        ord[j] = j;
+    }
+    std::sort(ord.begin(), ord.end(), [&](int x, int y) { return sv[x] > sv[y]; });
+    U.assign((size_t)n * n, 0.0);
+    Vt.assign((size_t)n * n, 0.0);
+    S.assign(n, 0.0);
+    for (int jj = 0; jj < n; jj++) {
+        const int j = ord[jj];
+        S[jj] = sv[j];
+        for (int i = 0; i < n; i++) {
+            U[(size_t)i * n + jj] = sv[j] > 0 ? col(B, j, i) / sv[j] : (i == jj ? 1.0 : 0.0);
+            Vt[(size_t)jj * n + i] = col(V, j, i);
+        }
+    }
+}
+
+int pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t maxit, const double *v0, const scanrs_snoop *snoop, double *u,
+              double *s, double *v, uint32_t *mprod_out) {
+    Ctx c(m);
+    const uint64_t M = m->rows(), N = m->cols();
+    if (c.st.shard.active()) fail(SCANRS_ERR_ARGUMENT, "irlba: sharded matrices are not supported");
+    if (M < 2 || N < 2) fail(SCANRS_ERR_SHAPE, "The input matrix must be at least 2x2.");
+    if (nu > std::min(M, N) || nu == 0) fail(SCANRS_ERR_INVALID_K, "invalid k");
+    if (m->off_rank) fail(SCANRS_ERR_ARGUMENT, "irlba: LowRankOffset has no Ix1 Dot impl in the reference (low_rank_offset.rs:68-96)");
+    const uint32_t m_b = (uint32_t)std::min<uint64_t>(nu + 20, std::min<uint64_t>(3ull * nu, N)); // irlba.rs:87
+    if (m_b < 4 || m_b <= nu) fail(SCANRS_ERR_INVALID_K, "invalid k");
+    const uint32_t ldm = even_up(m_b);
+    uint32_t mprod = 0, it = 0, j = 0, k = nu;
+    double smax = -1.7976931348623157e308;
+    double *V = c.dev("ir_V", (size_t)N * ldm), *W = c.dev("ir_W", (size_t)M * ldm);
+    double *F = c.dev("ir_F", (size_t)N * 2), *wv = c.dev("ir_w", (size_t)M * 2), *vv = c.dev("ir_v", (size_t)N * 2);
+    double *Vn = c.dev("ir_Vn", (size_t)N * ldm), *Wn = c.dev("ir_Wn", (size_t)M * ldm);
+    SCANRS_HIP(hipMemsetAsync(V, 0, (size_t)N * ldm * 8, c.s));
+    SCANRS_HIP(hipMemsetAsync(W, 0, (size_t)M * ldm * 8, c.s));
+    SCANRS_HIP(hipMemsetAsync(F, 0, (size_t)N * 2 * 8, c.s));
+    SCANRS_HIP(hipMemsetAsync(wv, 0, (size_t)M * 2 * 8, c.s));
+    SCANRS_HIP(hipMemsetAsync(vv, 0, (size_t)N * 2 * 8, c.s));
+    std::vector<double> B((size_t)m_b * m_b, 0.0), Us, Ss, Vts;
+    {
+        std::vector<double> h(N);
+        if (v0)
+            memcpy(h.data(), v0, N * 8);
+        else {
+            SmallRng rng(0);
+            for (auto &x : h) x = rng.normal();
+        }
+        double nn = 0;
+        for (double x : h) nn += x * x;
+        nn = 1.0 / std::sqrt(nn);
+        for (auto &x : h) x *= nn;
+        upload_panel(c, h.data(), N, 1, vv, 2);
+        set_col(c, V, ldm, 0, vv, N, 1.0);
+    }
+    double fnorm = 0.0;
+    std::vector<double> resid(m_b);
+    while (it < maxit) {
+        if (it > 0) j = k;
+        get_col(c, V, ldm, j, vv, N);
+        mat_apply(m, false, vv, 2, 1, wv, 2); // W[:, j] = A V[:, j]
+        mprod++;
+        if (it > 0) orthog_dev(c, wv, W, ldm, j, M, false); // irlba.rs:131-134 (assigned to column k == j)
+        double sn = norm_dev(c, wv, M, false);
+        double sinv = invcheck(sn);
+        set_col(c, W, ldm, j, wv, M, sinv);
+        while (j < m_b) {
+            get_col(c, W, ldm, j, wv, M);
+            mat_apply(m, true, wv, 2, 1, F, 2); // F = W[:, j]^T A
+            mprod++;
+            { // F -= V[:, j] * s
+                std::vector<double> a(1, -sn);
+                get_col(c, V, ldm, j, vv, N);
+                gemm_hostw(c, vv, 2, 1, a, 1, N, 1.0, 1.0, F, 2, "irlba_w");
+            }
+            orthog_dev(c, F, V, ldm, j + 1, N, false);
+            fnorm = norm_dev(c, F, N, false);
+            const double finv = invcheck(fnorm);
+            set_col(c, F, 2, 0, F, N, finv); // F *= finv (in place through the scale path)
+            if (j == m_b - 1) {
+                B[(size_t)j * m_b + j] = sn;
+            } else {
+                set_col(c, V, ldm, j + 1, F, N, 1.0);
+                B[(size_t)j * m_b + j] = sn;
+                B[(size_t)j * m_b + j + 1] = fnorm;
+                mat_apply(m, false, F, 2, 1, wv, 2); // A V[:, j+1] (the reference computes it twice, irlba.rs:152,155)
+                mprod += 1;
+                {
+                    std::vector<double> a(1, -fnorm);
+                    double *wj = c.dev("ir_wj", (size_t)M * 2);
+                    get_col(c, W, ldm, j, wj, M);
+                    gemm_hostw(c, wj, 2, 1, a, 1, M, 1.0, 1.0, wv, 2, "irlba_w");
+                }
+                orthog_dev(c, wv, W, ldm, j + 1, M, false);
+                sn = norm_dev(c, wv, M, false);
+                sinv = invcheck(sn);
+                set_col(c, W, ldm, j + 1, wv, M, sinv);
+            }
+            j++;
+        }
+        small_svd(B, (int)m_b, Us, Ss, Vts);
+        for (uint32_t i = 0; i < m_b; i++) resid[i] = fnorm * Us[(size_t)(m_b - 1) * m_b + i];
+        smax = Ss[0] > smax ? Ss[0] : smax;
+        uint32_t num_converged = 0;
+        for (uint32_t i = 0; i < nu; i++)
+            if (resid[i] < tol * smax) num_converged++; // no abs(), as irlba.rs:176-180
+        if (num_converged < nu) {
+            k = std::max(num_converged + nu, k);
+            k = std::min(k, m_b - 3);
+        } else {
+            break;
+        }
+        { // Ritz vector update, irlba.rs:190-203
+            std::vector<double> Wm((size_t)m_b * k);
+            for (uint32_t r = 0; r < m_b; r++)
+                for (uint32_t q2 = 0; q2 < k; q2++) Wm[(size_t)r * k + q2] = Vts[(size_t)q2 * m_b + r]; // vt.t()[:, 0..k]
+            double *dW = c.dev("irlba_w2", (size_t)m_b * k);
+            c.h2d(dW, Wm.data(), Wm.size());
+            launch_gemm_nn(c.st, V, ldm, m_b, dW, k, k, N, 1.0, 0.0, nullptr, 0, Vn, ldm);
+            launch_copy_cols(c.st, Vn, ldm, V, ldm, N, k);
+            set_col(c, V, ldm, k, F, N, 1.0);
+            std::fill(B.begin(), B.end(), 0.0);
+            for (uint32_t l2 = 0; l2 < k; l2++) B[(size_t)l2 * m_b + l2] = Ss[l2];
+            for (uint32_t l2 = 0; l2 < k; l2++) B[(size_t)l2 * m_b + k] = resid[l2];
+            for (uint32_t r = 0; r < m_b; r++)
+                for (uint32_t q2 = 0; q2 < k; q2++) Wm[(size_t)r * k + q2] = Us[(size_t)r * m_b + q2];
+            c.h2d(dW, Wm.data(), Wm.size());
+            launch_gemm_nn(c.st, W, ldm, m_b, dW, k, k, M, 1.0, 0.0, nullptr, 0, Wn, ldm);
+            launch_copy_cols(c.st, Wn, ldm, W, ldm, M, k);
+        }
+        it++;
+        c.sync();
+        progress_check(snoop, (double)it / (double)maxit);
+    }
+    {
+        std::vector<double> Wm((size_t)m_b * nu);
+        for (uint32_t r = 0; r < m_b; r++)
+            for (uint32_t q2 = 0; q2 < nu; q2++) Wm[(size_t)r * nu + q2] = Us[(size_t)r * m_b + q2];
+        double *dW = c.dev("irlba_w2", (size_t)m_b * nu);
+        c.h2d(dW, Wm.data(), Wm.size());
+        launch_gemm_nn(c.st, W, ldm, m_b, dW, nu, nu, M, 1.0, 0.0, nullptr, 0, Wn, ldm);
+        download_panel(c, Wn, ldm, M, nu, u);
+        for (uint32_t r = 0; r < m_b; r++)
+            for (uint32_t q2 = 0; q2 < nu; q2++) Wm[(size_t)r * nu + q2] = Vts[(size_t)q2 * m_b + r];
+        c.h2d(dW, Wm.data(), Wm.size());
+        launch_gemm_nn(c.st, V, ldm, m_b, dW, nu, nu, N, 1.0, 0.0, nullptr, 0, Vn, ldm);
+        download_panel(c, Vn, ldm, N, nu, v);
+        for (uint32_t i = 0; i < nu; i++) s[i] = Ss[i];
+    }
+    if (mprod_out) *mprod_out = mprod;
+    return SCANRS_OK;
+}
+
+} // namespace scanrs

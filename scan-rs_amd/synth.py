@@ -1,0 +1,89 @@
+"""Synthetic sparse UMI count matrices of the shapes BASELINE.json names.
+
+Model (after scan-rs/src/dim_red/test.rs:227-253, `gene_exp_sim_sprs_ex`): `n_clusters`
+cluster profiles of per-gene rates ~ Gamma(0.4, 2.0); a cell belongs to one cluster and has a
+log-normal depth factor; gene g is present in cell c with probability
+min(1, depth_c * rate[cluster_c, g] * density / mean(rate)); stored counts are
+1 + Geometric(0.6) (about 90 % of the values below 4, all well below the 4-bit design point
+of sqz/src/vec.rs:758-759).  Cell-major: rows are cells, columns genes, indices ascending.
+
+`synth_counts` (numpy, host) feeds the oracle and the parity tests; `synth_counts_torch`
+builds the same model directly in device memory for bench.py (a different random stream).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _profiles(rng, n_clusters, n_genes):
+    return rng.gamma(0.4, 2.0, size=(n_clusters, n_genes))
+
+
+def synth_counts(n_cells: int, n_genes: int, density: float, seed: int = 0, n_clusters: int = 20, chunk: int = 2048):
+    """Returns a scipy.sparse.csr_matrix (n_cells x n_genes) with uint32 data, sorted indices."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(seed)
+    rates = _profiles(rng, n_clusters, n_genes)
+    scale = density / rates.mean()
+    cluster = rng.integers(0, n_clusters, size=n_cells)
+    depth = np.exp(rng.normal(0.0, 0.3, size=n_cells))
+    indptr = np.zeros(n_cells + 1, dtype=np.uint64)
+    idx_parts, val_parts = [], []
+    for c0 in range(0, n_cells, chunk):
+        c1 = min(n_cells, c0 + chunk)
+        p = depth[c0:c1, None] * rates[cluster[c0:c1], :] * scale
+        mask = rng.random((c1 - c0, n_genes)) < p
+        rows, cols = np.nonzero(mask)
+        counts = np.bincount(rows, minlength=c1 - c0)
+        indptr[c0 + 1:c1 + 1] = counts
+        idx_parts.append(cols.astype(np.uint32))
+        val_parts.append(rng.geometric(0.6, size=cols.shape[0]).astype(np.uint32))
+    indptr = np.cumsum(indptr, dtype=np.uint64)
+    indices = np.concatenate(idx_parts) if idx_parts else np.zeros(0, dtype=np.uint32)
+    values = np.concatenate(val_parts) if val_parts else np.zeros(0, dtype=np.uint32)
+    m = sp.csr_matrix((values, indices.astype(np.int64), indptr.astype(np.int64)), shape=(n_cells, n_genes))
+    m.has_sorted_indices = True
+    return m
+
+
+def synth_counts_torch(n_cells: int, n_genes: int, density: float, seed: int, device, cell_begin: int = 0,
+                       cell_end: int | None = None, n_clusters: int = 20, chunk: int = 4096):
+    """Device-side generator: returns (indptr int64[n_local+1], indices int32[nnz], values int32[nnz])
+    for cells [cell_begin, cell_end) of the global matrix. Every chunk of `chunk` global cells has its own
+    generator seed, so any partition of the cells over ranks yields the same global matrix."""
+    import torch
+
+    cell_end = n_cells if cell_end is None else cell_end
+    g0 = torch.Generator(device=device)
+    g0.manual_seed(seed)
+    conc = torch.full((n_clusters, n_genes), 0.4, device=device, dtype=torch.float32)
+    # Gamma(0.4, scale 2.0): standard gamma * 2 (drawn once, identically on every rank)
+    torch.manual_seed(seed)
+    rates = torch._standard_gamma(conc) * 2.0
+    scale = density / float(rates.mean())
+    counts_parts, idx_parts, val_parts = [], [], []
+    first_chunk = cell_begin // chunk
+    last_chunk = (cell_end + chunk - 1) // chunk
+    for ci in range(first_chunk, last_chunk):
+        c0, c1 = ci * chunk, min(n_cells, (ci + 1) * chunk)
+        g = torch.Generator(device=device)
+        g.manual_seed(seed * 1000003 + 17 * ci + 1)
+        n = c1 - c0
+        cluster = torch.randint(0, n_clusters, (n,), device=device, generator=g)
+        depth = torch.exp(torch.randn(n, device=device, generator=g) * 0.3)
+        p = depth[:, None] * rates[cluster, :] * scale
+        mask = torch.rand((n, n_genes), device=device, generator=g) < p
+        lo, hi = max(c0, cell_begin) - c0, min(c1, cell_end) - c0
+        mask = mask[lo:hi]
+        nz = mask.nonzero()
+        counts_parts.append(mask.sum(dim=1))
+        idx_parts.append(nz[:, 1].to(torch.int32))
+        u = torch.rand(nz.shape[0], device=device, generator=g).clamp_(min=1e-12)
+        # Geometric(0.6) on {1, 2, ...}: 1 + floor(log(u) / log(1 - 0.6))
+        val_parts.append((1 + torch.floor(torch.log(u) / np.log(0.4))).to(torch.int32))
+        del p, mask, nz, u
+    counts = torch.cat(counts_parts)
+    indptr = torch.zeros(counts.shape[0] + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(counts, dim=0)
+    return indptr, torch.cat(idx_parts), torch.cat(val_parts)

@@ -1,0 +1,425 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes -> libscanrs_amd.so), against the
+CPU oracle and the reference's golden tables. Integer / index work is bit-exact; f64 work is compared
+at the tolerances written next to each assert."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import scanrs_oracle as so  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import scanrs_amd
+
+    if not scanrs_amd.device_available():
+        pytest.fail("gfx950 device required for -m gpu tests (no CPU fallback exists)")
+    return scanrs_amd
+
+
+def pair(sa, dense, storage):
+    dense = np.asarray(dense, dtype=np.uint32)
+    return sa.AdaptiveMat.from_dense(dense, storage), so.AdaptiveMat.from_dense(dense, storage)
+
+
+def random_counts(rng, rows, cols, fill, vmax):
+    d = np.zeros((rows, cols), dtype=np.uint32)
+    if rows and cols:
+        mask = rng.random((rows, cols)) < fill
+        d[mask] = rng.integers(1, vmax, size=int(mask.sum()))
+    return d
+
+
+def assert_close(a, b, rtol=1e-7, atol=1e-12):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    assert np.all(np.abs(a - b) <= np.abs(b) * rtol + atol), float(np.max(np.abs(a - b)))
+
+
+# ---- integer-exact products: property of sqz/src/mat.rs:1406-1486 ---------------------------------------
+@pytest.mark.parametrize("storage", [so.CSR, so.CSC])
+def test_spmm_u32_bit_exact(sa, storage):
+    rng = np.random.default_rng(10 + storage)
+    shapes = [(0, 0), (1, 1), (3, 0), (0, 4), (7, 5), (64, 64), (130, 257), (500, 33), (33, 900)]
+    for rows, cols in shapes:
+        dense = random_counts(rng, rows, cols, rng.random(), 50)
+        try:
+            g, o = pair(sa, dense, storage)
+        except Exception:
+            if rows == 0 or cols == 0:
+                continue
+            raise
+        for l in (1, 2, 16, 63, 64, 100):
+            q = rng.integers(0, 100, size=(cols, l), dtype=np.uint32)
+            want = (dense.astype(np.uint64) @ q.astype(np.uint64)).astype(np.uint32)
+            assert np.array_equal(g.dot(q), want)
+            assert np.array_equal(o.dot(q), want)
+            ql = rng.integers(0, 100, size=(l, rows), dtype=np.uint32)
+            want = (ql.astype(np.uint64) @ dense.astype(np.uint64)).astype(np.uint32)
+            assert np.array_equal(g.rdot(ql), want)
+        v = rng.integers(0, 100, size=cols, dtype=np.uint32)
+        assert np.array_equal(g.dot(v), (dense.astype(np.uint64) @ v.astype(np.uint64)).astype(np.uint32))
+        v = rng.integers(0, 100, size=rows, dtype=np.uint32)
+        assert np.array_equal(g.rdot(v), (v.astype(np.uint64) @ dense.astype(np.uint64)).astype(np.uint32))
+
+
+def test_spmm_u32_wide_and_long_vectors(sa):
+    # panels wider than one 512-column pass, outer vectors longer than one work item (slab path),
+    # u32 wrap-around
+    rng = np.random.default_rng(3)
+    dense = random_counts(rng, 6, 20000, 0.9, 1 << 20)
+    for storage in (so.CSR, so.CSC):
+        g, _ = pair(sa, dense, storage)
+        q = rng.integers(0, 1 << 16, size=(20000, 10), dtype=np.uint32)
+        want = (dense.astype(np.uint64) @ q.astype(np.uint64)).astype(np.uint32)
+        assert np.array_equal(g.dot(q), want)
+        ql = rng.integers(0, 1 << 16, size=(3, 6), dtype=np.uint32)
+        assert np.array_equal(g.rdot(ql), (ql.astype(np.uint64) @ dense.astype(np.uint64)).astype(np.uint32))
+    dense = random_counts(rng, 40, 30, 0.5, 9)
+    g, _ = pair(sa, dense, so.CSR)
+    q = rng.integers(0, 100, size=(30, 700), dtype=np.uint32)
+    assert np.array_equal(g.dot(q), (dense.astype(np.uint64) @ q.astype(np.uint64)).astype(np.uint32))
+
+
+def test_stored_zeros_are_skipped(sa):
+    # AbsIter::next skips stored zeros (sqz/src/vec.rs:113): nnz and every result ignore them
+    indptr = np.array([0, 3, 3, 5], dtype=np.uint64)
+    indices = np.array([0, 2, 3, 1, 2], dtype=np.uint32)
+    data = np.array([5, 0, 7, 0, 9], dtype=np.uint32)
+    g = sa.AdaptiveMat.from_csmat(3, 4, sa.CSR, indptr, indices, data)
+    assert g.nnz() == 3
+    want = np.array([[5, 0, 0, 7], [0, 0, 0, 0], [0, 0, 9, 0]], dtype=np.float64)
+    assert np.array_equal(g.to_dense(), want)
+    assert g.sum_axis(0, np.uint32).tolist() == [5, 0, 9, 7]
+
+
+def test_create_rejects_bad_input(sa):
+    with pytest.raises(sa.ScanrsError):
+        sa.AdaptiveMat.from_csmat(2, 3, sa.CSR, [0, 2, 2], [1, 0], [1, 1])  # not ascending
+    with pytest.raises(sa.ScanrsError):
+        sa.AdaptiveMat.from_csmat(2, 3, sa.CSR, [0, 1, 2], [1, 7], [1, 1])  # out of range
+    with pytest.raises(sa.ScanrsError):
+        sa.AdaptiveMat.from_csmat(2, 3, 5, [0, 1, 2], [1, 2], [1, 1])  # bad storage flag
+
+
+# ---- reductions + golden tables -------------------------------------------------------------------------------
+@pytest.mark.parametrize("storage", [so.CSR, so.CSC])
+def test_mat_stats_golden(sa, golden, storage):
+    g = golden["mat_stats"]
+    a, _ = pair(sa, g["input_a"], storage)
+    assert a.sum_axis(0, np.uint32).tolist() == g["sum0"]
+    assert a.sum_axis(1, np.uint32).tolist() == g["sum1"]
+    assert np.allclose(a.mean_axis(0), g["mean0"], rtol=0, atol=g["abs_tol"])
+    assert np.allclose(a.mean_axis(1), g["mean1"], rtol=0, atol=g["abs_tol"])
+    for axis, mk, vk in ((0, "mean0", "var0"), (1, "mean1", "var1")):
+        mean, var = a.mean_var_axis(axis)
+        assert np.allclose(mean, g[mk], rtol=0, atol=g["abs_tol"])
+        assert np.allclose(var, g[vk], rtol=0, atol=g["abs_tol"])
+    # transposed view swaps the axes
+    assert a.t().sum_axis(1, np.uint32).tolist() == g["sum0"]
+    assert a.t().shape() == [5, 4]
+
+
+def test_mat_misc_center_golden(sa, golden):
+    g = golden["mat_misc"]
+    for storage in (so.CSR, so.CSC):
+        a, _ = pair(sa, g["dense"], storage)
+        assert_close(a.view().center(0, None).to_dense(), g["centered_cols"], g["rtol"], g["atol"])
+        assert_close(a.view().center(1, None).to_dense(), g["centered_rows"], g["rtol"], g["atol"])
+        dense = np.array(g["dense"], dtype=np.float64)
+        for axis in (0, 1):
+            assert_close(a.sum_axis(axis), dense.sum(axis=axis))
+            mean, var = a.mean_var_axis(axis)
+            assert_close(mean, dense.mean(axis=axis))
+            assert_close(var, dense.var(axis=axis), atol=1e-9)
+
+
+def test_matrix_map_golden(sa, golden):
+    g = golden["matrix_map"]
+    sx = g["scale_axis"]
+    f = np.array(sx["scale_factors"])
+    for storage in (so.CSR, so.CSC):
+        a, _ = pair(sa, np.array(sx["orig"]), storage)
+        assert_close(a.view().compose_scale_axis(0, f).to_dense(), sx["expected_rows"], g["rtol"], g["atol"])
+        assert_close(a.view().compose_scale_axis(1, f).to_dense(), sx["expected_cols"], g["rtol"], g["atol"])
+        # transposes at each step (matrix_map.rs:360-399)
+        assert_close(a.view().compose_scale_axis(0, f).t().to_dense(), np.array(sx["expected_rows"]).T)
+        assert_close(a.t().compose_scale_axis(1, f).to_dense(), np.array(sx["expected_rows"]).T)
+        c = g["composed"]
+        a, _ = pair(sa, np.array(c["orig"]), storage)
+        rf = np.array(c["row_factors"])
+        assert_close(a.view().compose_scale_axis(0, rf).apply(sa.FN_SQUARE).to_dense(), c["scale_then_square"])
+        assert_close(a.view().apply(sa.FN_SQUARE).compose_scale_axis(0, rf).to_dense(), c["square_then_scale"])
+        assert_close(a.view().apply(sa.FN_SQUARE).compose_scale_axis(0, rf).t().to_dense(), np.array(c["square_then_scale"]).T)
+        ln = np.array(g["scalar_ln1p"]["orig"], dtype=np.float64)
+        a, _ = pair(sa, ln, storage)
+        assert_close(a.apply(sa.FN_LN_1P).to_dense(), np.log(ln + 1.0), g["rtol"], g["atol"])
+
+
+@pytest.mark.parametrize("storage", [so.CSR, so.CSC])
+def test_normalization_golden(sa, golden, storage):
+    g = golden["normalization"]
+    tol = g["abs_tol"]
+    N = sa.Normalization
+    mk = lambda: pair(sa, g["dense"], storage)[0]
+    assert np.allclose(sa.normalize(mk(), N.CellRanger).to_dense(), g["cellranger"]["expected"], rtol=0, atol=tol)
+    assert np.allclose(sa.normalize_with_size_factor(mk(), N.CellRanger).to_dense(), g["cellranger"]["expected"], rtol=0, atol=tol)
+    assert np.allclose(sa.normalize_with_size_factor(mk(), N.CellRanger8).to_dense(), g["cellranger8"]["expected"], rtol=0, atol=tol)
+    assert np.allclose(sa.normalize_with_size_factor(mk(), N.LogTransform).to_dense(), g["logtransform"]["expected"], rtol=0, atol=tol)
+    sf = g["size_factor_lognorm"]
+    dense = np.array(g["dense"], dtype=np.uint32)
+    size_factors = (sf["size_factor_offset"] + dense[sf["features_picked"], :].sum(axis=0)).astype(np.uint32)
+    out = sa.log_normalize_with_size_factor(mk(), None, sa.FN_LOG2_1P, size_factors).to_dense()
+    assert np.allclose(out, sf["expected"], rtol=0, atol=tol)
+    m = mk()
+    sa.log_normalize_with_size_factor(m, None, sa.FN_LOG2_1P, None)
+    assert m.target_umi() == float(np.median(dense.sum(axis=0)))
+    fp = g["fixed_point"]
+    out = sa.log1p_normalize_fixed_point(pair(sa, fp["dense"], storage)[0], sa.FN_LOG2_1P, fp["base"], fp["exponent"]).to_dense()
+    assert np.allclose(out, fp["expected"], rtol=0, atol=tol)
+
+
+def test_one_dim_nan_guard(sa, golden):
+    g = golden["one_dim_nan_guard"]
+    mat, _ = pair(sa, np.array(g["values"], dtype=np.uint32).reshape(g["shape"]), so.CSR)
+    out = sa.normalize(mat.view(), sa.Normalization.CellRanger).t().to_dense()
+    assert not np.isnan(out).any()
+
+
+def test_median_integer_floor(sa):
+    # even number of barcodes: (a + b) / 2 in u32 (scan-rs/src/stats.rs:32-34)
+    dense = np.array([[1, 10, 100, 1000], [0, 0, 0, 0]], dtype=np.uint32)
+    m, _ = pair(sa, dense, so.CSC)
+    sa.log_normalize_with_size_factor(m, None, sa.FN_LOG2_1P, None)
+    assert m.target_umi() == 55.0
+    dense = np.array([[1, 10, 100]], dtype=np.uint32)
+    m, _ = pair(sa, dense, so.CSR)
+    sa.log_normalize_with_size_factor(m, None, sa.FN_LOG2_1P, None)
+    assert m.target_umi() == 10.0
+    dense = np.array([[0, 0, 0, 7]], dtype=np.uint32)  # median 0 -> max(median, 1)
+    m, _ = pair(sa, dense, so.CSR)
+    sa.log_normalize_with_size_factor(m, None, sa.FN_LOG2_1P, None)
+    assert m.target_umi() == 1.0
+
+
+# ---- f64 products with the fused map + rank-1 offset vs the oracle ------------------------------------------------------
+def _norm_pair(sa, dense, storage, norm_name):
+    g, o = pair(sa, dense, storage)
+    names = {"cellranger": sa.Normalization.CellRanger, "cellranger8": sa.Normalization.CellRanger8,
+             "seuratlog": sa.Normalization.SeuratLog}
+    return sa.normalize(g, names[norm_name]), so.normalize(o, norm_name)
+
+
+@pytest.mark.parametrize("storage", [so.CSR, so.CSC])
+@pytest.mark.parametrize("norm", ["cellranger", "cellranger8", "seuratlog"])
+def test_normalized_products_match_oracle(sa, storage, norm):
+    rng = np.random.default_rng(5)
+    dense = random_counts(rng, 150, 400, 0.1, 30)
+    dense[:, 0] += 1  # no empty barcodes (a zero column sum gives inf scales in the reference too)
+    dense[0, :] += 1
+    g, o = _norm_pair(sa, dense, storage, norm)
+    # relative 1e-11: same f64 arithmetic, different summation order / fused multiply-add
+    assert_close(g.to_dense(), o.to_dense(), rtol=1e-11, atol=1e-11)
+    for l in (1, 3, 50, 100):
+        q = rng.standard_normal((400, l))
+        assert_close(g.dot(q), o.dot(q), rtol=1e-10, atol=1e-9)
+        ql = rng.standard_normal((l, 150))
+        assert_close(g.rdot(ql), o.rdot(ql), rtol=1e-10, atol=1e-9)
+        gt, ot = g.t(), o.t()
+        assert_close(gt.dot(ql.T.copy()), ot.dot(ql.T.copy()), rtol=1e-10, atol=1e-9)
+        assert_close(gt.rdot(q.T.copy()), ot.rdot(q.T.copy()), rtol=1e-10, atol=1e-9)
+
+
+def test_low_rank_offset_products(sa):
+    # sqz/src/low_rank_offset.rs:145-173: rank 1..4 offsets, both sides, vs the densified product
+    rng = np.random.default_rng(11)
+    for storage in (so.CSR, so.CSC):
+        dense = random_counts(rng, 37, 53, 0.3, 20)
+        for rank in range(1, 5):
+            u, v = rng.random((37, rank)), rng.random((rank, 53))
+            g, _ = pair(sa, dense, storage)
+            g.set_offset(u, v)
+            full = dense.astype(np.float64) + u @ v
+            assert_close(g.to_dense(), full, rtol=1e-12, atol=1e-12)
+            q = rng.random((53, 5))
+            assert_close(g.dot(q), full @ q, rtol=1e-7, atol=1e-10)
+            ql = rng.random((4, 37))
+            assert_close(g.rdot(ql), ql @ full, rtol=1e-7, atol=1e-10)
+            assert_close(g.t().to_dense(), full.T, rtol=1e-12, atol=1e-12)
+            assert_close(g.t().dot(ql.T.copy()), full.T @ ql.T, rtol=1e-7, atol=1e-10)
+
+
+def test_binomial_residual_maps(sa):
+    rng = np.random.default_rng(2)
+    dense = random_counts(rng, 60, 90, 0.2, 15)
+    dense[:, 0] += 1
+    dense[0, :] += 1
+    for storage in (so.CSR, so.CSC):
+        for fn_g, fn_o in ((sa.binom_deviance_resid, so.binom_deviance_resid), (sa.binom_pearson_resid, so.binom_pearson_resid)):
+            g, o = pair(sa, dense, storage)
+            g, o = fn_g(g), fn_o(o)
+            assert_close(g.to_dense(), o.to_dense(), rtol=1e-10, atol=1e-10)
+            q = rng.standard_normal((90, 7))
+            assert_close(g.dot(q), o.dot(q), rtol=1e-9, atol=1e-8)
+            ql = rng.standard_normal((6, 60))
+            assert_close(g.rdot(ql), o.rdot(ql), rtol=1e-9, atol=1e-8)
+
+
+def test_products_are_deterministic(sa):
+    rng = np.random.default_rng(8)
+    dense = random_counts(rng, 30, 20000, 0.6, 9)  # long outer vectors: several work items + slab
+    g, o = _norm_pair(sa, dense + 1, so.CSR, "cellranger")
+    q = rng.standard_normal((20000, 20))
+    a = g.dot(q)
+    for _ in range(3):
+        assert np.array_equal(a, g.dot(q))
+    assert_close(a, o.dot(q), rtol=1e-10, atol=1e-8)
+
+
+# ---- PCA drivers -------------------------------------------------------------------------------------------------------------
+def _sign_fix(a, ref):
+    return a * np.sign(np.sum(a * ref, axis=0))
+
+
+def _synth(n_cells, n_genes, density, seed):
+    from scanrs_amd.synth import synth_counts
+
+    return synth_counts(n_cells, n_genes, density, seed)
+
+
+@pytest.mark.parametrize("orientation", ["genes_x_cells_csc", "cells_x_genes_csr", "genes_x_cells_csr"])
+def test_bksvd_matches_oracle(sa, orientation):
+    m = _synth(2500, 600, 0.06, 1)  # cells x genes, CSR
+    k = 10
+    if orientation == "genes_x_cells_csc":  # Cell Ranger orientation held cell-major: n > m branch
+        g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+        o = so.AdaptiveMat(m.shape[1], m.shape[0], so.CSC, m.indptr, m.indices, m.data)
+        g, o = sa.normalize(g, sa.Normalization.CellRanger), so.normalize(o, "cellranger")
+        omega = so.omega_panel((2 * k, m.shape[1]), 0)
+    elif orientation == "genes_x_cells_csr":  # gene-major CSR as hdf5-io builds it
+        mt = m.T.tocsr()
+        mt.sort_indices()
+        g = sa.AdaptiveMat.from_csmat(mt.shape[0], mt.shape[1], sa.CSR, mt.indptr, mt.indices, mt.data)
+        o = so.AdaptiveMat(mt.shape[0], mt.shape[1], so.CSR, mt.indptr, mt.indices, mt.data)
+        g, o = sa.normalize(g, sa.Normalization.CellRanger), so.normalize(o, "cellranger")
+        omega = so.omega_panel((2 * k, m.shape[1]), 0)
+    else:  # the transposed view: m >= n branch
+        g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+        o = so.AdaptiveMat(m.shape[1], m.shape[0], so.CSC, m.indptr, m.indices, m.data)
+        g, o = sa.normalize(g, sa.Normalization.CellRanger).t(), so.normalize(o, "cellranger").t()
+        omega = so.omega_panel((m.shape[1], 2 * k), 0)
+    u, s, v = sa.BkSvd().run_pca(g, k, omega=omega)
+    uo, s_o, vo = so.BkSvd().run_pca(o, k, omega=omega)
+    assert u.shape == uo.shape and v.shape == vo.shape
+    # north-star tolerance is 1e-4 relative; the same algorithm in f64 lands far inside it
+    assert np.max(np.abs(s - s_o) / s_o) < 1e-8
+    assert np.max(np.abs(_sign_fix(u, uo) - uo)) < 1e-6
+    assert np.max(np.abs(_sign_fix(v, vo) - vo)) < 1e-6
+    # default seeded panel is the same stream in the library and the oracle
+    u2, s2, v2 = sa.BkSvd().run_pca(g, k)
+    _, s3, _ = so.BkSvd().run_pca(o, k)
+    assert np.max(np.abs(s2 - s3) / s3) < 1e-8
+
+
+def _simple_deterministic_ex(m, n):
+    x = np.arange(m * n, dtype=np.int64)
+    return (x % 7 + x % 4 + x % 50 + x % 47 + x % 12).astype(np.uint32).reshape(m, n)
+
+
+def _test_svd(a_gpu, dense, nu, run, thr):
+    # TestSvd::test_svd (scan-rs/src/dim_red/test.rs:58-110)
+    import scipy.linalg as sl
+
+    _, s_gt, vt_gt = sl.svd(dense, full_matrices=False)
+    u, s, v = run(a_gpu, nu)
+    av = a_gpu.dot(v)
+    assert so.frobenius(av - u * s) < thr["frob_err_max"]
+    assert np.max(np.abs((s - s_gt[:nu]) / s_gt[:nu])) < thr["s_err_max"]
+    av_gt = np.abs(dense @ vt_gt[:nu, :].T)
+    assert np.max(np.abs((np.abs(av) - av_gt) / av_gt)) < thr["proj_err_max"]
+
+
+@pytest.mark.parametrize("solver", ["bk", "rand", "irlba"])
+def test_svd_drivers_thresholds(sa, golden, solver):
+    thr = golden["svd_thresholds"]
+    for m, n in thr["shapes"]:
+        dense = _simple_deterministic_ex(m, n)
+        for storage in (so.CSR, so.CSC):
+            a, _ = pair(sa, dense, storage)
+            if solver == "bk":
+                run = lambda a, nu: sa.BkSvd().run_pca(a, nu)
+            elif solver == "rand":
+                run = lambda a, nu: sa.RandSvd().run_pca(a, nu)
+            else:
+                run = lambda a, nu: sa.Irlba(tol=0.00001, max_iter=300).run_pca(a, nu)
+            _test_svd(a, dense.astype(np.float64), thr["nu"], run, thr)
+
+
+def test_randsvd_matches_oracle(sa):
+    m = _synth(1500, 700, 0.06, 4)
+    k = 6
+    g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+    o = so.AdaptiveMat(m.shape[1], m.shape[0], so.CSC, m.indptr, m.indices, m.data)
+    g, o = sa.normalize(g, sa.Normalization.CellRanger), so.normalize(o, "cellranger")
+    for gg, oo, shape in ((g, o, (60, 700)), (g.t(), o.t(), (700, 60))):
+        omega = so.omega_panel(shape, 0)
+        u, s, v = sa.RandSvd().run_pca(gg, k, omega=omega)
+        uo, s_o, vo = so.RandSvd().run_pca(oo, k, omega=omega)
+        assert np.max(np.abs(s - s_o) / s_o) < 1e-8
+        assert np.max(np.abs(_sign_fix(u, uo) - uo)) < 1e-6
+        assert np.max(np.abs(_sign_fix(v, vo) - vo)) < 1e-6
+
+
+def test_irlba_matches_oracle(sa):
+    m = _synth(900, 400, 0.08, 6)
+    k = 5
+    g = sa.AdaptiveMat.from_csmat(m.shape[0], m.shape[1], sa.CSR, m.indptr, m.indices, m.data)
+    o = so.AdaptiveMat(m.shape[0], m.shape[1], so.CSR, m.indptr, m.indices, m.data)
+    # barcodes are rows here: normalise the transposed view, then flip back
+    v0 = np.random.default_rng(0).standard_normal(400)
+    gl = sa.log_normalize_with_size_factor(g.t(), None, sa.FN_LOG2_1P).t()
+    ol = so.log_normalize_with_size_factor(o.t(), None, so.LOG_TWO).t()
+    ir = sa.Irlba(tol=1e-6, max_iter=100)
+    u, s, v = ir.run_pca(gl, k, v0=v0)
+    uo, s_o, vo, mprod = so.irlba(ol, k, 1e-6, 100, v0=v0)
+    assert np.max(np.abs(s - s_o) / s_o) < 1e-7
+    assert np.max(np.abs(_sign_fix(u, uo) - uo)) < 1e-5
+    assert np.max(np.abs(_sign_fix(v, vo) - vo)) < 1e-5
+    assert ir.mprod > 0
+    with pytest.raises(sa.ScanrsError):  # LowRankOffset has no Ix1 Dot impl in the reference
+        sa.Irlba().run_pca(sa.normalize(pair(sa, random_counts(np.random.default_rng(0), 20, 30, 0.5, 5) + 1, so.CSR)[0], 0), 3)
+
+
+def test_pca_errors_and_cancellation(sa):
+    rng = np.random.default_rng(0)
+    dense = random_counts(rng, 40, 60, 0.5, 9) + 1
+    a, _ = pair(sa, dense, so.CSR)
+    with pytest.raises(sa.ScanrsError) as e:
+        sa.BkSvd().run_pca(a, 41)
+    assert e.value.code == 2 and "invalid k" in str(e.value)
+    one, _ = pair(sa, dense[:1, :], so.CSR)
+    with pytest.raises(sa.ScanrsError) as e:
+        sa.BkSvd().run_pca(one, 1)
+    assert e.value.code == 1 and "at least 2x2" in str(e.value)
+    snoop = sa.AtomicSnoop()
+    u, s, v = sa.BkSvd(2.0, 4).run_pca(a, 3, snoop=snoop)
+    # progress fractions of bk_svd.rs:96-114: i/n_iter*0.8, 0.82, 0.93, 1.0
+    assert snoop.history == [0.0, 0.2, pytest.approx(0.4), pytest.approx(0.6), 0.82, 0.93, 1.0]
+    snoop = sa.AtomicSnoop()
+    snoop.cancel()
+    with pytest.raises(sa.CancellationError):
+        sa.BkSvd().run_pca(a, 3, snoop=snoop)
+    # the handle is still usable after a cancelled run
+    u2, s2, v2 = sa.BkSvd(2.0, 4).run_pca(a, 3)
+    assert np.array_equal(s, s2) and np.array_equal(u, u2)
+
+
+def test_pca_is_deterministic(sa):
+    m = _synth(1200, 300, 0.08, 9)
+    g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+    g = sa.normalize(g, sa.Normalization.CellRanger)
+    a = sa.BkSvd().run_pca(g, 8)
+    b = sa.BkSvd().run_pca(g, 8)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
