@@ -225,7 +225,10 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
     st->rows = rows;
     st->cols = cols;
     st->storage = storage;
-    SCANRS_HIP(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking));
+    // a blocking stream: legacy null-stream copies (ours and the host program's, e.g. torch's default
+    // stream that produced a device-resident input) stay ordered with the kernels launched here
+    SCANRS_HIP(hipStreamCreate(&st->stream));
+    st->scratch.stream = st->stream;
     SparseCopy &cp = st->primary;
     cp.n_outer = storage == SCANRS_CSR ? rows : cols;
     cp.n_inner = storage == SCANRS_CSR ? cols : rows;
@@ -262,7 +265,7 @@ static uint32_t select_kth(Storage &st, const uint32_t *d, uint64_t n_local, uin
     const uint32_t shifts[3] = {20, 8, 0};
     const uint32_t bits[3] = {12, 12, 8};
     for (int pass = 0; pass < 3; pass++) {
-        launch_hist12(st, d, n_local, shifts[pass], mask, prefix, hist);
+        launch_hist12(st, d, n_local, shifts[pass], (1u << bits[pass]) - 1u, mask, prefix, hist);
         allreduce_u64(st, hist, 4096);
         SCANRS_HIP(hipMemcpyAsync(h.data(), hist, 4096 * 8, hipMemcpyDeviceToHost, st.stream));
         SCANRS_HIP(hipStreamSynchronize(st.stream));

@@ -71,13 +71,14 @@ struct DevBuf {
 // the first pass over them.
 struct Scratch {
     std::map<std::string, DevBuf<char>> bufs;
+    hipStream_t stream = nullptr; // zero-fills are ordered on the owning handle's stream
     template <typename T>
     T *get(const std::string &key, size_t count) {
         auto &b = bufs[key];
         size_t bytes = count * sizeof(T);
         if (bytes > b.n) {
             b.alloc(bytes + bytes / 8 + 256);
-            SCANRS_HIP(hipMemset(b.p, 0, b.n)); // padding columns of panels start out as zeros
+            SCANRS_HIP(hipMemsetAsync(b.p, 0, b.n, stream)); // padding columns of panels start out as zeros
         }
         return reinterpret_cast<T *>(b.p);
     }
@@ -241,8 +242,8 @@ void launch_fill_f64(Storage &st, double *p, uint64_t n, double v);
 void launch_finish_moments(Storage &st, const double *sum, const double *sumsq, uint64_t n, double m, int given_scale,
                            const double *scale_in, double *mean_over_scale_neg, double *inv_scale, double *scale_out);
 void launch_u32_to_scale(Storage &st, const uint32_t *counts, uint64_t n, double target, double *out);
-void launch_hist12(Storage &st, const uint32_t *v, uint64_t n, uint32_t shift, uint32_t prefix_mask, uint32_t prefix,
-                   unsigned long long *hist);
+void launch_hist12(Storage &st, const uint32_t *v, uint64_t n, uint32_t shift, uint32_t digit_mask, uint32_t prefix_mask,
+                   uint32_t prefix, unsigned long long *hist);
 void launch_sum_f64(Storage &st, const double *x, uint64_t n, double *out);
 void validate_copy(Storage &st, const SparseCopy &cp, uint64_t *zeros, uint64_t *bad);
 void launch_densify(Storage &st, const SparseCopy &cp, const DevMap &map, bool outer_is_view_row, uint64_t cols_v,

@@ -518,14 +518,14 @@ __global__ void u32_to_scale_kernel(const uint32_t *__restrict__ counts, uint64_
 // 12-bit digit histogram of the values matching a prefix: the counting step of the radix select that
 // stands in for median_mut's sort (scan-rs/src/stats.rs:13-38).
 __global__ __launch_bounds__(256) void hist12_kernel(const uint32_t *__restrict__ v, uint64_t n, uint32_t shift,
-                                                     uint32_t prefix_mask, uint32_t prefix,
+                                                     uint32_t digit_mask, uint32_t prefix_mask, uint32_t prefix,
                                                      unsigned long long *__restrict__ hist) {
     __shared__ uint32_t h[4096];
     for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x) h[i] = 0;
     __syncthreads();
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t x = v[i];
-        if ((x & prefix_mask) == prefix) atomicAdd(&h[(x >> shift) & 0xFFFu], 1u);
+        if ((x & prefix_mask) == prefix) atomicAdd(&h[(x >> shift) & digit_mask], 1u);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 4096u; i += blockDim.x)
@@ -827,12 +827,12 @@ void launch_u32_to_scale(Storage &st, const uint32_t *counts, uint64_t n, double
     hipLaunchKernelGGL(u32_to_scale_kernel, grid1(n, 256), dim3(256), 0, st.stream, counts, n, target, out);
     SCANRS_HIP(hipGetLastError());
 }
-void launch_hist12(Storage &st, const uint32_t *v, uint64_t n, uint32_t shift, uint32_t prefix_mask, uint32_t prefix,
-                   unsigned long long *hist) {
+void launch_hist12(Storage &st, const uint32_t *v, uint64_t n, uint32_t shift, uint32_t digit_mask, uint32_t prefix_mask,
+                   uint32_t prefix, unsigned long long *hist) {
     SCANRS_HIP(hipMemsetAsync(hist, 0, 4096 * sizeof(unsigned long long), st.stream));
     if (n) {
         const unsigned blocks = (unsigned)std::min<uint64_t>(1024, (n + 255) / 256);
-        hipLaunchKernelGGL(hist12_kernel, dim3(blocks), dim3(256), 0, st.stream, v, n, shift, prefix_mask, prefix, hist);
+        hipLaunchKernelGGL(hist12_kernel, dim3(blocks), dim3(256), 0, st.stream, v, n, shift, digit_mask, prefix_mask, prefix, hist);
     }
     SCANRS_HIP(hipGetLastError());
 }
