@@ -168,7 +168,8 @@ typedef struct {
  * omega: optional explicit start panel in the reference's own layout
  * ((cols x b) row-major when rows >= cols, else (b x rows)), b = min(rows, cols, ceil(k*k_multiplier));
  * null -> generated from `seed` like SmallRng::seed_from_u64 + Uniform(-1,1).
- * Outputs (caller-allocated, row-major): u rows x k, s k, v cols x k  (= PcaResult, dim_red/mod.rs:47). */
+ * Outputs (caller-allocated, row-major): u rows x k, s k, v cols x k  (= PcaResult, dim_red/mod.rs:47).
+ * u and/or v may be null: the factor then stays in device memory only (no PCIe copy). */
 int scanrs_pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
                   const scanrs_snoop *snoop, double *u, double *s, double *v);
 /* RandSvd::run_pca / svd_rand (dim_red/rand_svd.rs:37-129). l = max(k+4, (k*l_multiplier) as usize).

@@ -859,14 +859,14 @@ int scanrs_mat_target_umi(const scanrs_mat *m, double *target) {
 int scanrs_pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
                   const scanrs_snoop *snoop, double *u, double *s, double *v) {
     return guard([&] {
-        if (!m || !u || !s || !v) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        if (!m || !s) fail(SCANRS_ERR_ARGUMENT, "null argument");
         pca_bk(m, k, k_multiplier, n_iter, seed, omega, snoop, u, s, v);
     });
 }
 int scanrs_pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
                     double *u, double *s, double *v) {
     return guard([&] {
-        if (!m || !u || !s || !v) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        if (!m || !s) fail(SCANRS_ERR_ARGUMENT, "null argument");
         pca_rand(m, k, l_multiplier, n_iter, seed, omega, u, s, v);
     });
 }

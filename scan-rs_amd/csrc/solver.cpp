@@ -208,8 +208,9 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
     double *dEs = c.dev("ritz_es", (size_t)q * k);
     c.h2d(dEs, Es.data(), Es.size());
     launch_gemm_nn(c.st, T, ldt, q, dEs, k, k, dt, 1.0, 0.0, nullptr, 0, dT, ldk);
-    download_panel(c, dS, ldk, ds, k, hS);
-    download_panel(c, dT, ldk, dt, k, hT);
+    if (hS) download_panel(c, dS, ldk, ds, k, hS); // null: the caller keeps the result in HBM
+    if (hT) download_panel(c, dT, ldk, dt, k, hT);
+    c.sync();
 }
 
 int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
