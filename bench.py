@@ -40,11 +40,6 @@ def parse():
     return ap.parse_args()
 
 
-class _DevArr:
-    def __init__(self, ptr, n, typestr):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
-
-
 def main():
     args = parse()
     import numpy as np
@@ -72,8 +67,9 @@ def main():
         raise SystemExit("bench.py needs a gfx950 device (no CPU fallback)")
 
     # ---- synthetic shard, generated in device memory -------------------------------------------------
-    per = (args.cells + world - 1) // world
-    lo, hi = min(args.cells, rank * per), min(args.cells, (rank + 1) * per)
+    from scanrs_amd.dist import shard_bounds
+
+    lo, hi = shard_bounds(args.cells, world)[rank]
     t0 = time.time()
     indptr, indices, values = synth_counts_torch(args.cells, args.genes, args.density, args.seed, dev, lo, hi)
     torch.cuda.synchronize()
@@ -87,14 +83,10 @@ def main():
     del indptr, indices, values
     torch.cuda.empty_cache()
 
-    def allreduce(ptr, count, dtype):
-        t = torch.as_tensor(_DevArr(ptr, count, "<f8" if dtype == 0 else "<i8"), device=dev)
-        dist.all_reduce(t)
-        torch.cuda.synchronize()
-        return 0
-
     if world > 1:
-        mat.set_shard(rank, world, lo, args.cells, allreduce)
+        from scanrs_amd.dist import make_allreduce
+
+        mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev))
 
     bk = sa.BkSvd()  # k_multiplier 2.0, n_iter 5: the solver scan-rs-cmd uses (tools/src/bin/cmd.rs:70)
     s_out = np.zeros(args.k)

@@ -664,7 +664,9 @@ static void launch_spmm_t(Storage &st, const SparseCopy &cp, const DevMap &map, 
                              (double)cp.n_inner * lc * sizeof(T) + (double)cp.n_outer * lc * sizeof(T);
         const double *offw = off_w ? off_w + c0 : nullptr;
         {
-            ProfScope ps(st, sizeof(T) == 8 ? "spmm_gather_f64" : "spmm_gather_u32", bytes);
+            char pname[48];
+            snprintf(pname, sizeof(pname), "spmm_gather_kernel<%s, %u>", sizeof(T) == 8 ? "double" : "unsigned int", nacc);
+            ProfScope ps(st, pname, bytes);
 #define SCANRS_SPMM(NA)                                                                                              \
     hipLaunchKernelGGL((spmm_gather_kernel<T, NA>), grid, block, 0, st.stream, cp.indices.p, cp.values.p, cp.items.p, \
                        cp.n_items, map, X + c0, ldx, lc, out + c0, ldo, slab ? slab + c0 : nullptr, off_a, rank, offw, \

@@ -17,7 +17,7 @@
 
 namespace scanrs {
 
-// ---- rand-family generator for the seeded start panel ("parity unpinned", see oracle/scanrs_oracle.py) -----
+// ---- rand-family generator for the seeded start panel ("parity unpinned") -----
 struct SmallRng {
     uint64_t s[4];
     explicit SmallRng(uint64_t seed) {
