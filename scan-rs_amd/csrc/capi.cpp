@@ -2,6 +2,7 @@
 // scan-rs::normalization surface). See include/scanrs_amd.h for the reference citations per entry point.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -229,6 +230,10 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
     // stream that produced a device-resident input) stay ordered with the kernels launched here
     SCANRS_HIP(hipStreamCreate(&st->stream));
     st->scratch.stream = st->stream;
+    if (const char *e = getenv("SCANRS_L2_TILE_KB")) { // tuning knob for the L2-blocked gather (default 3072)
+        const long kb = atol(e);
+        if (kb >= 64) st->l2_tile_bytes = (size_t)kb << 10;
+    }
     SparseCopy &cp = st->primary;
     cp.n_outer = storage == SCANRS_CSR ? rows : cols;
     cp.n_inner = storage == SCANRS_CSR ? cols : rows;
@@ -949,6 +954,13 @@ int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uin
             i++;
         }
         *n = i;
+    });
+}
+int scanrs_mat_set_spmm_path(scanrs_mat *m, int path) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        if (path < 0 || path > 3) fail(SCANRS_ERR_ARGUMENT, "path must be 0 (auto), 1 (gather), 2 (LDS-tiled) or 3 (L2-blocked gather)");
+        m->st->spmm_path = path;
     });
 }
 int scanrs_mat_sync(scanrs_mat *m) {

@@ -130,6 +130,16 @@ struct MultiRow {
     uint32_t _pad;
 };
 
+// LDS-tiled regrouping of a copy (tiled.hip): nonzeros ordered by (16-vector group, column tile, vector, column),
+// packed to 32 bits; starts/lens locate each (group, tile) segment.
+struct TileCopy {
+    bool tried = false, usable = false;
+    uint32_t T = 0, n_blocks = 0;
+    DevBuf<uint32_t> words;
+    DevBuf<uint64_t> starts;
+    DevBuf<uint16_t> lens;
+};
+
 // A compressed orientation: n_outer vectors over n_inner positions.
 struct SparseCopy {
     uint64_t n_outer = 0, n_inner = 0, nnz = 0;
@@ -138,6 +148,8 @@ struct SparseCopy {
     DevBuf<Item> items;
     DevBuf<MultiRow> multi;
     uint32_t n_items = 0, n_multi = 0, n_slab = 0;
+    TileCopy tiles;
+    DevBuf<uint32_t> bounds; // L2-blocked gather: offset of the first nonzero >= b*1024 within each outer vector
     void build_items(hipStream_t s);
 };
 
@@ -160,6 +172,9 @@ struct Storage {
     Scratch scratch;
     Profile prof;
     ShardInfo shard; // sharding of primary's outer dimension
+    int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 LDS-tiled, 3 L2-blocked gather
+    size_t l2_tile_bytes = 3u << 20;      // panel slice per step of the L2-blocked gather (4 MB L2 per XCD)
+    uint64_t tiled_min_nnz = 1ull << 22; // auto: matrices below this stay on the gather kernel
     ~Storage();
     // the copy whose outer dimension is the base matrix's rows (true) or cols (false)
     SparseCopy &copy_with_outer_rows(bool outer_rows);
@@ -221,8 +236,11 @@ namespace scanrs {
 // ---- kernels.hip launchers ----------------------------------------------------------------
 // out[n_outer x l] = S * X (+ a * w) where S is `cp` seen through `map`.
 // off_a: n_outer x rank (row-major) or null; off_w: rank x l (ld = ldw).
-void launch_spmm_f64(Storage &st, const SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
+void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
                      double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw);
+void build_tile_copy(Storage &st, SparseCopy &cp);
+void launch_spmm_tiled(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
+                       double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw);
 void launch_spmm_u32(Storage &st, const SparseCopy &cp, const uint32_t *X, uint32_t ldx, uint32_t l, uint32_t *out,
                      uint32_t ldo);
 // per-outer-vector reductions. mode 0: sum of raw u32 counts; 1: sum of mapped values; 2: sum and sum of squares.

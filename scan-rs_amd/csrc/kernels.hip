@@ -215,6 +215,116 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const uint32_t *__rest
     }
 }
 
+// L2-blocked variant of the gather product (f64). The panel is cut into steps of `m` base tiles of 1024
+// rows, sized so that one step's slice of the panel (<= ~3 MB) stays resident in every XCD's 4 MB L2; one
+// launch per step walks ALL outer vectors but only their nonzeros inside the step (bounds table), carrying
+// the running sums through `out`. Every wave on the chip then gathers from the same L2-resident slice
+// instead of from a 26 MB..4 GB panel spread over Infinity Cache / HBM.
+constexpr uint32_t BT_SHIFT = 10;
+
+__global__ void build_bounds_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                    uint64_t n_outer, uint32_t nb, uint32_t *__restrict__ bounds) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_outer * (nb + 1)) return;
+    const uint64_t row = e / (nb + 1);
+    const uint32_t b = (uint32_t)(e % (nb + 1));
+    const uint64_t s = indptr[row], t = indptr[row + 1];
+    const uint64_t key = (uint64_t)b << BT_SHIFT;
+    uint64_t lo = s, hi = t;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)indices[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    bounds[e] = (uint32_t)(lo - s);
+}
+
+template <int NACC>
+__global__ __launch_bounds__(256) void spmm_gather2d_kernel(
+    const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices, const uint32_t *__restrict__ values,
+    const uint32_t *__restrict__ bounds, uint32_t nb, uint32_t b0, uint32_t b1, int first, int last, uint64_t n_outer,
+    DevMap map, const double *__restrict__ X, uint32_t ldx, uint32_t l, double *out, uint32_t ldo,
+    const double *__restrict__ off_a, uint32_t rank, const double *__restrict__ off_w, uint32_t ldw) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t row64 = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row64 >= n_outer) return;
+    const uint32_t row = (uint32_t)row64;
+    const uint32_t *__restrict__ bd = bounds + row64 * (nb + 1);
+    const uint32_t o0 = rfl(bd[b0]), o1 = rfl(bd[b1]);
+    const uint32_t len = o1 - o0;
+    const bool epilogue = last && rank > 0;
+    if (len == 0 && !first && !epilogue) return;
+    const uint64_t base = indptr[row64] + o0;
+    const uint32_t *__restrict__ ind = indices + base;
+    const uint32_t *__restrict__ val = values + base;
+
+    uint32_t col[NACC];
+    bool act[NACC];
+    d2 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+        col[a] = (a * 64u + lane) * 2u;
+        act[a] = col[a] < l;
+        acc[a] = (d2){0.0, 0.0};
+        if (!first && act[a]) acc[a] = *reinterpret_cast<const d2 *>(out + (size_t)row * ldo + col[a]);
+    }
+    for (uint32_t c = 0; c < len; c += 64u) {
+        const uint32_t p = c + lane;
+        uint32_t idx = 0;
+        double f = 0.0;
+        if (p < len) {
+            idx = ind[p];
+            f = eval_map(map, val[p], row, idx);
+        }
+        const uint32_t n = min(64u, len - c);
+        uint32_t j = 0;
+        for (; j + 8u <= n; j += 8u) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                const uint32_t g = rdlane(idx, j + u);
+                const double fv = bcast<double>(f, j + u);
+                const double *__restrict__ xr = X + (size_t)g * ldx;
+#pragma unroll
+                for (int a = 0; a < NACC; a++) {
+                    if (act[a]) {
+                        const d2 x = *reinterpret_cast<const d2 *>(xr + col[a]);
+                        acc[a].x = fma(fv, x.x, acc[a].x);
+                        acc[a].y = fma(fv, x.y, acc[a].y);
+                    }
+                }
+            }
+        }
+        for (; j < n; j++) {
+            const uint32_t g = rdlane(idx, j);
+            const double fv = bcast<double>(f, j);
+            const double *__restrict__ xr = X + (size_t)g * ldx;
+#pragma unroll
+            for (int a = 0; a < NACC; a++) {
+                if (act[a]) {
+                    const d2 x = *reinterpret_cast<const d2 *>(xr + col[a]);
+                    acc[a].x = fma(fv, x.x, acc[a].x);
+                    acc[a].y = fma(fv, x.y, acc[a].y);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+        if (!act[a]) continue;
+        d2 r = acc[a];
+        if (epilogue) {
+            for (uint32_t q = 0; q < rank; q++) {
+                const double aq = off_a[(size_t)row * rank + q];
+                r.x += aq * off_w[(size_t)q * ldw + col[a]];
+                r.y += aq * off_w[(size_t)q * ldw + col[a] + 1];
+            }
+        }
+        *reinterpret_cast<d2 *>(out + (size_t)row * ldo + col[a]) = r;
+    }
+}
+
 // Ordered sum of the partial rows of outer vectors that were cut into several items.
 template <typename T, int NACC>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const MultiRow *__restrict__ multi, uint32_t n_multi,
@@ -697,8 +807,58 @@ static void launch_spmm_t(Storage &st, const SparseCopy &cp, const DevMap &map, 
     SCANRS_HIP(hipGetLastError());
 }
 
-void launch_spmm_f64(Storage &st, const SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
+// L2-blocked gather: see spmm_gather2d_kernel.
+static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
+                           double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w,
+                           uint32_t ldw) {
+    if ((ldx & 1u) || (ldo & 1u)) fail(SCANRS_ERR_ARGUMENT, "panel leading dimensions must be even");
+    const uint32_t nb = (uint32_t)((cp.n_inner + (1ull << BT_SHIFT) - 1) >> BT_SHIFT);
+    if (cp.bounds.n != cp.n_outer * (nb + 1)) {
+        cp.bounds.alloc(cp.n_outer * (nb + 1));
+        const uint64_t n = cp.n_outer * (nb + 1);
+        hipLaunchKernelGGL(build_bounds_kernel, grid1(n, 256), dim3(256), 0, st.stream, cp.indptr.p, cp.indices.p, cp.n_outer,
+                           nb, cp.bounds.p);
+    }
+    // column chunks of <= 128 keep a panel-row slice <= 1 KB, so a step can hold >= 3 base tiles in L2
+    const uint32_t n_chunks = (l + 127u) / 128u;
+    uint32_t lc = (l + n_chunks - 1u) / n_chunks;
+    lc = (lc + 1u) & ~1u;
+    const dim3 grid((unsigned)((cp.n_outer + 3) / 4)), block(256);
+    for (uint32_t c0 = 0; c0 < l; c0 += lc) {
+        const uint32_t lw = std::min(lc, l - c0);
+        uint32_t m = (uint32_t)(st.l2_tile_bytes / ((size_t)(1u << BT_SHIFT) * lw * 8));
+        if (m < 1u) m = 1u;
+        const uint32_t steps = (nb + m - 1u) / m;
+        const double bytes = ((double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_inner * lw * 8.0 +
+                              (double)cp.n_outer * lw * 8.0) / steps;
+        const double *offw = off_w ? off_w + c0 : nullptr;
+        for (uint32_t sidx = 0; sidx < steps; sidx++) {
+            const uint32_t b0 = sidx * m, b1 = std::min(nb, b0 + m);
+            ProfScope ps(st, cp.n_outer >= cp.n_inner ? (lw > 110 ? "spmm_gather2d_kernel<1>/long-outer/wide" : "spmm_gather2d_kernel<1>/long-outer")
+                                                      : "spmm_gather2d_kernel<1>/short-outer", bytes);
+            hipLaunchKernelGGL((spmm_gather2d_kernel<1>), grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p,
+                               cp.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, sidx + 1 == steps ? 1 : 0, cp.n_outer, map, X + c0,
+                               ldx, lw, out + c0, ldo, off_a, rank, offw, ldw);
+        }
+    }
+    SCANRS_HIP(hipGetLastError());
+}
+
+void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
                      double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw) {
+    const bool want_2d = st.spmm_path == 3 || (st.spmm_path == 0 && cp.nnz >= st.tiled_min_nnz && l >= 16);
+    if (want_2d && l > 0 && cp.n_outer > 0 && cp.n_inner > 0) {
+        launch_spmm_2d(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
+        return;
+    }
+    bool want_tiled = st.spmm_path == 2;
+    if (want_tiled && l > 0 && cp.n_outer > 0) {
+        if (!cp.tiles.tried) build_tile_copy(st, cp);
+        if (cp.tiles.usable) {
+            launch_spmm_tiled(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
+            return;
+        }
+    }
     launch_spmm_t<double>(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
 }
 void launch_spmm_u32(Storage &st, const SparseCopy &cp, const uint32_t *X, uint32_t ldx, uint32_t l, uint32_t *out,

@@ -429,3 +429,86 @@ def test_pca_is_deterministic(sa):
     b = sa.BkSvd().run_pca(g, 8)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+# ---- the LDS-tiled product kernel (forced on small inputs) vs the gather kernel and the oracle ------------------------
+@pytest.mark.parametrize("storage", [so.CSR, so.CSC])
+def test_tiled_kernel_matches_gather_and_oracle(sa, storage):
+    rng = np.random.default_rng(21 + storage)
+    # shapes around the tile (64) / group (16) / block (256) edges, empty vectors, dense and sparse parts
+    for rows, cols, fill in ((1, 1, 1.0), (15, 63, 0.5), (16, 64, 0.3), (17, 65, 0.9), (300, 130, 0.05), (257, 1000, 0.02),
+                             (700, 257, 0.2)):
+        dense = random_counts(rng, rows, cols, fill, 40)
+        dense[rng.random(rows) < 0.2, :] = 0  # some empty rows
+        dense[0, 0] = 7
+        g2, o = pair(sa, dense, storage)
+        g1, _ = pair(sa, dense, storage)
+        g3, _ = pair(sa, dense, storage)
+        g1.set_spmm_path(1)
+        g2.set_spmm_path(2)
+        g3.set_spmm_path(3)
+        f = rng.random(cols) + 0.5
+        fr = rng.random(rows) + 0.5
+        for gm in (g1, g2, g3):
+            gm.compose_scale_axis(1, f).apply(sa.FN_LOG2_1P).compose_scale_axis(0, fr)
+        o = o.compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=1, a=f)).apply(so.OP_LOG2_1P).compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=0, a=fr))
+        u, v = rng.standard_normal((rows, 2)), rng.standard_normal((2, cols))
+        g1.set_offset(u, v)
+        g2.set_offset(u, v)
+        g3.set_offset(u, v)
+        lo = so.LowRankOffset(o, u, v)
+        for l in (1, 2, 17, 64, 100, 127, 128, 129, 300):
+            q = rng.standard_normal((cols, l))
+            a1, a2, a3, ref = g1.dot(q), g2.dot(q), g3.dot(q), lo.dot(q)
+            assert_close(a2, ref, rtol=1e-10, atol=1e-9)
+            assert_close(a3, ref, rtol=1e-10, atol=1e-9)
+            assert_close(a1, a2, rtol=1e-11, atol=1e-10)
+            ql = rng.standard_normal((l, rows))
+            a1, a2, a3, ref = g1.rdot(ql), g2.rdot(ql), g3.rdot(ql), lo.rdot(ql)
+            assert_close(a2, ref, rtol=1e-10, atol=1e-9)
+            assert_close(a3, ref, rtol=1e-10, atol=1e-9)
+            assert_close(a1, a2, rtol=1e-11, atol=1e-10)
+
+
+def test_tiled_kernel_split_tiles_and_determinism(sa):
+    # few row blocks x many tiles -> the tile range is split over workgroups and summed in order
+    rng = np.random.default_rng(4)
+    dense = random_counts(rng, 40, 9000, 0.3, 25)
+    for path in (2, 3):  # path 3: several L2 steps carried through the output panel
+        g, o = pair(sa, dense + 0, so.CSR)
+        g.set_spmm_path(path)
+        sa.log_normalize_with_size_factor(g, None, sa.FN_LOG2_1P)
+        o = so.log_normalize_with_size_factor(o, None, so.LOG_TWO)
+        q = rng.standard_normal((9000, 100))
+        a = g.dot(q)
+        assert_close(a, o.dot(q), rtol=1e-10, atol=1e-8)
+        for _ in range(3):
+            assert np.array_equal(a, g.dot(q))
+        ql = rng.standard_normal((100, 40))
+        assert_close(g.rdot(ql), o.rdot(ql), rtol=1e-10, atol=1e-8)
+
+
+def test_tiled_kernel_falls_back_for_huge_counts(sa):
+    dense = np.zeros((20, 30), dtype=np.uint32)
+    dense[3, 4] = (1 << 20) + 5  # does not fit the 20-bit packed field: the gather kernel must serve it
+    dense[5, 6] = 3
+    g, o = pair(sa, dense, so.CSR)
+    g.set_spmm_path(2)
+    q = np.random.default_rng(0).standard_normal((30, 20))
+    assert_close(g.dot(q), o.dot(q), rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("path", [2, 3])
+def test_bksvd_through_tiled_kernel(sa, path):
+    m = _synth(2500, 600, 0.06, 1)
+    k = 10
+    g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+    g.set_spmm_path(path)
+    o = so.AdaptiveMat(m.shape[1], m.shape[0], so.CSC, m.indptr, m.indices, m.data)
+    g, o = sa.normalize(g, sa.Normalization.CellRanger), so.normalize(o, "cellranger")
+    omega = so.omega_panel((2 * k, m.shape[1]), 0)
+    u, s, v = sa.BkSvd().run_pca(g, k, omega=omega)
+    uo, s_o, vo = so.BkSvd().run_pca(o, k, omega=omega)
+    assert np.max(np.abs(s - s_o) / s_o) < 1e-8
+    assert np.max(np.abs(_sign_fix(u, uo) - uo)) < 1e-6
+    assert np.max(np.abs(_sign_fix(v, vo) - vo)) < 1e-6
