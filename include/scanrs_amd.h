@@ -212,8 +212,8 @@ int scanrs_profile_reset(scanrs_mat *m);
 /* Fills up to `cap` entries, writes the total count to *n. */
 int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uint32_t *n);
 /* Which f64 product kernel serves this handle (and its views): 0 = auto (L2-blocked gather for large matrices and
- * panels of 16+ columns, plain gather otherwise), 1 = plain gather, 2 = LDS-tiled kernel whenever the matrix allows
- * (counts below 2^20 - 1), 3 = L2-blocked gather. All are HIP kernels; results agree to rounding. */
+ * panels of 16+ columns, plain gather otherwise), 1 = plain gather, 2 = L2-blocked gather. Both are HIP kernels;
+ * results agree to rounding. */
 int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
 /* Block until all work queued on the handle's stream is done. */
 int scanrs_mat_sync(scanrs_mat *m);

@@ -392,7 +392,7 @@ class AdaptiveMat:
         _check(_lib.scanrs_mat_sync(self._h))
 
     def set_spmm_path(self, path: int):
-        """0 auto, 1 gather kernel, 2 LDS-tiled kernel (see scanrs_mat_set_spmm_path)."""
+        """0 auto, 1 plain gather kernel, 2 L2-blocked gather kernel (see scanrs_mat_set_spmm_path)."""
         _check(_lib.scanrs_mat_set_spmm_path(self._h, ctypes.c_int(path)))
         return self
 

@@ -959,7 +959,7 @@ int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uin
 int scanrs_mat_set_spmm_path(scanrs_mat *m, int path) {
     return guard([&] {
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
-        if (path < 0 || path > 3) fail(SCANRS_ERR_ARGUMENT, "path must be 0 (auto), 1 (gather), 2 (LDS-tiled) or 3 (L2-blocked gather)");
+        if (path < 0 || path > 2) fail(SCANRS_ERR_ARGUMENT, "path must be 0 (auto), 1 (plain gather) or 2 (L2-blocked gather)");
         m->st->spmm_path = path;
     });
 }

@@ -130,16 +130,6 @@ struct MultiRow {
     uint32_t _pad;
 };
 
-// LDS-tiled regrouping of a copy (tiled.hip): nonzeros ordered by (16-vector group, column tile, vector, column),
-// packed to 32 bits; starts/lens locate each (group, tile) segment.
-struct TileCopy {
-    bool tried = false, usable = false;
-    uint32_t T = 0, n_blocks = 0;
-    DevBuf<uint32_t> words;
-    DevBuf<uint64_t> starts;
-    DevBuf<uint16_t> lens;
-};
-
 // A compressed orientation: n_outer vectors over n_inner positions.
 struct SparseCopy {
     uint64_t n_outer = 0, n_inner = 0, nnz = 0;
@@ -148,7 +138,6 @@ struct SparseCopy {
     DevBuf<Item> items;
     DevBuf<MultiRow> multi;
     uint32_t n_items = 0, n_multi = 0, n_slab = 0;
-    TileCopy tiles;
     DevBuf<uint32_t> bounds; // L2-blocked gather: offset of the first nonzero >= b*1024 within each outer vector
     void build_items(hipStream_t s);
 };
@@ -172,9 +161,9 @@ struct Storage {
     Scratch scratch;
     Profile prof;
     ShardInfo shard; // sharding of primary's outer dimension
-    int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 LDS-tiled, 3 L2-blocked gather
+    int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 L2-blocked gather
     size_t l2_tile_bytes = 3u << 20;      // panel slice per step of the L2-blocked gather (4 MB L2 per XCD)
-    uint64_t tiled_min_nnz = 1ull << 22; // auto: matrices below this stay on the gather kernel
+    uint64_t blocked_min_nnz = 1ull << 22; // auto: matrices below this stay on the plain gather kernel
     ~Storage();
     // the copy whose outer dimension is the base matrix's rows (true) or cols (false)
     SparseCopy &copy_with_outer_rows(bool outer_rows);
@@ -238,9 +227,6 @@ namespace scanrs {
 // off_a: n_outer x rank (row-major) or null; off_w: rank x l (ld = ldw).
 void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
                      double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw);
-void build_tile_copy(Storage &st, SparseCopy &cp);
-void launch_spmm_tiled(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
-                       double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw);
 void launch_spmm_u32(Storage &st, const SparseCopy &cp, const uint32_t *X, uint32_t ldx, uint32_t l, uint32_t *out,
                      uint32_t ldo);
 // per-outer-vector reductions. mode 0: sum of raw u32 counts; 1: sum of mapped values; 2: sum and sum of squares.
@@ -257,6 +243,8 @@ void launch_gemm_nn(Storage &st, const double *X, uint32_t ldx, uint32_t n, cons
                     uint64_t rows, double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo);
 void launch_copy_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows, uint32_t l);
 void launch_fill_f64(Storage &st, double *p, uint64_t n, double v);
+void launch_permute_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows,
+                         const uint32_t *d_idx, uint32_t n_idx, bool scatter);
 void launch_finish_moments(Storage &st, const double *sum, const double *sumsq, uint64_t n, double m, int given_scale,
                            const double *scale_in, double *mean_over_scale_neg, double *inv_scale, double *scale_out);
 void launch_u32_to_scale(Storage &st, const uint32_t *counts, uint64_t n, double target, double *out);

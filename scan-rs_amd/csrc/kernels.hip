@@ -596,6 +596,18 @@ __global__ void copy_cols_kernel(const double *__restrict__ src, uint32_t lds, d
     const uint32_t c = (uint32_t)(e % l);
     dst[r * ldd + c] = src[r * lds + c];
 }
+// dst[:, j] = src[:, idx[j]] (gather) or dst[:, idx[j]] = src[:, j] (scatter), j < n_idx
+__global__ void permute_cols_kernel(const double *__restrict__ src, uint32_t lds, double *__restrict__ dst, uint32_t ldd,
+                                    uint64_t rows, const uint32_t *__restrict__ idx, uint32_t n_idx, int scatter) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * n_idx) return;
+    const uint64_t r = e / n_idx;
+    const uint32_t j = (uint32_t)(e % n_idx);
+    if (scatter)
+        dst[r * ldd + idx[j]] = src[r * lds + j];
+    else
+        dst[r * ldd + j] = src[r * lds + idx[j]];
+}
 __global__ void fill_kernel(double *p, uint64_t n, double v) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n) p[e] = v;
@@ -846,18 +858,10 @@ static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const
 
 void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
                      double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw) {
-    const bool want_2d = st.spmm_path == 3 || (st.spmm_path == 0 && cp.nnz >= st.tiled_min_nnz && l >= 16);
+    const bool want_2d = st.spmm_path == 2 || (st.spmm_path == 0 && cp.nnz >= st.blocked_min_nnz && l >= 16);
     if (want_2d && l > 0 && cp.n_outer > 0 && cp.n_inner > 0) {
         launch_spmm_2d(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
         return;
-    }
-    bool want_tiled = st.spmm_path == 2;
-    if (want_tiled && l > 0 && cp.n_outer > 0) {
-        if (!cp.tiles.tried) build_tile_copy(st, cp);
-        if (cp.tiles.usable) {
-            launch_spmm_tiled(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
-            return;
-        }
     }
     launch_spmm_t<double>(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
 }
@@ -970,6 +974,13 @@ void launch_copy_cols(Storage &st, const double *src, uint32_t lds, double *dst,
                       uint32_t l) {
     if (rows == 0 || l == 0) return;
     hipLaunchKernelGGL(copy_cols_kernel, grid1(rows * l, 256), dim3(256), 0, st.stream, src, lds, dst, ldd, rows, l);
+    SCANRS_HIP(hipGetLastError());
+}
+void launch_permute_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows,
+                         const uint32_t *d_idx, uint32_t n_idx, bool scatter) {
+    if (rows == 0 || n_idx == 0) return;
+    hipLaunchKernelGGL(permute_cols_kernel, grid1(rows * n_idx, 256), dim3(256), 0, st.stream, src, lds, dst, ldd, rows, d_idx,
+                       n_idx, scatter ? 1 : 0);
     SCANRS_HIP(hipGetLastError());
 }
 void launch_fill_f64(Storage &st, double *p, uint64_t n, double v) {

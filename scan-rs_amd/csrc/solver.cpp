@@ -10,12 +10,31 @@
 // Rayleigh-Ritz values, see DESIGN.md — and `svddc_into` of the 5b x n projection becomes an
 // eigendecomposition of its 5b x 5b Gram matrix (only the top k triplets are returned by the reference).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
 
 namespace scanrs {
+
+// SCANRS_TRACE=1: wall-clock of the solver phases on stderr (diagnostics only)
+static bool trace_on() {
+    static int v = -1;
+    if (v < 0) v = getenv("SCANRS_TRACE") ? 1 : 0;
+    return v == 1;
+}
+struct Tick {
+    const char *what;
+    std::chrono::steady_clock::time_point t0;
+    explicit Tick(const char *w) : what(w), t0(std::chrono::steady_clock::now()) {}
+    ~Tick() {
+        if (trace_on())
+            fprintf(stderr, "[scanrs trace] %-28s %8.3f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
 
 // ---- rand-family generator for the seeded start panel ("parity unpinned") -----
 struct SmallRng {
@@ -121,7 +140,11 @@ static void gemm_hostw(Ctx &c, const double *X, uint32_t ldx, uint32_t n, const 
 
 // Orthonormalise the columns of P (rows x n, ld) in place: iterated CholeskyQR, with a diagonal shift
 // when the Gram matrix is numerically singular (shifted CholeskyQR). tmp: same size as P.
-static void orth_cholqr(Ctx &c, double *P, double *tmp, uint32_t ld, uint32_t n, uint64_t rows, bool sharded_rows) {
+// coef (optional, coef_rows x n row-major): kept equal to the matrix C with P = (original basis) * C, i.e.
+// every right-multiplication applied to P is applied to it too.
+static void orth_cholqr(Ctx &c, double *P, double *tmp, uint32_t ld, uint32_t n, uint64_t rows, bool sharded_rows,
+                        std::vector<double> *coef = nullptr, uint32_t coef_rows = 0) {
+    Tick tk("  orth_cholqr");
     std::vector<double> G, R;
     for (int pass = 0; pass < 8; pass++) {
         gram_host(c, P, ld, n, P, ld, n, rows, sharded_rows, G);
@@ -145,6 +168,23 @@ static void orth_cholqr(Ctx &c, double *P, double *tmp, uint32_t ld, uint32_t n,
             for (uint32_t i = 0; i < n; i++) R[(size_t)i * n + i] += shift;
         }
         inv_upper(R.data(), (int)n);
+        if (coef) { // C <- C * R^-1 (R^-1 upper triangular)
+            Tick tk2("    coef Rinv update");
+            std::vector<double> nc((size_t)coef_rows * n, 0.0);
+            for (uint32_t r = 0; r < coef_rows; r++) {
+                const double *__restrict__ cr = coef->data() + (size_t)r * n;
+                double *__restrict__ o = nc.data() + (size_t)r * n;
+                bool any = false;
+                for (uint32_t p2 = 0; p2 < n; p2++) any = any || cr[p2] != 0.0;
+                if (!any) continue;
+                for (uint32_t p2 = 0; p2 < n; p2++) {
+                    const double x = cr[p2];
+                    const double *__restrict__ rr = R.data() + (size_t)p2 * n;
+                    for (uint32_t j = p2; j < n; j++) o[j] += x * rr[j];
+                }
+            }
+            coef->swap(nc);
+        }
         double *dW = c.dev("orth_w", (size_t)n * n);
         c.h2d(dW, R.data(), (size_t)n * n);
         launch_gemm_nn(c.st, P, ld, n, dW, n, n, rows, 1.0, 0.0, nullptr, 0, tmp, ld);
@@ -155,8 +195,10 @@ static void orth_cholqr(Ctx &c, double *P, double *tmp, uint32_t ld, uint32_t n,
 
 // Orthonormalise block `Bj` (rows x b, ld ldb) against the first `nprev` columns of Q (ld ldq) and
 // within itself; rounds of (project, CholeskyQR) until the projection is at rounding level.
+// coef / cfull (optional): coefficient bookkeeping, Bj = Korig * coef (coef: q x b), Q = Korig * cfull (q x q).
 static void orth_against(Ctx &c, const double *Q, uint32_t ldq, uint32_t nprev, double *Bj, double *tmp, uint32_t ldb,
-                         uint32_t b, uint64_t rows, bool sharded_rows) {
+                         uint32_t b, uint64_t rows, bool sharded_rows, std::vector<double> *coef = nullptr,
+                         const std::vector<double> *cfull = nullptr, uint32_t q = 0) {
     std::vector<double> C;
     for (int round = 0; round < 4; round++) {
         if (nprev) {
@@ -165,8 +207,20 @@ static void orth_against(Ctx &c, const double *Q, uint32_t ldq, uint32_t nprev, 
             for (double x : C) cmax = std::max(cmax, std::fabs(x));
             if (round >= 1 && cmax < 1e-14) return;
             gemm_hostw(c, Q, ldq, nprev, C, b, rows, -1.0, 1.0, Bj, ldb);
+            if (coef) { // coef -= cfull[:, :nprev] * C   (cfull is block upper triangular)
+                Tick tk2("    coef projection update");
+                for (uint32_t r = 0; r < nprev; r++) {
+                    double *__restrict__ o = coef->data() + (size_t)r * b;
+                    const double *__restrict__ cf = cfull->data() + (size_t)r * q;
+                    for (uint32_t p2 = (r / b) * b; p2 < nprev; p2++) {
+                        const double x = cf[p2];
+                        const double *__restrict__ cc = C.data() + (size_t)p2 * b;
+                        for (uint32_t j = 0; j < b; j++) o[j] -= x * cc[j];
+                    }
+                }
+            }
         }
-        orth_cholqr(c, Bj, tmp, ldb, b, rows, sharded_rows);
+        orth_cholqr(c, Bj, tmp, ldb, b, rows, sharded_rows, coef, q);
         if (!nprev) return;
     }
 }
@@ -188,7 +242,10 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
             G[(size_t)i * q + j] = G[(size_t)j * q + i] = a;
         }
     std::vector<double> w(q), Z((size_t)q * q);
-    if (!sym_eig(G.data(), (int)q, w.data(), Z.data())) fail(SCANRS_ERR_NUMERICAL, "eigensolver did not converge");
+    {
+        Tick tk("ritz: host sym_eig");
+        if (!sym_eig(G.data(), (int)q, w.data(), Z.data())) fail(SCANRS_ERR_NUMERICAL, "eigensolver did not converge");
+    }
     std::vector<double> E((size_t)q * k), Es((size_t)q * k);
     for (uint32_t j = 0; j < k; j++) {
         const double sig = std::sqrt(std::max(w[j], 0.0));
@@ -264,29 +321,93 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
         upload_panel(c, h.data(), ds, b, P, ldb);
     }
 
+    // The projection T = Q^T A (bk_svd.rs:104,131) is not recomputed as one q-wide sparse product: with
+    // K = [K_0 .. K_{n-1}] the blocks A^T K_i (resp. A K_i) for i < n-1 are exactly the first half-products of
+    // iterations 1..n-1, so they are written straight into T; one extra b-wide product supplies the last block
+    // and T' = (op(A) K) C with Q = K C (C small, tracked on the host through the orthonormalisation).
+    const bool reuse = (b % 2u) == 0u;
+    double *T = c.dev("bk_T", (size_t)dt * ldq);
     for (uint32_t i = 0; i < n_iter; i++) {
+        Tick tk("bk: iteration");
         // m >= n: B = qr((A B)^T A)^T .Q  (bk_svd.rs:94);  n > m: T = (B A)^T; B = qr(A T).Q^T  (bk_svd.rs:122-123)
-        mat_apply(m, to_t_transpose, P, ldb, b, Y, ldb);
-        mat_apply(m, !to_t_transpose, Y, ldb, b, P, ldb);
+        double *Yi = (reuse && i >= 1) ? T + (size_t)(i - 1) * b : Y;
+        const uint32_t ldy = (reuse && i >= 1) ? ldq : ldb;
+        mat_apply(m, to_t_transpose, P, ldb, b, Yi, ldy);
+        mat_apply(m, !to_t_transpose, Yi, ldy, b, P, ldb);
         orth_cholqr(c, P, Ptmp, ldb, b, ds, false);
         launch_copy_cols(c.st, P, ldb, K + (size_t)i * b, ldq, ds, b);
         c.sync();
         progress_check(snoop, (double)i / (double)n_iter * 0.8);
     }
+    if (reuse) {
+        Tick tk("bk: last block product");
+        mat_apply(m, to_t_transpose, P, ldb, b, T + (size_t)(n_iter - 1) * b, ldq);
+    }
     // Q = qr(K).Q: block i is already orthonormal; orthogonalise it against blocks < i.
+    std::vector<double> cfull((size_t)q * q, 0.0);
+    for (uint32_t i = 0; i < q; i++) cfull[(size_t)i * q + i] = 1.0;
     {
+        Tick tk("bk: orth(K)");
         double *Bj = c.dev("bk_Bj", (size_t)ds * ldb);
+        std::vector<double> coef;
         for (uint32_t i = 1; i < n_iter; i++) {
             launch_copy_cols(c.st, K + (size_t)i * b, ldq, Bj, ldb, ds, b);
-            orth_against(c, K, ldq, i * b, Bj, Ptmp, ldb, b, ds, false);
+            coef.assign((size_t)q * b, 0.0);
+            for (uint32_t j = 0; j < b; j++) coef[(size_t)(i * b + j) * b + j] = 1.0;
+            orth_against(c, K, ldq, i * b, Bj, Ptmp, ldb, b, ds, false, &coef, &cfull, q);
             launch_copy_cols(c.st, Bj, ldb, K + (size_t)i * b, ldq, ds, b);
+            for (uint32_t r = 0; r < q; r++)
+                for (uint32_t j = 0; j < b; j++) cfull[(size_t)r * q + i * b + j] = coef[(size_t)r * b + j];
         }
         c.sync();
     }
     progress_check(snoop, 0.82);
-    double *T = c.dev("bk_T", (size_t)dt * ldq);
-    mat_apply(m, to_t_transpose, K, ldq, q, T, ldq);
-    c.sync();
+    // T' = (op(A) K) C amplifies the rounding of op(A) K by |C|. Columns of Q whose coefficient column stays
+    // small (<= 1e5: error <= ~1e-11) take the cheap dense route; the others — directions in which the Krylov
+    // blocks are numerically dependent — are recomputed directly as a (narrow) sparse product op(A) Q[:, bad].
+    double cmax_limit = 1e5;
+    if (const char *e = getenv("SCANRS_REUSE_CMAX")) cmax_limit = atof(e);
+    std::vector<uint32_t> bad;
+    if (reuse) {
+        std::vector<double> colmax(q, 0.0);
+        for (uint32_t r = 0; r < q; r++)
+            for (uint32_t j = 0; j < q; j++) colmax[j] = std::max(colmax[j], std::fabs(cfull[(size_t)r * q + j]));
+        for (uint32_t j = 0; j < q; j++)
+            if (!(colmax[j] < cmax_limit)) bad.push_back(j);
+        if (trace_on()) fprintf(stderr, "[scanrs trace] bk: %zu of %u projection columns recomputed directly\n", bad.size(), q);
+    }
+    {
+        Tick tk("bk: projection");
+        if (reuse && bad.size() * 2 < q) {
+            // in place, last block first: T'_j = T[:, 0:(j+1)b] * C[0:(j+1)b, block j]
+            std::vector<double> W;
+            for (uint32_t j = n_iter - 1; j >= 1; j--) {
+                const uint32_t nr = (j + 1) * b;
+                W.assign((size_t)nr * b, 0.0);
+                for (uint32_t r = 0; r < nr; r++)
+                    for (uint32_t cc = 0; cc < b; cc++) W[(size_t)r * b + cc] = cfull[(size_t)r * q + j * b + cc];
+                double *dW = c.dev("bk_projw", (size_t)nr * b);
+                c.h2d(dW, W.data(), W.size());
+                launch_gemm_nn(c.st, T, ldq, nr, dW, b, b, dt, 1.0, 0.0, nullptr, 0, Y, ldb);
+                launch_copy_cols(c.st, Y, ldb, T + (size_t)j * b, ldq, dt, b);
+            }
+            if (!bad.empty()) {
+                const uint32_t nbad = (uint32_t)bad.size(), ldbad = even_up(nbad);
+                uint32_t *d_idx = c.st.scratch.get<uint32_t>("bk_badidx", nbad);
+                SCANRS_HIP(hipMemcpyAsync(d_idx, bad.data(), (size_t)nbad * 4, hipMemcpyHostToDevice, c.s));
+                c.sync();
+                double *Qbad = c.dev("bk_Qbad", (size_t)ds * ldbad);
+                double *Tbad = c.dev("bk_Tbad", (size_t)dt * ldbad);
+                launch_permute_cols(c.st, K, ldq, Qbad, ldbad, ds, d_idx, nbad, false);
+                mat_apply(m, to_t_transpose, Qbad, ldbad, nbad, Tbad, ldbad);
+                launch_permute_cols(c.st, Tbad, ldbad, T, ldq, dt, d_idx, nbad, true);
+            }
+        } else {
+            mat_apply(m, to_t_transpose, K, ldq, q, T, ldq);
+        }
+        c.sync();
+    }
+    Tick tk_fin("bk: ritz_finish");
     progress_check(snoop, 0.93);
     // m >= n: T = A Q (m x q): U = T E S^-1, V = Q E.   n > m: T^T = A^T Q (n x q): U = Q E, V = T E S^-1.
     if (rows_ge)
