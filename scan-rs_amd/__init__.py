@@ -58,6 +58,32 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(hipcc --offload-arch=gfx950). scan-rs_amd has no CPU fallback."
     )
+
+
+def _preload_rocm_runtime():
+    """PyTorch-ROCm wheels bundle their own HIP / HSA runtime under torch/lib with the same sonames as
+    /opt/rocm's. Whichever copy is loaded first serves the whole process, and torch does not find the GPU
+    when the system copy came first. So if torch is installed (not imported: find_spec only) its copy is
+    loaded up front; without torch the system runtime is used."""
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
+_preload_rocm_runtime()
 _lib = ctypes.CDLL(LIB_PATH)
 _lib.scanrs_last_error.restype = ctypes.c_char_p
 _lib.scanrs_version.restype = ctypes.c_char_p

@@ -497,3 +497,30 @@ def test_bksvd_through_each_product_kernel(sa, path):
     assert np.max(np.abs(s - s_o) / s_o) < 1e-8
     assert np.max(np.abs(_sign_fix(u, uo) - uo)) < 1e-6
     assert np.max(np.abs(_sign_fix(v, vo) - vo)) < 1e-6
+
+
+def test_nccl_hook_wraps_library_memory(sa):
+    # the collective hook bench.py hands to the library: an RCCL all-reduce on a tensor aliasing raw device
+    # memory (world size 1 here; the 2-rank numerics are covered by the gloo tests)
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    from scanrs_amd.dist import make_allreduce
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        hook = make_allreduce(dist, dev)
+        x = torch.arange(1000, dtype=torch.float64, device=dev)
+        assert hook(x.data_ptr(), x.numel(), 0) == 0
+        assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float64))
+        y = torch.arange(77, dtype=torch.int64, device=dev)
+        assert hook(y.data_ptr(), y.numel(), 1) == 0
+        assert torch.equal(y.cpu(), torch.arange(77, dtype=torch.int64))
+    finally:
+        dist.destroy_process_group()
