@@ -154,6 +154,14 @@ def main():
         dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
         name, st = dom
         achieved = st["algorithmic_bytes"] / (st["total_ms"] * 1e-3) / 1e9 if st["total_ms"] > 0 else 0.0
+        traffic = None
+        try:  # HBM bytes per launch from the committed PMC passes (profiles/, separate --pmc runs), headline workload only
+            with open(os.path.join(ROOT, "profiles", "r01b_pmc_traffic.json")) as f:
+                pm = json.load(f)["kernels"].get(name)
+            if pm and args.cells == 1_000_000 and args.genes == 33_000 and world == 1:
+                traffic = round(pm["hbm_bytes_per_launch_corrected"])
+        except (OSError, ValueError, KeyError):
+            traffic = None
         roof = {
             "bound": "hbm",
             "kernel": name,
@@ -161,7 +169,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None,
+            "traffic": traffic,
             "launches_per_step": st["launches"] / args.steps,
             "avg_launch_ms": round(st["total_ms"] / max(1, st["launches"]), 4),
             "algorithmic_bytes_per_launch": round(st["algorithmic_bytes"] / max(1, st["launches"])),
