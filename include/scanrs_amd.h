@@ -226,6 +226,8 @@ int scanrs_host_chol_upper(double *g, int n);
 int scanrs_host_inv_upper(double *r, int n);
 /* symmetric eigen-decomposition, w descending, z[i*n + j] = component i of eigenvector j */
 int scanrs_host_sym_eig(const double *a, int n, double *w, double *z);
+/* the k leading eigenpairs only: w[0..k) descending, z row-major n x k */
+int scanrs_host_sym_eig_topk(const double *a, int n, int k, double *w, double *z);
 
 #ifdef __cplusplus
 }

@@ -575,6 +575,14 @@ def host_sym_eig(a):
     return w, z
 
 
+def host_sym_eig_topk(a, k):
+    a = _f64(a)
+    n = a.shape[0]
+    w, z = np.zeros(k), np.zeros((n, k))
+    _check(_lib.scanrs_host_sym_eig_topk(_p(a), ctypes.c_int(n), ctypes.c_int(k), _p(w), _p(z)))
+    return w, z
+
+
 EXPORTED_SYMBOLS = [
     "scanrs_last_error", "scanrs_device_available", "scanrs_version", "scanrs_mat_create", "scanrs_mat_create_device",
     "scanrs_mat_free", "scanrs_mat_view", "scanrs_mat_t", "scanrs_mat_shape", "scanrs_mat_nnz", "scanrs_mat_storage",
@@ -585,5 +593,5 @@ EXPORTED_SYMBOLS = [
     "scanrs_normalize", "scanrs_log_normalize", "scanrs_log1p_normalize_fixed_point", "scanrs_mat_target_umi",
     "scanrs_pca_bk", "scanrs_pca_rand", "scanrs_pca_irlba", "scanrs_omega_fill", "scanrs_mat_set_shard",
     "scanrs_plan_shards", "scanrs_profile_enable", "scanrs_profile_reset", "scanrs_profile_get", "scanrs_mat_sync", "scanrs_mat_set_spmm_path",
-    "scanrs_host_chol_upper", "scanrs_host_inv_upper", "scanrs_host_sym_eig",
+    "scanrs_host_chol_upper", "scanrs_host_inv_upper", "scanrs_host_sym_eig", "scanrs_host_sym_eig_topk",
 ]

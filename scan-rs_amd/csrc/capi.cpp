@@ -977,5 +977,8 @@ int scanrs_host_inv_upper(double *r, int n) {
     return 0;
 }
 int scanrs_host_sym_eig(const double *a, int n, double *w, double *z) { return sym_eig(a, n, w, z) ? 0 : SCANRS_ERR_NUMERICAL; }
+int scanrs_host_sym_eig_topk(const double *a, int n, int k, double *w, double *z) {
+    return sym_eig_topk(a, n, k, w, z) ? 0 : SCANRS_ERR_NUMERICAL;
+}
 
 } // extern "C"

@@ -268,6 +268,8 @@ bool chol_upper(double *g, int n);
 void inv_upper(double *r, int n);
 // symmetric eigen-decomposition: on return w[0..n) descending, z row-major with z[i*n + j] = component i of vector j.
 bool sym_eig(const double *a, int n, double *w, double *z);
+// k leading eigenpairs only: w[0..k) descending, z row-major n x k
+bool sym_eig_topk(const double *a, int n, int k, double *w, double *z);
 
 // ---- solver.cpp ------------------------------------------------------------------------------------
 struct PcaOut {

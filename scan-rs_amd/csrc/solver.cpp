@@ -241,10 +241,11 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
             const double a = 0.5 * (G[(size_t)i * q + j] + G[(size_t)j * q + i]);
             G[(size_t)i * q + j] = G[(size_t)j * q + i] = a;
         }
-    std::vector<double> w(q), Z((size_t)q * q);
+    std::vector<double> w(k), Z((size_t)q * k);
     {
-        Tick tk("ritz: host sym_eig");
-        if (!sym_eig(G.data(), (int)q, w.data(), Z.data())) fail(SCANRS_ERR_NUMERICAL, "eigensolver did not converge");
+        Tick tk("ritz: host sym_eig_topk");
+        if (!sym_eig_topk(G.data(), (int)q, (int)k, w.data(), Z.data()))
+            fail(SCANRS_ERR_NUMERICAL, "eigensolver did not converge");
     }
     std::vector<double> E((size_t)q * k), Es((size_t)q * k);
     for (uint32_t j = 0; j < k; j++) {
@@ -252,8 +253,8 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
         hSigma[j] = sig;
         const double inv = sig > 0.0 ? 1.0 / sig : 0.0;
         for (uint32_t i = 0; i < q; i++) {
-            E[(size_t)i * k + j] = Z[(size_t)i * q + j];
-            Es[(size_t)i * k + j] = Z[(size_t)i * q + j] * inv;
+            E[(size_t)i * k + j] = Z[(size_t)i * k + j];
+            Es[(size_t)i * k + j] = Z[(size_t)i * k + j] * inv;
         }
     }
     const uint32_t ldk = even_up(k);

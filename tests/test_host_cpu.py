@@ -131,3 +131,26 @@ def test_world2_sharded_c_abi_on_one_gpu(tmp_path):
     for v in vs:
         assert v["v_rows"] == 600
         assert v["s_rel"] < 1e-8 and v["u_abs"] < 1e-6 and v["v_abs"] < 1e-6, v
+
+
+def test_host_sym_eig_topk(sa):
+    rng = np.random.default_rng(5)
+    for n, k in ((1, 1), (2, 2), (7, 3), (64, 64), (200, 20)):
+        a = rng.standard_normal((n + 2, n))
+        g = a.T @ a
+        w, z = sa.host_sym_eig_topk(g, k)
+        wr = np.linalg.eigvalsh(g)[::-1][:k]
+        assert np.allclose(w, wr, rtol=1e-12, atol=1e-12 * wr[0])
+        assert np.allclose(z.T @ z, np.eye(k), atol=1e-12)
+        assert np.max(np.abs(g @ z - z * w)) <= 1e-12 * wr[0]
+    # spectrum shaped like the projected Gram matrix of a PCA: a few large, a flat bulk, a numerically null tail
+    n = 300
+    q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+    lam = np.concatenate([np.linspace(1e8, 5e7, 19), 1e6 * (1 + 1e-3 * rng.random(200)), [3.0, 3.0, 3.0], 1e-9 * rng.random(78)])
+    g = q @ np.diag(lam) @ q.T
+    g = (g + g.T) / 2
+    w, z = sa.host_sym_eig_topk(g, 60)
+    ws = np.sort(lam)[::-1][:60]
+    assert np.max(np.abs(w - ws) / ws) < 1e-12
+    assert np.max(np.abs(z.T @ z - np.eye(60))) < 1e-12
+    assert np.max(np.abs(g @ z - z * w)) < 1e-12 * ws[0]
