@@ -370,6 +370,46 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     return v;
 }
 
+// Sparse x vector (panel of 1 or 2 columns: the Ix1 `Dot` impls of sqz/src/mat.rs:1092-1112,1150-1170 that
+// IRLBA runs on). Lanes stride over the nonzeros of the item, each gathers its own x entries; HBM-bound.
+__global__ __launch_bounds__(256) void spmv_kernel(const uint32_t *__restrict__ indices,
+                                                   const uint32_t *__restrict__ values,
+                                                   const Item *__restrict__ items, uint32_t n_items, DevMap map,
+                                                   const double *__restrict__ X, uint32_t ldx, uint32_t l,
+                                                   double *__restrict__ out, uint32_t ldo, double *__restrict__ slab,
+                                                   const double *__restrict__ off_a, uint32_t rank,
+                                                   const double *__restrict__ off_w, uint32_t ldw) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wid >= n_items) return;
+    const Item it = items[wid];
+    const uint32_t *__restrict__ ind = indices + it.start;
+    const uint32_t *__restrict__ val = values + it.start;
+    double s0 = 0.0, s1 = 0.0;
+    for (uint32_t p = lane; p < it.len; p += 64u) {
+        const uint32_t g = ind[p];
+        const double f = eval_map(map, val[p], it.row, g);
+        s0 = fma(f, X[(size_t)g * ldx], s0);
+        if (l > 1) s1 = fma(f, X[(size_t)g * ldx + 1], s1);
+    }
+    s0 = wave_sum(s0);
+    if (l > 1) s1 = wave_sum(s1);
+    if (lane == 0) {
+        if (it.slab == NO_SLAB) {
+            for (uint32_t q = 0; q < rank; q++) {
+                const double aq = off_a[(size_t)it.row * rank + q];
+                s0 += aq * off_w[(size_t)q * ldw];
+                if (l > 1) s1 += aq * off_w[(size_t)q * ldw + 1];
+            }
+            out[(size_t)it.row * ldo] = s0;
+            if (l > 1) out[(size_t)it.row * ldo + 1] = s1;
+        } else {
+            slab[(size_t)it.slab * ldo] = s0;
+            slab[(size_t)it.slab * ldo + 1] = s1;
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void row_reduce_kernel(const uint32_t *__restrict__ indices,
                                                          const uint32_t *__restrict__ values,
@@ -861,6 +901,22 @@ void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const doubl
     const bool want_2d = st.spmm_path == 2 || (st.spmm_path == 0 && cp.nnz >= st.blocked_min_nnz && l >= 16);
     if (want_2d && l > 0 && cp.n_outer > 0 && cp.n_inner > 0) {
         launch_spmm_2d(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
+        return;
+    }
+    if (l <= 2 && l > 0 && cp.n_outer > 0) {
+        if ((ldx & 1u) || (ldo & 1u)) fail(SCANRS_ERR_ARGUMENT, "panel leading dimensions must be even");
+        double *slab = nullptr;
+        if (cp.n_slab) slab = st.scratch.get<double>("spmm_slab", (size_t)cp.n_slab * ldo);
+        const dim3 grid((cp.n_items + 3u) / 4u), block(256);
+        {
+            ProfScope ps(st, "spmv_kernel", (double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)(cp.n_inner + cp.n_outer) * l * 8.0);
+            hipLaunchKernelGGL(spmv_kernel, grid, block, 0, st.stream, cp.indices.p, cp.values.p, cp.items.p, cp.n_items, map, X, ldx,
+                               l, out, ldo, slab, off_a, rank, off_w, ldw);
+        }
+        if (cp.n_multi)
+            hipLaunchKernelGGL((slab_reduce_kernel<double, 1>), dim3((cp.n_multi + 3u) / 4u), block, 0, st.stream, cp.multi.p, cp.n_multi,
+                               slab, l, out, ldo, off_a, rank, off_w, ldw);
+        SCANRS_HIP(hipGetLastError());
         return;
     }
     launch_spmm_t<double>(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
