@@ -74,14 +74,16 @@ def synth_counts_torch(n_cells: int, n_genes: int, density: float, seed: int, de
         depth = torch.exp(torch.randn(n, device=device, generator=g) * 0.3)
         p = depth[:, None] * rates[cluster, :] * scale
         mask = torch.rand((n, n_genes), device=device, generator=g) < p
-        lo, hi = max(c0, cell_begin) - c0, min(c1, cell_end) - c0
-        mask = mask[lo:hi]
         nz = mask.nonzero()
-        counts_parts.append(mask.sum(dim=1))
-        idx_parts.append(nz[:, 1].to(torch.int32))
         u = torch.rand(nz.shape[0], device=device, generator=g).clamp_(min=1e-12)
         # Geometric(0.6) on {1, 2, ...}: 1 + floor(log(u) / log(1 - 0.6))
-        val_parts.append((1 + torch.floor(torch.log(u) / np.log(0.4))).to(torch.int32))
+        vals = (1 + torch.floor(torch.log(u) / np.log(0.4))).to(torch.int32)
+        # the whole chunk is drawn, then the rows of this rank are kept: the matrix does not depend on the partition
+        lo, hi = max(c0, cell_begin) - c0, min(c1, cell_end) - c0
+        keep = (nz[:, 0] >= lo) & (nz[:, 0] < hi)
+        counts_parts.append(mask[lo:hi].sum(dim=1))
+        idx_parts.append(nz[keep, 1].to(torch.int32))
+        val_parts.append(vals[keep])
         del p, mask, nz, u
     counts = torch.cat(counts_parts)
     indptr = torch.zeros(counts.shape[0] + 1, dtype=torch.int64, device=device)

@@ -524,3 +524,21 @@ def test_nccl_hook_wraps_library_memory(sa):
         assert torch.equal(y.cpu(), torch.arange(77, dtype=torch.int64))
     finally:
         dist.destroy_process_group()
+
+
+def test_device_generator_is_partition_independent(sa):
+    # bench.py --gpus N: every rank draws its own cell range; the global matrix must not depend on N
+    import torch
+
+    from scanrs_amd.dist import shard_bounds
+    from scanrs_amd.synth import synth_counts_torch
+
+    dev = torch.device("cuda", 0)
+    whole = synth_counts_torch(10000, 300, 0.05, 3, dev)
+    for world in (2, 3):
+        parts = [synth_counts_torch(10000, 300, 0.05, 3, dev, lo, hi) for lo, hi in shard_bounds(10000, world)]
+        assert torch.equal(torch.cat([p[1] for p in parts]), whole[1])
+        assert torch.equal(torch.cat([p[2] for p in parts]), whole[2])
+        counts = torch.cat([p[0][1:] - p[0][:-1] for p in parts])
+        assert torch.equal(counts, whole[0][1:] - whole[0][:-1])
+    assert int(whole[2].min()) >= 1 and abs(float(whole[0][-1]) / (10000 * 300) - 0.05) < 0.005
