@@ -241,6 +241,13 @@ void launch_gram(Storage &st, const double *X, uint32_t ldx, uint32_t n, const d
 // Out[rows x m] = beta * Cin + alpha * X[rows x n] * W[n x m]   (W device, row-major ld = ldw). Cin may equal Out.
 void launch_gemm_nn(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *W, uint32_t ldw, uint32_t m,
                     uint64_t rows, double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo);
+// dense.hip: LDS-tiled MFMA versions for big panels
+bool gram_tiled_ok(uint32_t n, uint32_t m, uint64_t rows);
+bool gemm_tiled_ok(uint32_t n, uint32_t m, uint64_t rows);
+void launch_gram_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *Y, uint32_t ldy, uint32_t m,
+                       uint64_t rows, double *C);
+void launch_gemm_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *W, uint32_t ldw, uint32_t m,
+                       uint64_t rows, double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo);
 void launch_copy_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows, uint32_t l);
 void launch_fill_f64(Storage &st, double *p, uint64_t n, double v);
 void launch_permute_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows,

@@ -1,0 +1,261 @@
+// LDS-tiled tall-skinny dense kernels on v_mfma_f64_16x16x4_f64 (gfx950): the big-panel versions of
+// gram_kernel / gemm_nn_kernel in kernels.hip. They stand where the reference multiplies dense panels
+// through ndarray `dot` -> BLAS (`T = Q^T A` Gram / `Q.dot(&U)`, scan-rs/src/dim_red/bk_svd.rs:134-142).
+//
+// Both compute C_tile(128 x 128) += sum_k A[k][i] * B[k][j] from two LDS images laid out [k][128 + pad]:
+//   gram:  k = panel row,           A = X[:, i0:i0+128], B = Y[:, j0:j0+128]   (straight row copies)
+//   gemm:  k = inner dimension n,   A[k][i] = X[r0+i][k0+k] (transposed while staging), B = W[k0+k][j0:]
+// Workgroup = 4 waves, each owning a 64 x 64 quadrant as 4 x 4 MFMA tiles (64 f64 accumulators per lane).
+// Operand maps of v_mfma_f64_16x16x4_f64: lane l supplies A[i = l&15][k = l>>4], B[k = l>>4][j = l&15];
+// lane l holds D[row = (l>>4) + 4*reg][col = l&15]. LDS rows are padded to 144 doubles (1152 B) so that
+// the two k values a 32-lane ds_read_b64 group touches fall on disjoint bank halves.
+#include "common.hpp"
+
+#include <algorithm>
+
+namespace scanrs {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t DT = 128;  // tile edge
+constexpr uint32_t DK = 16;   // k-depth per staging step
+constexpr uint32_t DLD = 144; // LDS row stride in doubles
+
+__device__ __forceinline__ void tile_mma(const double *__restrict__ As, const double *__restrict__ Bs, uint32_t wi,
+                                         uint32_t wj, uint32_t li, uint32_t lk, d4 (&acc)[4][4]) {
+#pragma unroll
+    for (uint32_t kk = 0; kk < DK / 4; kk++) {
+        const uint32_t row = (kk * 4 + lk) * DLD;
+        double a[4], b[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            a[t] = As[row + wi * 64 + t * 16 + li];
+            b[t] = Bs[row + wj * 64 + t * 16 + li];
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int nj = 0; nj < 4; nj++) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+    }
+}
+
+// C = X^T Y over a slice of rows. grid.x = tile pair, grid.y = row split; partial tiles go to slab[split].
+__global__ __launch_bounds__(256) void gram_tiled_kernel(const double *__restrict__ X, uint32_t ldx, uint32_t n,
+                                                         const double *__restrict__ Y, uint32_t ldy, uint32_t m, uint64_t rows,
+                                                         uint64_t rows_per_split, const uint32_t *__restrict__ tile_ij,
+                                                         double *__restrict__ slab) {
+    __shared__ double As[DK * DLD];
+    __shared__ double Bs[DK * DLD];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint32_t li = lane & 15u, lk = lane >> 4, wi = w >> 1, wj = w & 1u;
+    const uint32_t i0 = tile_ij[2 * blockIdx.x] * DT, j0 = tile_ij[2 * blockIdx.x + 1] * DT;
+    const uint64_t r0 = (uint64_t)blockIdx.y * rows_per_split;
+    const uint64_t r1 = min(rows, r0 + rows_per_split);
+    d4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = (d4){0, 0, 0, 0};
+    // staging map: thread -> (k = tid / 16, 8 consecutive columns starting at (tid % 16) * 8).
+    // Register-staged pipeline: the global loads of block t+1 are issued before the MFMAs of block t and
+    // written to LDS after them, so their latency hides under 64 MFMAs per wave.
+    const uint32_t sk = tid >> 4, sc = (tid & 15u) * 8u;
+    d2 xa[4], yb[4];
+    auto load_block = [&](uint64_t r) {
+        const uint64_t gr = r + sk;
+        const bool rv = gr < r1;
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const uint32_t c = sc + 2u * h;
+            xa[h] = (d2){0.0, 0.0};
+            yb[h] = (d2){0.0, 0.0};
+            if (rv) {
+                const double *xr = X + gr * ldx + i0 + c;
+                const double *yr = Y + gr * ldy + j0 + c;
+                if (i0 + c + 1 < n)
+                    xa[h] = *reinterpret_cast<const d2 *>(xr);
+                else if (i0 + c < n)
+                    xa[h].x = xr[0];
+                if (j0 + c + 1 < m)
+                    yb[h] = *reinterpret_cast<const d2 *>(yr);
+                else if (j0 + c < m)
+                    yb[h].x = yr[0];
+            }
+        }
+    };
+    auto store_block = [&]() {
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const uint32_t c = sc + 2u * h;
+            *reinterpret_cast<d2 *>(&As[sk * DLD + c]) = xa[h];
+            *reinterpret_cast<d2 *>(&Bs[sk * DLD + c]) = yb[h];
+        }
+    };
+    if (r0 < r1) {
+        load_block(r0);
+        store_block();
+    }
+    __syncthreads();
+    for (uint64_t r = r0; r < r1; r += DK) {
+        const bool more = r + DK < r1;
+        if (more) load_block(r + DK);
+        tile_mma(As, Bs, wi, wj, li, lk, acc);
+        __syncthreads();
+        if (more) store_block();
+        __syncthreads();
+    }
+    double *__restrict__ dst = slab + (size_t)blockIdx.y * n * m;
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int nj = 0; nj < 4; nj++)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const uint32_t row = i0 + wi * 64 + mi * 16 + lk + 4 * reg;
+                const uint32_t col = j0 + wj * 64 + nj * 16 + li;
+                if (row < n && col < m) dst[(size_t)row * m + col] = acc[mi][nj][reg];
+            }
+}
+
+// ordered sum of the row-split partials; with `symmetric` the strictly-lower tiles were skipped and are mirrored
+__global__ void gram_tiled_finish_kernel(const double *__restrict__ slab, uint32_t splits, uint32_t n, uint32_t m,
+                                         int symmetric, double *__restrict__ C) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)n * m) return;
+    uint32_t row = (uint32_t)(e / m), col = (uint32_t)(e % m);
+    uint64_t src = e;
+    if (symmetric && row / DT > col / DT) src = (uint64_t)col * m + row;
+    double s = 0.0;
+    for (uint32_t k = 0; k < splits; k++) s += slab[(size_t)k * n * m + src];
+    C[e] = s;
+}
+
+// Out = beta * Cin + alpha * X W;  grid.x = 128-row tile, grid.y = 128-column tile
+__global__ __launch_bounds__(256) void gemm_tiled_kernel(const double *__restrict__ X, uint32_t ldx, uint32_t n,
+                                                         const double *__restrict__ W, uint32_t ldw, uint32_t m, uint64_t rows,
+                                                         double alpha, double beta, const double *Cin, uint32_t ldc,
+                                                         double *Out, uint32_t ldo) {
+    __shared__ double As[DK * DLD];
+    __shared__ double Bs[DK * DLD];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint32_t li = lane & 15u, lk = lane >> 4, wi = w >> 1, wj = w & 1u;
+    const uint64_t r0 = (uint64_t)blockIdx.x * DT;
+    const uint32_t j0 = blockIdx.y * DT;
+    d4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = (d4){0, 0, 0, 0};
+    // A staging: thread -> (row i = tid / 2, 8 consecutive k starting at (tid % 2) * 8), written transposed
+    const uint32_t ai = tid >> 1, ak = (tid & 1u) * 8u;
+    const uint64_t arow = r0 + ai;
+    const bool arv = arow < rows;
+    // B staging: thread -> (k = tid / 16, 8 consecutive columns)
+    const uint32_t bk = tid >> 4, bc = (tid & 15u) * 8u;
+    d2 av[4], bv[4];
+    auto load_block = [&](uint32_t k0) {
+        const double *xr = X + arow * ldx + k0 + ak;
+        const uint32_t kb = k0 + bk;
+        const double *wr = W + (size_t)kb * ldw + j0 + bc;
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            const uint32_t kk = k0 + ak + 2u * h;
+            av[h] = (d2){0.0, 0.0};
+            if (arv) {
+                if (kk + 1 < n)
+                    av[h] = *reinterpret_cast<const d2 *>(xr + 2 * h);
+                else if (kk < n)
+                    av[h].x = xr[2 * h];
+            }
+            const uint32_t c = bc + 2u * h;
+            bv[h] = (d2){0.0, 0.0};
+            if (kb < n) {
+                if (j0 + c + 1 < m)
+                    bv[h].x = wr[2 * h], bv[h].y = wr[2 * h + 1]; // ldw may be odd: scalar loads
+                else if (j0 + c < m)
+                    bv[h].x = wr[2 * h];
+            }
+        }
+    };
+    auto store_block = [&]() {
+#pragma unroll
+        for (int h = 0; h < 4; h++) {
+            As[(ak + 2u * h) * DLD + ai] = av[h].x;
+            As[(ak + 2u * h + 1u) * DLD + ai] = av[h].y;
+            *reinterpret_cast<d2 *>(&Bs[bk * DLD + bc + 2u * h]) = bv[h];
+        }
+    };
+    if (n > 0) {
+        load_block(0);
+        store_block();
+    }
+    __syncthreads();
+    for (uint32_t k0 = 0; k0 < n; k0 += DK) {
+        const bool more = k0 + DK < n;
+        if (more) load_block(k0 + DK);
+        tile_mma(As, Bs, wi, wj, li, lk, acc);
+        __syncthreads();
+        if (more) store_block();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const uint64_t row = r0 + wi * 64 + mi * 16 + lk + 4 * reg;
+            if (row >= rows) continue;
+#pragma unroll
+            for (int nj = 0; nj < 4; nj++) {
+                const uint32_t col = j0 + wj * 64 + nj * 16 + li;
+                if (col >= m) continue;
+                double r = alpha * acc[mi][nj][reg];
+                if (beta != 0.0) r = fma(beta, Cin[row * ldc + col], r);
+                Out[row * ldo + col] = r;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+bool gram_tiled_ok(uint32_t n, uint32_t m, uint64_t rows) { return n >= 48 && m >= 48 && rows >= 2048; }
+bool gemm_tiled_ok(uint32_t n, uint32_t m, uint64_t rows) { return n >= 16 && m >= 48 && rows >= 2048; }
+
+void launch_gram_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *Y, uint32_t ldy, uint32_t m,
+                       uint64_t rows, double *C) {
+    const uint32_t tn = (n + DT - 1) / DT, tm = (m + DT - 1) / DT;
+    const bool symmetric = X == Y && ldx == ldy && n == m;
+    std::vector<uint32_t> tiles;
+    for (uint32_t i = 0; i < tn; i++)
+        for (uint32_t j = symmetric ? i : 0; j < tm; j++) {
+            tiles.push_back(i);
+            tiles.push_back(j);
+        }
+    const uint32_t n_tiles = (uint32_t)tiles.size() / 2;
+    uint32_t *d_tiles = st.scratch.get<uint32_t>("gramt_tiles", tiles.size());
+    SCANRS_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st.stream));
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    // ~2k workgroups, slices of at least 256 rows and a multiple of the staging depth
+    uint64_t splits = std::max<uint64_t>(1, std::min<uint64_t>((rows + 255) / 256, (2048 + n_tiles - 1) / n_tiles));
+    uint64_t rps = (rows + splits - 1) / splits;
+    rps = (rps + DK - 1) / DK * DK;
+    splits = std::max<uint64_t>(1, (rows + rps - 1) / rps);
+    double *slab = st.scratch.get<double>("gram_slab", (size_t)splits * n * m);
+    if (st.prof.on) st.prof.begin(st.stream, "gram_tiled_mfma_f64", (double)rows * (n + (symmetric ? 0 : m)) * 8.0 + (double)n * m * 8.0);
+    hipLaunchKernelGGL(gram_tiled_kernel, dim3(n_tiles, (unsigned)splits), dim3(256), 0, st.stream, X, ldx, n, Y, ldy, m, rows, rps,
+                       d_tiles, slab);
+    hipLaunchKernelGGL(gram_tiled_finish_kernel, dim3((unsigned)(((uint64_t)n * m + 255) / 256)), dim3(256), 0, st.stream, slab,
+                       (uint32_t)splits, n, m, symmetric ? 1 : 0, C);
+    if (st.prof.on) st.prof.end(st.stream);
+    SCANRS_HIP(hipGetLastError());
+}
+
+void launch_gemm_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *W, uint32_t ldw, uint32_t m,
+                       uint64_t rows, double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo) {
+    if (st.prof.on) st.prof.begin(st.stream, "gemm_tiled_mfma_f64", (double)rows * (n + m) * 8.0 + (double)n * m * 8.0);
+    hipLaunchKernelGGL(gemm_tiled_kernel, dim3((unsigned)((rows + DT - 1) / DT), (m + DT - 1) / DT), dim3(256), 0, st.stream, X, ldx,
+                       n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
+    if (st.prof.on) st.prof.end(st.stream);
+    SCANRS_HIP(hipGetLastError());
+}
+
+} // namespace scanrs

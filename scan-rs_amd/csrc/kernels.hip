@@ -985,6 +985,10 @@ void launch_weighted_colsum(Storage &st, const double *B, uint32_t rank, const d
 void launch_gram(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *Y, uint32_t ldy, uint32_t m,
                  uint64_t rows, double *C) {
     if (n == 0 || m == 0) return;
+    if (gram_tiled_ok(n, m, rows) && !(ldx & 1u) && !(ldy & 1u)) {
+        launch_gram_tiled(st, X, ldx, n, Y, ldy, m, rows, C);
+        return;
+    }
     const uint32_t tiles_n = (n + 31u) / 32u, tiles_m = (m + 31u) / 32u;
     const uint64_t tiles = (uint64_t)tiles_n * tiles_m;
     // aim for ~8k waves, at least 64 rows per slice
@@ -1010,6 +1014,10 @@ void launch_gemm_nn(Storage &st, const double *X, uint32_t ldx, uint32_t n, cons
                     uint32_t ldo) {
     if (rows == 0 || m == 0) return;
     if (ldx & 1u) fail(SCANRS_ERR_ARGUMENT, "gemm: ldx must be even");
+    if (gemm_tiled_ok(n, m, rows)) {
+        launch_gemm_tiled(st, X, ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
+        return;
+    }
     const uint64_t waves = (rows + 15) / 16;
     ProfScope ps(st, "gemm_nn_mfma_f64", (double)rows * (n + m) * 8.0 + (double)n * m * 8.0);
     const dim3 block(256);
