@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--cpu-cells", type=int, default=8000, help="cells of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also time one step that copies U and V to the host")
+    ap.add_argument("--also-randsvd", action="store_true", help="also time one RandSvd{10, 2} PCA (SURVEY.md §8d: reported alongside)")
     ap.add_argument("--events-in-timed-region", action="store_true",
                     help="record the per-launch HIP events inside the K timed steps instead of in a second pass of K steps")
     return ap.parse_args()
@@ -163,6 +164,19 @@ def main():
         barrier()
         pcie = args.cells / (time.perf_counter() - t0)
 
+    randsvd_ms = None
+    if args.also_randsvd and world == 1:
+        import ctypes
+
+        mat.reset_map()
+        sa.normalize(mat, sa.Normalization.CellRanger)
+        barrier()
+        t0 = time.perf_counter()
+        sa._check(sa._lib.scanrs_pca_rand(mat._h, ctypes.c_uint32(args.k), ctypes.c_double(10.0), ctypes.c_uint32(2), ctypes.c_uint64(0),
+                                          None, None, s_out.ctypes.data_as(ctypes.c_void_p), None))
+        barrier()
+        randsvd_ms = (time.perf_counter() - t0) * 1e3
+
     # ---- roofline of the dominant kernel -------------------------------------------------------------------
     roof = None
     if prof:
@@ -246,6 +260,8 @@ def main():
         }
         if pcie is not None:
             out["config"]["pcie_inclusive_cells_per_s"] = round(pcie, 1)
+        if randsvd_ms is not None:
+            out["config"]["randsvd_l10_it2_ms"] = round(randsvd_ms, 1)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -211,3 +211,18 @@ def test_smallrng_is_deterministic():
     b = so.omega_panel((3, 5), 0)
     assert np.array_equal(a, b) and a.min() >= -1.0 and a.max() < 1.0
     assert not np.array_equal(a, so.omega_panel((3, 5), 1))
+
+
+def test_config1_plumbing_10k_x_2k():
+    # BASELINE.json configs[0]: 10k cells x 2k genes, 5 % nnz, top-10 PCA on the CPU path (no GPU)
+    from scanrs_amd.synth import synth_counts
+
+    m = synth_counts(10_000, 2_000, 0.05, 0)
+    assert abs(m.nnz / (10_000 * 2_000) - 0.05) < 0.005
+    a = so.normalize(so.AdaptiveMat(2_000, 10_000, so.CSC, m.indptr, m.indices, m.data), "cellranger")
+    u, s, v = so.BkSvd().run_pca(a, 10)
+    assert u.shape == (2_000, 10) and v.shape == (10_000, 10)
+    assert np.all(np.diff(s) <= 0)
+    assert np.max(np.abs(u.T @ u - np.eye(10))) < 1e-10 and np.max(np.abs(v.T @ v - np.eye(10))) < 1e-10
+    # Ritz relation A^T u = s v
+    assert np.max(np.abs(a.rdot(u.T).T - v * s)) < 1e-8 * s[0]
