@@ -542,3 +542,54 @@ def test_device_generator_is_partition_independent(sa):
         counts = torch.cat([p[0][1:] - p[0][:-1] for p in parts])
         assert torch.equal(counts, whole[0][1:] - whole[0][:-1])
     assert int(whole[2].min()) >= 1 and abs(float(whole[0][-1]) / (10000 * 300) - 0.05) < 0.005
+
+
+# ---- solver edge cases ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k,mult,n_iter", [(1, 2.0, 5), (3, 1.0, 2), (7, 1.5, 3), (5, 2.6, 1), (10, 2.0, 5)])
+def test_bksvd_parameter_grid_matches_oracle(sa, k, mult, n_iter):
+    # odd block sizes (b = ceil(k * mult)) take the direct projection product, even ones the reuse path
+    m = _synth(900, 260, 0.08, 12)
+    for transposed in (False, True):
+        g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+        o = so.AdaptiveMat(m.shape[1], m.shape[0], so.CSC, m.indptr, m.indices, m.data)
+        g, o = sa.normalize(g, sa.Normalization.CellRanger), so.normalize(o, "cellranger")
+        if transposed:
+            g, o = g.t(), o.t()
+        u, s, v = sa.BkSvd(mult, n_iter).run_pca(g, k)
+        uo, s_o, vo = so.BkSvd(mult, n_iter).run_pca(o, k)
+        assert np.max(np.abs(s - s_o) / s_o) < 1e-8
+        assert np.max(np.abs(_sign_fix(u, uo) - uo)) < 1e-6
+        assert np.max(np.abs(_sign_fix(v, vo) - vo)) < 1e-6
+
+
+def test_bksvd_block_clipped_to_matrix_size(sa):
+    # b = min(m, n, b) (bk_svd.rs:81): a 12 x 40 matrix with k = 5 -> b = 10, then 5 blocks of 10 > 12 rows is refused
+    rng = np.random.default_rng(3)
+    dense = random_counts(rng, 12, 40, 0.7, 9) + 1
+    g, o = pair(sa, dense, so.CSR)
+    with pytest.raises(sa.ScanrsError):
+        sa.BkSvd().run_pca(g, 5)
+    # 2 x 2 is the smallest accepted input (bk_svd.rs:73-75)
+    g2, o2 = pair(sa, np.array([[3, 1], [1, 2]], dtype=np.uint32), so.CSR)
+    u, s, v = sa.BkSvd(1.0, 2).run_pca(g2, 1)
+    full = np.linalg.svd(np.array([[3.0, 1.0], [1.0, 2.0]]), compute_uv=False)
+    assert abs(s[0] - full[0]) < 1e-9 * full[0]
+
+
+def test_empty_vectors_and_reset_map(sa):
+    rng = np.random.default_rng(9)
+    dense = random_counts(rng, 50, 80, 0.2, 9)
+    dense[:, 5] = 0  # a barcode with no counts: the reference divides by zero too (inf scale, never applied)
+    dense[7, :] = 0  # a gene never seen: variance 0 -> scale 1 (mat.rs:996)
+    dense[:, 6] += 1
+    for storage in (so.CSR, so.CSC):
+        g, o = pair(sa, dense, storage)
+        g, o = sa.normalize(g, sa.Normalization.CellRanger), so.normalize(o, "cellranger")
+        assert_close(g.to_dense(), o.to_dense(), rtol=1e-11, atol=1e-11)
+        q = rng.standard_normal((80, 9))
+        assert_close(g.dot(q), o.dot(q), rtol=1e-10, atol=1e-9)
+        # the handle can be taken back to raw counts and normalised differently
+        g.reset_map()
+        assert np.array_equal(g.to_dense(), dense.astype(np.float64))
+        sa.normalize(g, sa.Normalization.SeuratLog)
+        assert_close(g.to_dense(), so.normalize(pair(sa, dense, storage)[1], "seuratlog").to_dense(), rtol=1e-11, atol=1e-11)
