@@ -230,7 +230,7 @@ void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const doubl
 void launch_spmm_u32(Storage &st, const SparseCopy &cp, const uint32_t *X, uint32_t ldx, uint32_t l, uint32_t *out,
                      uint32_t ldo);
 // per-outer-vector reductions. mode 0: sum of raw u32 counts; 1: sum of mapped values; 2: sum and sum of squares.
-void launch_row_reduce(Storage &st, const SparseCopy &cp, const DevMap &map, int mode, uint32_t *out_u32, double *out_sum,
+void launch_row_reduce(Storage &st, SparseCopy &cp, const DevMap &map, int mode, uint32_t *out_u32, double *out_sum,
                        double *out_sumsq);
 // w[rank x l] (ld ldw) = B^T X, B: n x rank row-major, X: n x l (ld ldx)
 void launch_weighted_colsum(Storage &st, const double *B, uint32_t rank, const double *X, uint32_t ldx, uint64_t n,

@@ -454,6 +454,38 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(const uint32_t *__restr
     }
 }
 
+// Blocked form of the mapped reductions: when the map reads an array indexed by the INNER position (the per-barcode
+// scale while walking gene-major vectors) and that array is larger than an XCD's L2, a straight pass turns every
+// nonzero into a 64-B miss (measured 4x the algorithmic HBM bytes). Walking the vectors in steps of inner positions
+// whose slice of the array is L2-resident (bounds table) brings the traffic back to the nonzeros themselves.
+template <int MODE>
+__global__ __launch_bounds__(256) void row_reduce2d_kernel(const uint64_t *__restrict__ indptr,
+                                                           const uint32_t *__restrict__ indices,
+                                                           const uint32_t *__restrict__ values,
+                                                           const uint32_t *__restrict__ bounds, uint32_t nb, uint32_t b0,
+                                                           uint32_t b1, int first, uint64_t n_outer, DevMap map,
+                                                           double *__restrict__ out_sum, double *__restrict__ out_sumsq) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t row = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row >= n_outer) return;
+    const uint32_t *__restrict__ bd = bounds + row * (nb + 1);
+    const uint32_t o0 = bd[b0], len = bd[b1] - o0;
+    if (len == 0 && !first) return;
+    const uint64_t base = indptr[row] + o0;
+    double s = 0.0, s2 = 0.0;
+    for (uint32_t p = lane; p < len; p += 64u) {
+        const double x = eval_map(map, values[base + p], (uint32_t)row, indices[base + p]);
+        s += x;
+        if constexpr (MODE == 2) s2 = fma(x, x, s2);
+    }
+    s = wave_sum(s);
+    if constexpr (MODE == 2) s2 = wave_sum(s2);
+    if (lane == 0) {
+        out_sum[row] = first ? s : out_sum[row] + s;
+        if constexpr (MODE == 2) out_sumsq[row] = first ? s2 : out_sumsq[row] + s2;
+    }
+}
+
 template <int MODE>
 __global__ void row_reduce_finish_kernel(const MultiRow *__restrict__ multi, uint32_t n_multi,
                                          const uint32_t *__restrict__ slab_u32, const double *__restrict__ slab_f64,
@@ -859,11 +891,8 @@ static void launch_spmm_t(Storage &st, const SparseCopy &cp, const DevMap &map, 
     SCANRS_HIP(hipGetLastError());
 }
 
-// L2-blocked gather: see spmm_gather2d_kernel.
-static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
-                           double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w,
-                           uint32_t ldw) {
-    if ((ldx & 1u) || (ldo & 1u)) fail(SCANRS_ERR_ARGUMENT, "panel leading dimensions must be even");
+// the table of per-outer-vector offsets at multiples of 1024 inner positions; returns the number of base tiles
+static uint32_t ensure_bounds(Storage &st, SparseCopy &cp) {
     const uint32_t nb = (uint32_t)((cp.n_inner + (1ull << BT_SHIFT) - 1) >> BT_SHIFT);
     if (cp.bounds.n != cp.n_outer * (nb + 1)) {
         cp.bounds.alloc(cp.n_outer * (nb + 1));
@@ -871,6 +900,15 @@ static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const
         hipLaunchKernelGGL(build_bounds_kernel, grid1(n, 256), dim3(256), 0, st.stream, cp.indptr.p, cp.indices.p, cp.n_outer,
                            nb, cp.bounds.p);
     }
+    return nb;
+}
+
+// L2-blocked gather: see spmm_gather2d_kernel.
+static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
+                           double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w,
+                           uint32_t ldw) {
+    if ((ldx & 1u) || (ldo & 1u)) fail(SCANRS_ERR_ARGUMENT, "panel leading dimensions must be even");
+    const uint32_t nb = ensure_bounds(st, cp);
     // column chunks of <= 128 keep a panel-row slice <= 1 KB, so a step can hold >= 3 base tiles in L2
     const uint32_t n_chunks = (l + 127u) / 128u;
     uint32_t lc = (l + n_chunks - 1u) / n_chunks;
@@ -928,9 +966,35 @@ void launch_spmm_u32(Storage &st, const SparseCopy &cp, const uint32_t *X, uint3
     launch_spmm_t<uint32_t>(st, cp, map, X, ldx, l, out, ldo, nullptr, 0, nullptr, 0);
 }
 
-void launch_row_reduce(Storage &st, const SparseCopy &cp, const DevMap &map, int mode, uint32_t *out_u32, double *out_sum,
+static uint32_t ensure_bounds(Storage &st, SparseCopy &cp);
+
+void launch_row_reduce(Storage &st, SparseCopy &cp, const DevMap &map, int mode, uint32_t *out_u32, double *out_sum,
                        double *out_sumsq) {
     if (cp.n_outer == 0) return;
+    if (mode != 0 && cp.nnz >= st.blocked_min_nnz && cp.n_inner >= (1ull << 19)) {
+        bool inner_indexed = false;
+        for (int i = 0; i < map.n; i++)
+            inner_indexed = inner_indexed || (map.ops[i].a && !map.ops[i].a_outer) || (map.ops[i].b && !map.ops[i].b_outer);
+        if (inner_indexed) {
+            const uint32_t nb = ensure_bounds(st, cp);
+            const uint32_t m = 256; // 256 * 1024 inner positions * 8 B = 2 MB slice of the scale array
+            const uint32_t steps = (nb + m - 1) / m;
+            const dim3 grid((unsigned)((cp.n_outer + 3) / 4)), block(256);
+            const double bytes = ((double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_outer * (mode == 1 ? 8.0 : 16.0)) / steps;
+            for (uint32_t sidx = 0; sidx < steps; sidx++) {
+                const uint32_t b0 = sidx * m, b1 = std::min(nb, b0 + m);
+                ProfScope ps(st, mode == 1 ? "row_reduce2d_sum" : "row_reduce2d_moments", bytes);
+                if (mode == 1)
+                    hipLaunchKernelGGL((row_reduce2d_kernel<1>), grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p,
+                                       cp.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, cp.n_outer, map, out_sum, out_sumsq);
+                else
+                    hipLaunchKernelGGL((row_reduce2d_kernel<2>), grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p,
+                                       cp.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, cp.n_outer, map, out_sum, out_sumsq);
+            }
+            SCANRS_HIP(hipGetLastError());
+            return;
+        }
+    }
     uint32_t *slab_u32 = nullptr;
     double *slab_f64 = nullptr;
     if (cp.n_slab) {
