@@ -205,7 +205,8 @@ typedef struct {
     char name[48];
     uint64_t launches;
     double total_ms;
-    double algorithmic_bytes; /* summed over launches, SURVEY.md §8d accounting */
+    double algorithmic_bytes;   /* summed over launches, SURVEY.md §8d accounting */
+    double onchip_gather_bytes; /* panel bytes gathered through L2 / L1 by the sparse products (nnz * 8 * l), else 0 */
 } scanrs_kernel_stat;
 int scanrs_profile_enable(scanrs_mat *m, int on);
 int scanrs_profile_reset(scanrs_mat *m);

@@ -102,6 +102,7 @@ class _KernelStat(ctypes.Structure):
         ("launches", ctypes.c_uint64),
         ("total_ms", ctypes.c_double),
         ("algorithmic_bytes", ctypes.c_double),
+        ("onchip_gather_bytes", ctypes.c_double),
     ]
 
 
@@ -410,6 +411,7 @@ class AdaptiveMat:
                 "launches": int(arr[i].launches),
                 "total_ms": float(arr[i].total_ms),
                 "algorithmic_bytes": float(arr[i].algorithmic_bytes),
+                "onchip_gather_bytes": float(arr[i].onchip_gather_bytes),
             }
             for i in range(min(int(n.value), 64))
         }

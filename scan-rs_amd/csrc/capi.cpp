@@ -73,8 +73,8 @@ hipEvent_t Profile::take() {
     SCANRS_HIP(hipEventCreate(&e));
     return e;
 }
-void Profile::begin(hipStream_t s, const char *name, double bytes) {
-    Rec r{name, take(), take(), bytes};
+void Profile::begin(hipStream_t s, const char *name, double bytes, double onchip) {
+    Rec r{name, take(), take(), bytes, onchip};
     SCANRS_HIP(hipEventRecord(r.a, s));
     pending.push_back(r);
 }
@@ -90,6 +90,7 @@ void Profile::resolve() {
             st.launches++;
             st.ms += ms;
             st.bytes += r.bytes;
+            st.onchip += r.onchip;
         }
         pool.push_back(r.a);
         pool.push_back(r.b);
@@ -950,6 +951,7 @@ int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uin
                 out[i].launches = kv.second.launches;
                 out[i].total_ms = kv.second.ms;
                 out[i].algorithmic_bytes = kv.second.bytes;
+                out[i].onchip_gather_bytes = kv.second.onchip;
             }
             i++;
         }

@@ -91,17 +91,17 @@ struct Profile {
     struct Rec {
         std::string name;
         hipEvent_t a, b;
-        double bytes;
+        double bytes, onchip;
     };
     std::vector<Rec> pending;
     std::vector<hipEvent_t> pool;
     struct Stat {
         uint64_t launches = 0;
-        double ms = 0, bytes = 0;
+        double ms = 0, bytes = 0, onchip = 0;
     };
     std::map<std::string, Stat> stats;
     hipEvent_t take();
-    void begin(hipStream_t s, const char *name, double bytes);
+    void begin(hipStream_t s, const char *name, double bytes, double onchip = 0.0);
     void end(hipStream_t s);
     void resolve();
     void reset();

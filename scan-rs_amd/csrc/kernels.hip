@@ -137,13 +137,14 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const uint32_t *__rest
     const uint32_t *__restrict__ ind = indices + start;
     const uint32_t *__restrict__ val = values + start;
 
-    uint32_t col[NACC];
+    uint32_t col[NACC], lcol[NACC];
     bool act[NACC];
     V2 acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) {
         col[a] = (a * 64u + lane) * 2u;
         act[a] = col[a] < l;
+        lcol[a] = act[a] ? col[a] : 0u;
         acc[a] = (V2){(T)0, (T)0};
     }
 
@@ -168,12 +169,10 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const uint32_t *__rest
                 const T fv = bcast<T>(f, j + u);
                 const T *__restrict__ xr = X + (size_t)g * ldx;
 #pragma unroll
-                for (int a = 0; a < NACC; a++) {
-                    if (act[a]) {
-                        const V2 x = *reinterpret_cast<const V2 *>(xr + col[a]);
-                        acc[a].x = mul_add<T>(fv, x.x, acc[a].x);
-                        acc[a].y = mul_add<T>(fv, x.y, acc[a].y);
-                    }
+                for (int a = 0; a < NACC; a++) { // no branch: idle lanes re-read column pair 0 and discard it
+                    const V2 x = *reinterpret_cast<const V2 *>(xr + lcol[a]);
+                    acc[a].x = mul_add<T>(fv, x.x, acc[a].x);
+                    acc[a].y = mul_add<T>(fv, x.y, acc[a].y);
                 }
             }
         }
@@ -182,12 +181,10 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const uint32_t *__rest
             const T fv = bcast<T>(f, j);
             const T *__restrict__ xr = X + (size_t)g * ldx;
 #pragma unroll
-            for (int a = 0; a < NACC; a++) {
-                if (act[a]) {
-                    const V2 x = *reinterpret_cast<const V2 *>(xr + col[a]);
-                    acc[a].x = mul_add<T>(fv, x.x, acc[a].x);
-                    acc[a].y = mul_add<T>(fv, x.y, acc[a].y);
-                }
+            for (int a = 0; a < NACC; a++) { // no branch: idle lanes re-read column pair 0 and discard it
+                const V2 x = *reinterpret_cast<const V2 *>(xr + lcol[a]);
+                acc[a].x = mul_add<T>(fv, x.x, acc[a].x);
+                acc[a].y = mul_add<T>(fv, x.y, acc[a].y);
             }
         }
     }
@@ -260,13 +257,14 @@ __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
     const uint32_t *__restrict__ ind = indices + base;
     const uint32_t *__restrict__ val = values + base;
 
-    uint32_t col[NACC];
+    uint32_t col[NACC], lcol[NACC];
     bool act[NACC];
     d2 acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) {
         col[a] = (a * 64u + lane) * 2u;
         act[a] = col[a] < l;
+        lcol[a] = act[a] ? col[a] : 0u;
         acc[a] = (d2){0.0, 0.0};
         if (!first && act[a]) acc[a] = *reinterpret_cast<const d2 *>(out + (size_t)row * ldo + col[a]);
     }
@@ -287,12 +285,10 @@ __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
                 const double fv = bcast<double>(f, j + u);
                 const double *__restrict__ xr = X + (size_t)g * ldx;
 #pragma unroll
-                for (int a = 0; a < NACC; a++) {
-                    if (act[a]) {
-                        const d2 x = *reinterpret_cast<const d2 *>(xr + col[a]);
-                        acc[a].x = fma(fv, x.x, acc[a].x);
-                        acc[a].y = fma(fv, x.y, acc[a].y);
-                    }
+                for (int a = 0; a < NACC; a++) { // no branch: idle lanes re-read column pair 0 and discard it
+                    const d2 x = *reinterpret_cast<const d2 *>(xr + lcol[a]);
+                    acc[a].x = fma(fv, x.x, acc[a].x);
+                    acc[a].y = fma(fv, x.y, acc[a].y);
                 }
             }
         }
@@ -301,12 +297,10 @@ __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
             const double fv = bcast<double>(f, j);
             const double *__restrict__ xr = X + (size_t)g * ldx;
 #pragma unroll
-            for (int a = 0; a < NACC; a++) {
-                if (act[a]) {
-                    const d2 x = *reinterpret_cast<const d2 *>(xr + col[a]);
-                    acc[a].x = fma(fv, x.x, acc[a].x);
-                    acc[a].y = fma(fv, x.y, acc[a].y);
-                }
+            for (int a = 0; a < NACC; a++) { // no branch: idle lanes re-read column pair 0 and discard it
+                const d2 x = *reinterpret_cast<const d2 *>(xr + lcol[a]);
+                acc[a].x = fma(fv, x.x, acc[a].x);
+                acc[a].y = fma(fv, x.y, acc[a].y);
             }
         }
     }
@@ -832,8 +826,8 @@ static inline dim3 grid1(uint64_t n, uint32_t block) { return dim3((unsigned)((n
 
 struct ProfScope {
     Storage &st;
-    ProfScope(Storage &s, const char *name, double bytes) : st(s) {
-        if (st.prof.on) st.prof.begin(st.stream, name, bytes);
+    ProfScope(Storage &s, const char *name, double bytes, double onchip = 0.0) : st(s) {
+        if (st.prof.on) st.prof.begin(st.stream, name, bytes, onchip);
     }
     ~ProfScope() {
         if (st.prof.on) st.prof.end(st.stream);
@@ -860,7 +854,7 @@ static void launch_spmm_t(Storage &st, const SparseCopy &cp, const DevMap &map, 
         {
             char pname[48];
             snprintf(pname, sizeof(pname), "spmm_gather_kernel<%s, %u>", sizeof(T) == 8 ? "double" : "unsigned int", nacc);
-            ProfScope ps(st, pname, bytes);
+            ProfScope ps(st, pname, bytes, (double)cp.nnz * sizeof(T) * lc);
 #define SCANRS_SPMM(NA)                                                                                              \
     hipLaunchKernelGGL((spmm_gather_kernel<T, NA>), grid, block, 0, st.stream, cp.indices.p, cp.values.p, cp.items.p, \
                        cp.n_items, map, X + c0, ldx, lc, out + c0, ldo, slab ? slab + c0 : nullptr, off_a, rank, offw, \
@@ -925,7 +919,8 @@ static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const
         for (uint32_t sidx = 0; sidx < steps; sidx++) {
             const uint32_t b0 = sidx * m, b1 = std::min(nb, b0 + m);
             ProfScope ps(st, cp.n_outer >= cp.n_inner ? (lw > 110 ? "spmm_gather2d_kernel<1>/long-outer/wide" : "spmm_gather2d_kernel<1>/long-outer")
-                                                      : "spmm_gather2d_kernel<1>/short-outer", bytes);
+                                                      : "spmm_gather2d_kernel<1>/short-outer", bytes,
+                        (double)cp.nnz * 8.0 * lw / steps);
             hipLaunchKernelGGL((spmm_gather2d_kernel<1>), grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p,
                                cp.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, sidx + 1 == steps ? 1 : 0, cp.n_outer, map, X + c0,
                                ldx, lw, out + c0, ldo, off_a, rank, offw, ldw);
