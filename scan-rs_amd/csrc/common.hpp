@@ -195,11 +195,6 @@ struct DevMap {
     DevOp ops[MAX_OPS];
 };
 
-struct Panel {
-    double *p = nullptr;
-    uint64_t rows = 0;
-    uint32_t l = 0, ld = 0;
-};
 inline uint32_t even_up(uint32_t x) { return (x + 1u) & ~1u; }
 
 } // namespace scanrs
@@ -279,9 +274,6 @@ bool sym_eig(const double *a, int n, double *w, double *z);
 bool sym_eig_topk(const double *a, int n, int k, double *w, double *z);
 
 // ---- solver.cpp ------------------------------------------------------------------------------------
-struct PcaOut {
-    double *u, *s, *v; // host buffers
-};
 int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
            const scanrs_snoop *snoop, double *u, double *s, double *v);
 int pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, uint64_t seed, const double *omega, double *u,

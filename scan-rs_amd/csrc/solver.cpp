@@ -375,7 +375,14 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
             for (uint32_t j = 0; j < q; j++) colmax[j] = std::max(colmax[j], std::fabs(cfull[(size_t)r * q + j]));
         for (uint32_t j = 0; j < q; j++)
             if (!(colmax[j] < cmax_limit)) bad.push_back(j);
-        if (trace_on()) fprintf(stderr, "[scanrs trace] bk: %zu of %u projection columns recomputed directly\n", bad.size(), q);
+        if (trace_on()) {
+            fprintf(stderr, "[scanrs trace] bk: %zu of %u projection columns recomputed directly\n", bad.size(), q);
+            for (double thr : {1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10}) {
+                int cnt = 0;
+                for (uint32_t j = 0; j < q; j++) cnt += !(colmax[j] < thr);
+                fprintf(stderr, "[scanrs trace] bk:   columns with max|C| >= %.0e: %d\n", thr, cnt);
+            }
+        }
     }
     {
         Tick tk("bk: projection");
@@ -480,13 +487,6 @@ int pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, ui
 }
 
 // ---- IRLBA (scan-rs/src/dim_red/irlba.rs:71-215), vectors on the device, small B on the host -----------------
-namespace {
-struct Vecs {
-    Ctx &c;
-    explicit Vecs(Ctx &cc) : c(cc) {}
-};
-} // namespace
-
 // y <- y - X (X^T y) for the first j columns of X (rows x ldx); irlba.rs:19-22
 static void orthog_dev(Ctx &c, double *y, const double *X, uint32_t ldx, uint32_t j, uint64_t rows, bool sharded) {
     if (j == 0) return;
