@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--cpu-cells", type=int, default=8000, help="cells of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie", action="store_true", help="also time one step that copies U and V to the host")
+    ap.add_argument("--f32-panels", action="store_true",
+                    help="opt-in fast mode: gathered panels rounded to f32, f64 sums (NOT the headline configuration)")
     ap.add_argument("--also-randsvd", action="store_true", help="also time one RandSvd{10, 2} PCA (SURVEY.md §8d: reported alongside)")
     ap.add_argument("--events-in-timed-region", action="store_true",
                     help="record the per-launch HIP events inside the K timed steps instead of in a second pass of K steps")
@@ -91,6 +93,8 @@ def main():
 
         mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev))
 
+    if args.f32_panels:
+        mat.set_panel_precision(1)
     bk = sa.BkSvd()  # k_multiplier 2.0, n_iter 5: the solver scan-rs-cmd uses (tools/src/bin/cmd.rs:70)
     s_out = np.zeros(args.k)
 
@@ -251,7 +255,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if not args.f32_panels else "f64 sums over f32-rounded gather panels (opt-in fast mode)",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.cells} cells x {args.genes} genes, {args.density:.0%} nnz synthetic sqz CSC, "

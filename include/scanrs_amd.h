@@ -216,6 +216,10 @@ int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uin
  * panels of 16+ columns, plain gather otherwise), 1 = plain gather, 2 = L2-blocked gather. Both are HIP kernels;
  * results agree to rounding. */
 int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
+/* Arithmetic of the large sparse products: 0 (default) = f64 throughout, the reference's arithmetic; 1 = opt-in fast
+ * mode: the dense panel is rounded to f32 before it is gathered (half the on-chip bytes per nonzero), products and
+ * sums stay f64. Singular values / loadings then agree with the f64 path to ~1e-7 relative, not to rounding. */
+int scanrs_mat_set_panel_precision(scanrs_mat *m, int precision);
 /* Block until all work queued on the handle's stream is done. */
 int scanrs_mat_sync(scanrs_mat *m);
 

@@ -419,6 +419,11 @@ class AdaptiveMat:
     def sync(self):
         _check(_lib.scanrs_mat_sync(self._h))
 
+    def set_panel_precision(self, precision: int):
+        """0 = f64 panels (default, the reference's arithmetic); 1 = f32 gather panels with f64 sums (opt-in fast mode)."""
+        _check(_lib.scanrs_mat_set_panel_precision(self._h, ctypes.c_int(precision)))
+        return self
+
     def set_spmm_path(self, path: int):
         """0 auto, 1 plain gather kernel, 2 L2-blocked gather kernel (see scanrs_mat_set_spmm_path)."""
         _check(_lib.scanrs_mat_set_spmm_path(self._h, ctypes.c_int(path)))
@@ -594,6 +599,6 @@ EXPORTED_SYMBOLS = [
     "scanrs_mat_dot", "scanrs_mat_rdot", "scanrs_mat_dot_u32", "scanrs_mat_rdot_u32", "scanrs_mat_dot_device",
     "scanrs_normalize", "scanrs_log_normalize", "scanrs_log1p_normalize_fixed_point", "scanrs_mat_target_umi",
     "scanrs_pca_bk", "scanrs_pca_rand", "scanrs_pca_irlba", "scanrs_omega_fill", "scanrs_mat_set_shard",
-    "scanrs_plan_shards", "scanrs_profile_enable", "scanrs_profile_reset", "scanrs_profile_get", "scanrs_mat_sync", "scanrs_mat_set_spmm_path",
+    "scanrs_plan_shards", "scanrs_profile_enable", "scanrs_profile_reset", "scanrs_profile_get", "scanrs_mat_sync", "scanrs_mat_set_spmm_path", "scanrs_mat_set_panel_precision",
     "scanrs_host_chol_upper", "scanrs_host_inv_upper", "scanrs_host_sym_eig", "scanrs_host_sym_eig_topk",
 ]

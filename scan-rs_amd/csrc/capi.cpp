@@ -965,6 +965,13 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path) {
         m->st->spmm_path = path;
     });
 }
+int scanrs_mat_set_panel_precision(scanrs_mat *m, int precision) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        if (precision != 0 && precision != 1) fail(SCANRS_ERR_ARGUMENT, "precision must be 0 (f64 panels) or 1 (f32 gather panels)");
+        m->st->panel_precision = precision;
+    });
+}
 int scanrs_mat_sync(scanrs_mat *m) {
     return guard([&] {
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");

@@ -162,6 +162,7 @@ struct Storage {
     Profile prof;
     ShardInfo shard; // sharding of primary's outer dimension
     int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 L2-blocked gather
+    int panel_precision = 0;              // 0: f64 panels (default); 1: gathered panels rounded to f32, f64 sums (opt-in)
     size_t l2_tile_bytes = 3u << 20;      // panel slice per step of the L2-blocked gather (4 MB L2 per XCD)
     uint64_t blocked_min_nnz = 1ull << 22; // auto: matrices below this stay on the plain gather kernel
     ~Storage();

@@ -319,6 +319,97 @@ __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
     }
 }
 
+// Opt-in "f32 gather panel" form of the L2-blocked product (scanrs_mat_set_panel_precision): the panel is
+// rounded to f32 once per product, every gathered row costs half the L2 -> CU bytes, and the sums stay in f64.
+// Two nonzeros share one load instruction: lanes 0-31 fetch the row of nonzero j, lanes 32-63 that of nonzero
+// j+1 (4 columns = 16 B per lane, 128 columns per half-wave); the two half-wave partial sums are added at the end.
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__global__ void f64_to_f32_panel_kernel(const double *__restrict__ src, uint32_t lds_, uint64_t rows, uint32_t l,
+                                        float *__restrict__ dst, uint32_t ldd) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * ldd) return;
+    const uint64_t r = e / ldd;
+    const uint32_t c = (uint32_t)(e % ldd);
+    dst[e] = c < l ? (float)src[r * lds_ + c] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void spmm_gather2d_f32_kernel(
+    const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices, const uint32_t *__restrict__ values,
+    const uint32_t *__restrict__ bounds, uint32_t nb, uint32_t b0, uint32_t b1, int first, int last, uint64_t n_outer,
+    DevMap map, const float *__restrict__ Xf, uint32_t ldf, uint32_t l, double *out, uint32_t ldo,
+    const double *__restrict__ off_a, uint32_t rank, const double *__restrict__ off_w, uint32_t ldw) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t row64 = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (row64 >= n_outer) return;
+    const uint32_t row = (uint32_t)row64;
+    const uint32_t *__restrict__ bd = bounds + row64 * (nb + 1);
+    const uint32_t o0 = rfl(bd[b0]), o1 = rfl(bd[b1]);
+    const uint32_t len = o1 - o0;
+    const bool epilogue = last && rank > 0;
+    if (len == 0 && !first && !epilogue) return;
+    const uint64_t base = indptr[row64] + o0;
+    const uint32_t *__restrict__ ind = indices + base;
+    const uint32_t *__restrict__ val = values + base;
+    const uint32_t half = lane >> 5, sub = lane & 31u;
+    const uint32_t col = sub * 4u;
+    const bool act = col < l;
+    const uint32_t lcol = act ? col : 0u;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    if (!first && act && half == 0) {
+        const double *o = out + (size_t)row * ldo + col;
+        acc0 = o[0];
+        if (col + 1 < l) acc1 = o[1];
+        if (col + 2 < l) acc2 = o[2];
+        if (col + 3 < l) acc3 = o[3];
+    }
+    for (uint32_t c = 0; c < len; c += 64u) {
+        const uint32_t p = c + lane;
+        uint32_t idx = 0;
+        double f = 0.0;
+        if (p < len) {
+            idx = ind[p];
+            f = eval_map(map, val[p], row, idx);
+        }
+        const uint32_t n = min(64u, len - c);
+        // lanes past the chunk hold idx 0 / f 0, so an odd tail simply adds 0 * row 0 in the upper half
+        for (uint32_t j = 0; j < n; j += 8u) {
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u += 2u) {
+                const int srcl = (int)(j + u + half);
+                const uint32_t g = (uint32_t)__shfl((int)idx, srcl, 64);
+                const double fv = __shfl(f, srcl, 64);
+                const f4 x = *reinterpret_cast<const f4 *>(Xf + (size_t)g * ldf + lcol);
+                acc0 = fma(fv, (double)x.x, acc0);
+                acc1 = fma(fv, (double)x.y, acc1);
+                acc2 = fma(fv, (double)x.z, acc2);
+                acc3 = fma(fv, (double)x.w, acc3);
+            }
+        }
+    }
+    acc0 += __shfl_down(acc0, 32, 64);
+    acc1 += __shfl_down(acc1, 32, 64);
+    acc2 += __shfl_down(acc2, 32, 64);
+    acc3 += __shfl_down(acc3, 32, 64);
+    if (half == 0 && act) {
+        if (epilogue) {
+            for (uint32_t q = 0; q < rank; q++) {
+                const double aq = off_a[(size_t)row * rank + q];
+                const double *w = off_w + (size_t)q * ldw + col;
+                acc0 += aq * w[0];
+                if (col + 1 < l) acc1 += aq * w[1];
+                if (col + 2 < l) acc2 += aq * w[2];
+                if (col + 3 < l) acc3 += aq * w[3];
+            }
+        }
+        double *o = out + (size_t)row * ldo + col;
+        o[0] = acc0;
+        if (col + 1 < l) o[1] = acc1;
+        if (col + 2 < l) o[2] = acc2;
+        if (col + 3 < l) o[3] = acc3;
+    }
+}
+
 // Ordered sum of the partial rows of outer vectors that were cut into several items.
 template <typename T, int NACC>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const MultiRow *__restrict__ multi, uint32_t n_multi,
@@ -929,11 +1020,50 @@ static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const
     SCANRS_HIP(hipGetLastError());
 }
 
+// L2-blocked gather over an f32 copy of the panel (opt-in, see spmm_gather2d_f32_kernel)
+static void launch_spmm_2d_f32(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
+                               double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w,
+                               uint32_t ldw) {
+    const uint32_t nb = ensure_bounds(st, cp);
+    const uint32_t n_chunks = (l + 127u) / 128u;
+    uint32_t lc = (l + n_chunks - 1u) / n_chunks;
+    lc = (lc + 3u) & ~3u;
+    const dim3 grid((unsigned)((cp.n_outer + 3) / 4)), block(256);
+    for (uint32_t c0 = 0; c0 < l; c0 += lc) {
+        const uint32_t lw = std::min(lc, l - c0);
+        const uint32_t ldf = (lw + 3u) & ~3u;
+        float *Xf = st.scratch.get<float>("spmm_xf32", (size_t)cp.n_inner * ldf);
+        {
+            ProfScope ps(st, "f64_to_f32_panel", (double)cp.n_inner * lw * 12.0);
+            hipLaunchKernelGGL(f64_to_f32_panel_kernel, grid1((uint64_t)cp.n_inner * ldf, 256), block, 0, st.stream, X + c0, ldx,
+                               cp.n_inner, lw, Xf, ldf);
+        }
+        uint32_t m = (uint32_t)(st.l2_tile_bytes / ((size_t)(1u << BT_SHIFT) * ldf * 4));
+        if (m < 1u) m = 1u;
+        const uint32_t steps = (nb + m - 1u) / m;
+        const double bytes = ((double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_inner * lw * 4.0 +
+                              (double)cp.n_outer * lw * 8.0) / steps;
+        const double *offw = off_w ? off_w + c0 : nullptr;
+        for (uint32_t sidx = 0; sidx < steps; sidx++) {
+            const uint32_t b0 = sidx * m, b1 = std::min(nb, b0 + m);
+            ProfScope ps(st, cp.n_outer >= cp.n_inner ? "spmm_gather2d_f32_kernel/long-outer" : "spmm_gather2d_f32_kernel/short-outer",
+                         bytes, (double)cp.nnz * 4.0 * lw / steps);
+            hipLaunchKernelGGL(spmm_gather2d_f32_kernel, grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p, cp.bounds.p,
+                               nb, b0, b1, sidx == 0 ? 1 : 0, sidx + 1 == steps ? 1 : 0, cp.n_outer, map, Xf, ldf, lw, out + c0, ldo,
+                               off_a, rank, offw, ldw);
+        }
+    }
+    SCANRS_HIP(hipGetLastError());
+}
+
 void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
                      double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw) {
     const bool want_2d = st.spmm_path == 2 || (st.spmm_path == 0 && cp.nnz >= st.blocked_min_nnz && l >= 16);
     if (want_2d && l > 0 && cp.n_outer > 0 && cp.n_inner > 0) {
-        launch_spmm_2d(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
+        if (st.panel_precision == 1)
+            launch_spmm_2d_f32(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
+        else
+            launch_spmm_2d(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
         return;
     }
     if (l <= 2 && l > 0 && cp.n_outer > 0) {

@@ -593,3 +593,32 @@ def test_empty_vectors_and_reset_map(sa):
         assert np.array_equal(g.to_dense(), dense.astype(np.float64))
         sa.normalize(g, sa.Normalization.SeuratLog)
         assert_close(g.to_dense(), so.normalize(pair(sa, dense, storage)[1], "seuratlog").to_dense(), rtol=1e-11, atol=1e-11)
+
+
+def test_f32_gather_panel_mode(sa):
+    # opt-in fast mode: panel rounded to f32 before the gather, f64 sums. Products agree to f32 rounding of the
+    # panel (6e-8 relative), the PCA to ~1e-6 — far inside the 1e-4 north-star tolerance, but not to rounding.
+    rng = np.random.default_rng(31)
+    dense = random_counts(rng, 300, 2500, 0.05, 30) + (rng.random((300, 2500)) < 0.002)
+    for storage in (so.CSR, so.CSC):
+        g, o = _norm_pair(sa, dense.astype(np.uint32), storage, "cellranger")
+        g.set_spmm_path(2).set_panel_precision(1)
+        for l in (17, 100, 128, 131):
+            q = rng.standard_normal((2500, l))
+            ref = o.dot(q)
+            assert np.max(np.abs(g.dot(q) - ref)) <= 3e-7 * np.max(np.abs(ref))
+            ql = rng.standard_normal((l, 300))
+            ref = o.rdot(ql)
+            assert np.max(np.abs(g.rdot(ql) - ref)) <= 3e-7 * np.max(np.abs(ref))
+    m = _synth(2500, 600, 0.06, 1)
+    k = 10
+    g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+    g.set_spmm_path(2).set_panel_precision(1)
+    o = so.AdaptiveMat(m.shape[1], m.shape[0], so.CSC, m.indptr, m.indices, m.data)
+    g, o = sa.normalize(g, sa.Normalization.CellRanger), so.normalize(o, "cellranger")
+    omega = so.omega_panel((2 * k, m.shape[1]), 0)
+    u, s, v = sa.BkSvd().run_pca(g, k, omega=omega)
+    uo, s_o, vo = so.BkSvd().run_pca(o, k, omega=omega)
+    assert np.max(np.abs(s - s_o) / s_o) < 1e-5
+    assert np.max(np.abs(_sign_fix(u, uo) - uo)) < 1e-4
+    assert np.max(np.abs(_sign_fix(v, vo) - vo)) < 1e-4
