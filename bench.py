@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--pcie", action="store_true", help="also time one step that copies U and V to the host")
     ap.add_argument("--f32-panels", action="store_true",
                     help="opt-in fast mode: gathered panels rounded to f32, f64 sums (NOT the headline configuration)")
+    ap.add_argument("--spmm-path", type=int, default=0, help="0 auto, 1 plain gather, 2 L2-blocked gather, 3 LDS-tiled (experimental)")
     ap.add_argument("--also-randsvd", action="store_true", help="also time one RandSvd{10, 2} PCA (SURVEY.md §8d: reported alongside)")
     ap.add_argument("--events-in-timed-region", action="store_true",
                     help="record the per-launch HIP events inside the K timed steps instead of in a second pass of K steps")
@@ -95,6 +96,8 @@ def main():
 
     if args.f32_panels:
         mat.set_panel_precision(1)
+    if args.spmm_path:
+        mat.set_spmm_path(args.spmm_path)
     bk = sa.BkSvd()  # k_multiplier 2.0, n_iter 5: the solver scan-rs-cmd uses (tools/src/bin/cmd.rs:70)
     s_out = np.zeros(args.k)
 
