@@ -26,6 +26,12 @@ void fail(int code, const char *fmt, ...) {
     throw Failure{code};
 }
 
+bool trace_on() {
+    static int v = -1;
+    if (v < 0) v = getenv("SCANRS_TRACE") ? 1 : 0;
+    return v == 1;
+}
+
 template <typename F>
 static int guard(F &&f) {
     try {
@@ -111,6 +117,7 @@ Profile::~Profile() {
 
 // ---- Storage -------------------------------------------------------------------------------------
 Storage::~Storage() {
+    if (host_stage) (void)hipHostFree(host_stage);
     if (stream) {
         (void)hipStreamSynchronize(stream);
         (void)hipStreamDestroy(stream);
@@ -303,6 +310,7 @@ static bool median_u32(Storage &st, const uint32_t *d, uint64_t n_local, uint64_
 
 static void log_normalize_impl(scanrs_mat *m, double umi_count_sum, int log_fn, const uint32_t *size_factors) {
     // log_normalize_with_size_factor, scan-rs/src/normalization.rs:138-178
+    Tick tk("normalize: log_normalize");
     if (!map_is_raw(m) || m->off_rank) fail(SCANRS_ERR_ARGUMENT, "log_normalize needs the raw count matrix (AdaptiveMat<u32>)");
     if (log_fn != OP_LN_1P && log_fn != OP_LOG2_1P && log_fn != OP_LOG10_1P) fail(SCANRS_ERR_ARGUMENT, "bad log base");
     if (rows_sharded(m)) fail(SCANRS_ERR_ARGUMENT, "normalisation needs the barcode (column) dimension to be the sharded one");
@@ -372,6 +380,7 @@ static void set_offset_dev(scanrs_mat *m, uint32_t rank, std::shared_ptr<DevBuf<
 
 static void scale_and_center_impl(scanrs_mat *m, int axis, const double *given_scaling) {
     // sqz/src/mat.rs:986-1001
+    Tick tk("normalize: scale_and_center");
     if (axis != 0 && axis != 1) fail(SCANRS_ERR_ARGUMENT, "axis must be 0 or 1");
     if (m->off_rank) fail(SCANRS_ERR_ARGUMENT, "matrix already carries a low-rank offset");
     Storage &st = *m->st;

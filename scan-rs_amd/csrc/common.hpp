@@ -1,5 +1,6 @@
 // Shared declarations of the scanrs_amd library (host side). gfx950 only.
 #pragma once
+#include <chrono>
 #include <cstring>
 #include <cstdio>
 #include <cstdint>
@@ -30,6 +31,19 @@ void set_error(const char *fmt, ...);
             ::scanrs::fail(SCANRS_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
                            __FILE__, __LINE__);                                                       \
     } while (0)
+
+// SCANRS_TRACE=1: wall-clock of host-side phases on stderr (diagnostics only)
+bool trace_on();
+struct Tick {
+    const char *what;
+    std::chrono::steady_clock::time_point t0;
+    explicit Tick(const char *w) : what(w), t0(std::chrono::steady_clock::now()) {}
+    ~Tick() {
+        if (trace_on())
+            fprintf(stderr, "[scanrs trace] %-28s %8.3f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
 
 // ---- device memory ------------------------------------------------------------------
 template <typename T>
@@ -159,6 +173,23 @@ struct Storage {
     bool has_other = false;
     hipStream_t stream = nullptr;
     Scratch scratch;
+    // GF(2) jump tables of the device-side seeded-panel generator (solver.cpp / omega_jump_kernel)
+    DevBuf<uint64_t> jump_tab;
+    uint64_t jump_d = 0;
+    int jump_npow = 0;
+    // grow-only pinned host staging buffer (seeded start panels): no page faults, DMA-speed uploads
+    void *host_stage = nullptr;
+    size_t host_stage_bytes = 0;
+    void *pinned(size_t bytes) {
+        if (bytes > host_stage_bytes) {
+            if (host_stage) (void)hipHostFree(host_stage);
+            host_stage = nullptr;
+            host_stage_bytes = 0;
+            SCANRS_HIP(hipHostMalloc(&host_stage, bytes, hipHostMallocDefault));
+            host_stage_bytes = bytes;
+        }
+        return host_stage;
+    }
     Profile prof;
     ShardInfo shard; // sharding of primary's outer dimension
     int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 L2-blocked gather
@@ -246,6 +277,9 @@ void launch_gemm_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, c
                        uint64_t rows, double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo);
 void launch_copy_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows, uint32_t l);
 void launch_fill_f64(Storage &st, double *p, uint64_t n, double v);
+void launch_omega_jump(Storage &st, const uint64_t *d_jpow, int n_pow, const uint64_t s[4], uint64_t d, uint64_t total, double *out,
+                       uint32_t ld, uint64_t seq_cols, bool transpose);
+void launch_transpose(Storage &st, const double *src, uint64_t rows, uint64_t cols, double *dst, uint32_t ldd);
 void launch_permute_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows,
                          const uint32_t *d_idx, uint32_t n_idx, bool scatter);
 void launch_finish_moments(Storage &st, const double *sum, const double *sumsq, uint64_t n, double m, int given_scale,

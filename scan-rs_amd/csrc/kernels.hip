@@ -765,6 +765,66 @@ __global__ void permute_cols_kernel(const double *__restrict__ src, uint32_t lds
     else
         dst[r * ldd + j] = src[r * lds + idx[j]];
 }
+// Seeded start panel generated on the device. The reference draws the panel from ONE sequential stream
+// (SmallRng = xoshiro256++, scan-rs/src/dim_red/bk_svd.rs:83-90); the state transition of xoshiro is linear over
+// GF(2), so the state after s*d draws is J^s * state0 with J = T^d. The host supplies J^(2^k) (solver.cpp); stream s
+// rebuilds its start state from the binary digits of s and then draws its d values sequentially. The values and
+// their order are identical to the sequential stream.
+__device__ __forceinline__ uint64_t xo_rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+__global__ __launch_bounds__(256) void omega_jump_kernel(const uint64_t *__restrict__ jpow, int n_pow, uint64_t s0, uint64_t s1,
+                                                         uint64_t s2, uint64_t s3, uint64_t d, uint64_t total, double *__restrict__ out,
+                                                         uint32_t ld, uint64_t seq_cols, int transpose) {
+    const uint64_t sid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t e0 = sid * d;
+    if (e0 >= total) return;
+    uint64_t st[4] = {s0, s1, s2, s3};
+    for (int k = 0; k < n_pow; k++) {
+        if (!((sid >> k) & 1ull)) continue;
+        const uint64_t *__restrict__ m = jpow + (size_t)k * 256 * 4;
+        uint64_t nx[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 256; i++) {
+            const uint64_t *r = m + i * 4;
+            const uint64_t x = (r[0] & st[0]) ^ (r[1] & st[1]) ^ (r[2] & st[2]) ^ (r[3] & st[3]);
+            nx[i >> 6] |= (uint64_t)(__popcll(x) & 1) << (i & 63);
+        }
+        st[0] = nx[0];
+        st[1] = nx[1];
+        st[2] = nx[2];
+        st[3] = nx[3];
+    }
+    const uint64_t e1 = min(total, e0 + d);
+    for (uint64_t e = e0; e < e1; e++) {
+        const uint64_t result = xo_rotl(st[0] + st[3], 23) + st[0];
+        const uint64_t t = st[1] << 17;
+        st[2] ^= st[0];
+        st[3] ^= st[1];
+        st[1] ^= st[2];
+        st[0] ^= st[3];
+        st[2] ^= t;
+        st[3] = xo_rotl(st[3], 45);
+        const double v12 = __longlong_as_double((long long)((result >> 12) | 0x3FF0000000000000ull));
+        const double v = (v12 - 1.0) * 2.0 + (-1.0);
+        // sequential order is row-major over (seq_rows x seq_cols); the device panel is that matrix or its transpose
+        const uint64_t i = e / seq_cols, j = e % seq_cols;
+        if (transpose)
+            out[j * ld + i] = v;
+        else
+            out[i * ld + j] = v;
+    }
+}
+
+// dst[j, i] = src[i, j] for src (rows x cols, compact) -> dst (cols x rows, leading dimension ldd); LDS tile transpose
+__global__ __launch_bounds__(256) void transpose_kernel(const double *__restrict__ src, uint64_t rows, uint64_t cols,
+                                                        double *__restrict__ dst, uint32_t ldd) {
+    __shared__ double tile[32][33];
+    const uint64_t c0 = (uint64_t)blockIdx.x * 32u, r0 = (uint64_t)blockIdx.y * 32u;
+    const uint32_t tx = threadIdx.x & 31u, ty = threadIdx.x >> 5; // 32 x 8
+    for (uint32_t k = ty; k < 32u; k += 8u)
+        if (r0 + k < rows && c0 + tx < cols) tile[k][tx] = src[(r0 + k) * cols + c0 + tx];
+    __syncthreads();
+    for (uint32_t k = ty; k < 32u; k += 8u)
+        if (c0 + k < cols && r0 + tx < rows) dst[(c0 + k) * ldd + r0 + tx] = tile[tx][k];
+}
 __global__ void fill_kernel(double *p, uint64_t n, double v) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n) p[e] = v;
@@ -1234,6 +1294,19 @@ void launch_permute_cols(Storage &st, const double *src, uint32_t lds, double *d
     if (rows == 0 || n_idx == 0) return;
     hipLaunchKernelGGL(permute_cols_kernel, grid1(rows * n_idx, 256), dim3(256), 0, st.stream, src, lds, dst, ldd, rows, d_idx,
                        n_idx, scatter ? 1 : 0);
+    SCANRS_HIP(hipGetLastError());
+}
+void launch_omega_jump(Storage &st, const uint64_t *d_jpow, int n_pow, const uint64_t s[4], uint64_t d, uint64_t total, double *out,
+                       uint32_t ld, uint64_t seq_cols, bool transpose) {
+    const uint64_t streams = (total + d - 1) / d;
+    hipLaunchKernelGGL(omega_jump_kernel, grid1(streams, 256), dim3(256), 0, st.stream, d_jpow, n_pow, s[0], s[1], s[2], s[3], d, total,
+                       out, ld, seq_cols, transpose ? 1 : 0);
+    SCANRS_HIP(hipGetLastError());
+}
+void launch_transpose(Storage &st, const double *src, uint64_t rows, uint64_t cols, double *dst, uint32_t ldd) {
+    if (rows == 0 || cols == 0) return;
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32)), dim3(256), 0, st.stream, src,
+                       rows, cols, dst, ldd);
     SCANRS_HIP(hipGetLastError());
 }
 void launch_fill_f64(Storage &st, double *p, uint64_t n, double v) {

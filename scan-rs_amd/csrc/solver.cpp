@@ -10,31 +10,14 @@
 // Rayleigh-Ritz values, see DESIGN.md — and `svddc_into` of the 5b x n projection becomes an
 // eigendecomposition of its 5b x 5b Gram matrix (only the top k triplets are returned by the reference).
 #include <algorithm>
-#include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "common.hpp"
 
 namespace scanrs {
-
-// SCANRS_TRACE=1: wall-clock of the solver phases on stderr (diagnostics only)
-static bool trace_on() {
-    static int v = -1;
-    if (v < 0) v = getenv("SCANRS_TRACE") ? 1 : 0;
-    return v == 1;
-}
-struct Tick {
-    const char *what;
-    std::chrono::steady_clock::time_point t0;
-    explicit Tick(const char *w) : what(w), t0(std::chrono::steady_clock::now()) {}
-    ~Tick() {
-        if (trace_on())
-            fprintf(stderr, "[scanrs trace] %-28s %8.3f ms\n", what,
-                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    }
-};
 
 // ---- rand-family generator for the seeded start panel ("parity unpinned") -----
 struct SmallRng {
@@ -76,6 +59,100 @@ struct SmallRng {
         return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
     }
 };
+
+// ---- GF(2) jump tables for the device-side panel generator (kernels.hip, omega_jump_kernel) ---------------------
+namespace {
+struct BitMat { // 256 x 256 over GF(2); row i = mask of the input bits that feed output bit i
+    uint64_t r[256][4];
+};
+void bm_mul(const BitMat &a, const BitMat &b, BitMat &c) { // c = a after b
+    for (int i = 0; i < 256; i++) {
+        uint64_t acc[4] = {0, 0, 0, 0};
+        for (int w = 0; w < 4; w++) {
+            uint64_t bits = a.r[i][w];
+            while (bits) {
+                const int k = __builtin_ctzll(bits) + 64 * w;
+                bits &= bits - 1;
+                acc[0] ^= b.r[k][0];
+                acc[1] ^= b.r[k][1];
+                acc[2] ^= b.r[k][2];
+                acc[3] ^= b.r[k][3];
+            }
+        }
+        for (int w = 0; w < 4; w++) c.r[i][w] = acc[w];
+    }
+}
+void bm_identity(BitMat &m) {
+    memset(&m, 0, sizeof(m));
+    for (int i = 0; i < 256; i++) m.r[i][i >> 6] = 1ull << (i & 63);
+}
+void xoshiro_step_matrix(BitMat &t) { // one state transition of xoshiro256++ (the output scrambler is not part of it)
+    memset(&t, 0, sizeof(t));
+    for (int j = 0; j < 256; j++) {
+        uint64_t s[4] = {0, 0, 0, 0};
+        s[j >> 6] = 1ull << (j & 63);
+        const uint64_t tt = s[1] << 17;
+        s[2] ^= s[0];
+        s[3] ^= s[1];
+        s[1] ^= s[2];
+        s[0] ^= s[3];
+        s[2] ^= tt;
+        s[3] = (s[3] << 45) | (s[3] >> 19);
+        for (int i = 0; i < 256; i++)
+            if ((s[i >> 6] >> (i & 63)) & 1ull) t.r[i][j >> 6] |= 1ull << (j & 63);
+    }
+}
+} // namespace
+
+// J^(2^k), k = 0..n_pow-1 with J = T^d, flattened [k][256][4]
+static std::vector<uint64_t> jump_powers(uint64_t d, int n_pow) {
+    auto t = std::make_unique<BitMat>(), acc = std::make_unique<BitMat>(), tmp = std::make_unique<BitMat>(),
+         sq = std::make_unique<BitMat>();
+    xoshiro_step_matrix(*t);
+    bm_identity(*acc);
+    *sq = *t;
+    for (uint64_t e = d; e; e >>= 1) { // acc = T^d
+        if (e & 1) {
+            bm_mul(*sq, *acc, *tmp);
+            *acc = *tmp;
+        }
+        if (e >> 1) {
+            bm_mul(*sq, *sq, *tmp);
+            *sq = *tmp;
+        }
+    }
+    std::vector<uint64_t> out((size_t)n_pow * 256 * 4);
+    for (int k = 0; k < n_pow; k++) {
+        memcpy(out.data() + (size_t)k * 1024, acc->r, sizeof(acc->r));
+        if (k + 1 < n_pow) {
+            bm_mul(*acc, *acc, *tmp);
+            *acc = *tmp;
+        }
+    }
+    return out;
+}
+
+// Fill a device panel with the seeded Uniform(-1, 1) stream: `out` holds the (seq_rows x seq_cols) row-major
+// sequence, or its transpose, with leading dimension ld.
+static void omega_fill_device(Storage &st, uint64_t seed, uint64_t seq_rows, uint64_t seq_cols, double *out, uint32_t ld,
+                              bool transpose) {
+    const uint64_t total = seq_rows * seq_cols;
+    if (total == 0) return;
+    const uint64_t d = 512; // draws per device stream
+    const uint64_t streams = (total + d - 1) / d;
+    int n_pow = 1;
+    while ((1ull << n_pow) < streams) n_pow++;
+    if (st.jump_d != d || st.jump_npow < n_pow) { // tables depend only on (d, n_pow): built once per handle
+        const std::vector<uint64_t> tab = jump_powers(d, n_pow);
+        st.jump_tab.alloc(tab.size());
+        SCANRS_HIP(hipMemcpyAsync(st.jump_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st.stream));
+        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        st.jump_d = d;
+        st.jump_npow = n_pow;
+    }
+    SmallRng rng(seed);
+    launch_omega_jump(st, st.jump_tab.p, n_pow, rng.s, d, total, out, ld, seq_cols, transpose);
+}
 
 void omega_fill(uint64_t seed, uint64_t count, double *out) {
     SmallRng rng(seed);
@@ -273,6 +350,7 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
 
 int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
            const scanrs_snoop *snoop, double *u, double *s, double *v) {
+    Tick tk_all("bk: total");
     Ctx c(m);
     const uint64_t M = m->rows(), N = m->cols();
     // global extents decide the branch and the validation, as the reference sees the whole matrix
@@ -304,22 +382,20 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
     SCANRS_HIP(hipMemsetAsync(K, 0, (size_t)ds * ldq * 8, c.s));
 
     { // start panel: m >= n -> (n x b) as is; n > m -> reference holds (b x m), we hold its transpose
-        std::vector<double> h((size_t)ds * b);
-        if (rows_ge) {
-            if (omega)
-                memcpy(h.data(), omega, h.size() * 8);
+        Tick tk("bk: start panel");
+        if (!omega) {
+            // reference order: (n x b) row-major when m >= n, else (b x m) row-major held transposed here
+            if (rows_ge)
+                omega_fill_device(c.st, seed, ds, b, P, ldb, false);
             else
-                omega_fill(seed, h.size(), h.data());
-        } else {
-            std::vector<double> t((size_t)b * ds);
-            if (omega)
-                memcpy(t.data(), omega, t.size() * 8);
-            else
-                omega_fill(seed, t.size(), t.data());
-            for (uint32_t i = 0; i < b; i++)
-                for (uint64_t j = 0; j < ds; j++) h[j * b + i] = t[(size_t)i * ds + j];
+                omega_fill_device(c.st, seed, b, ds, P, ldb, true);
+        } else if (rows_ge) {
+            upload_panel(c, omega, ds, b, P, ldb);
+        } else { // (b x ds) row-major on the host side: transposed on the device
+            double *tmp = c.dev("bk_omega_t", (size_t)b * ds);
+            c.h2d(tmp, omega, (size_t)b * ds);
+            launch_transpose(c.st, tmp, b, ds, P, ldb);
         }
-        upload_panel(c, h.data(), ds, b, P, ldb);
     }
 
     // The projection T = Q^T A (bk_svd.rs:104,131) is not recomputed as one q-wide sparse product: with
@@ -450,22 +526,18 @@ int pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, ui
     SCANRS_HIP(hipMemsetAsync(Om, 0, (size_t)d_om * ldl * 8, c.s));
     {
         if (om_sharded && !omega) fail(SCANRS_ERR_ARGUMENT, "a sharded start panel must be passed explicitly");
-        std::vector<double> h((size_t)d_om * l);
-        if (rows_ge) {
-            if (omega)
-                memcpy(h.data(), omega, h.size() * 8);
+        if (!omega) {
+            if (rows_ge)
+                omega_fill_device(c.st, seed, d_om, l, Om, ldl, false);
             else
-                omega_fill(seed, h.size(), h.data());
+                omega_fill_device(c.st, seed, l, d_om, Om, ldl, true);
+        } else if (rows_ge) {
+            upload_panel(c, omega, d_om, l, Om, ldl);
         } else {
-            std::vector<double> t((size_t)l * d_om);
-            if (omega)
-                memcpy(t.data(), omega, t.size() * 8);
-            else
-                omega_fill(seed, t.size(), t.data());
-            for (uint32_t i = 0; i < l; i++)
-                for (uint64_t j = 0; j < d_om; j++) h[j * l + i] = t[(size_t)i * d_om + j];
+            double *tmp2 = c.dev("rs_omega_t", (size_t)l * d_om);
+            c.h2d(tmp2, omega, (size_t)l * d_om);
+            launch_transpose(c.st, tmp2, l, d_om, Om, ldl);
         }
-        upload_panel(c, h.data(), d_om, l, Om, ldl);
     }
     // Q = qr(A Omega).Q   (rand_svd.rs:87 / :109)
     mat_apply(m, om_to_q_transpose, Om, ldl, l, Qp, ldl);

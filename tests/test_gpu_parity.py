@@ -622,3 +622,29 @@ def test_f32_gather_panel_mode(sa):
     assert np.max(np.abs(s - s_o) / s_o) < 1e-5
     assert np.max(np.abs(_sign_fix(u, uo) - uo)) < 1e-4
     assert np.max(np.abs(_sign_fix(v, vo) - vo)) < 1e-4
+
+
+def test_default_seed_panel_is_the_sequential_stream(sa):
+    # the library draws the seeded start panel on the device through GF(2) jump tables; the values and their order
+    # must be those of the sequential stream (scanrs_omega_fill / the oracle's SmallRng), for both panel layouts
+    m = _synth(700, 330, 0.08, 8)
+    for transposed, k in ((False, 9), (True, 4)):
+        g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+        g = sa.normalize(g, sa.Normalization.CellRanger)
+        if transposed:
+            g = g.t()
+        r, c = g.shape()
+        b = 2 * k
+        shape = (c, b) if r >= c else (b, r)
+        explicit = sa.omega_fill(5, shape[0] * shape[1]).reshape(shape)
+        a = sa.BkSvd().run_pca(g, k, seed=5)
+        e = sa.BkSvd().run_pca(g, k, omega=explicit)
+        for x, y in zip(a, e):
+            assert np.array_equal(x, y)
+        l = max(k + 4, 10 * k)
+        shape = (c, l) if r >= c else (l, r)
+        explicit = sa.omega_fill(5, shape[0] * shape[1]).reshape(shape)
+        a = sa.RandSvd().run_pca(g, k, seed=5)
+        e = sa.RandSvd().run_pca(g, k, omega=explicit)
+        for x, y in zip(a, e):
+            assert np.array_equal(x, y)
