@@ -27,6 +27,8 @@ def main():
                 key = "gram_tiled_kernel"
             elif "gemm_tiled_kernel" in n:
                 key = "gemm_tiled_kernel"
+            elif "row_reduce2d_kernel<2>" in n:
+                key = "row_reduce2d_kernel<2>"
             elif "row_reduce_kernel<2>" in n:
                 key = "row_reduce_kernel<2>"
             elif "row_reduce_kernel<0>" in n:
