@@ -41,6 +41,8 @@ def parse():
                     help="opt-in fast mode: gathered panels rounded to f32, f64 sums (NOT the headline configuration)")
     ap.add_argument("--spmm-path", type=int, default=0, help="0 auto, 1 plain gather, 2 L2-blocked gather, 3 LDS-tiled (experimental)")
     ap.add_argument("--also-randsvd", action="store_true", help="also time one RandSvd{10, 2} PCA (SURVEY.md §8d: reported alongside)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N=1 only: serve the exchange steps through RCCL (world 1) anyway, to price the hook itself")
     ap.add_argument("--events-in-timed-region", action="store_true",
                     help="record the per-launch HIP events inside the K timed steps instead of in a second pass of K steps")
     return ap.parse_args()
@@ -60,10 +62,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_collective:
         import torch.distributed as dist_mod
 
         dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import scanrs_amd as sa
@@ -89,7 +93,7 @@ def main():
     del indptr, indices, values
     torch.cuda.empty_cache()
 
-    if world > 1:
+    if dist is not None:
         from scanrs_amd.dist import make_allreduce
 
         mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev))

@@ -153,6 +153,10 @@ struct SparseCopy {
     DevBuf<MultiRow> multi;
     uint32_t n_items = 0, n_multi = 0, n_slab = 0;
     DevBuf<uint32_t> bounds; // L2-blocked gather: offset of the first nonzero >= b*1024 within each outer vector
+    // L2-blocked gather, launch order: outer vectors by descending length (longest first) and the sorted lengths
+    // on the host (how many vectors are "hot" for a given step count is a binary search)
+    DevBuf<uint32_t> order;
+    std::vector<uint32_t> sorted_len;
     void build_items(hipStream_t s);
 };
 
@@ -161,7 +165,8 @@ struct ShardInfo {
     uint64_t outer_begin = 0, outer_global = 0;
     scanrs_allreduce_fn allreduce = nullptr;
     void *ctx = nullptr;
-    bool active() const { return world > 1; }
+    // a callback given at world == 1 is still served (single-rank RCCL runs exercise the exchange steps)
+    bool active() const { return world > 1 || allreduce != nullptr; }
 };
 
 // Storage shared by a handle and its views (AdaptiveMat::view / t share `&[AdaptiveVec]`).
@@ -195,6 +200,8 @@ struct Storage {
     int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 L2-blocked gather
     int panel_precision = 0;              // 0: f64 panels (default); 1: gathered panels rounded to f32, f64 sums (opt-in)
     size_t l2_tile_bytes = 3u << 20;      // panel slice per step of the L2-blocked gather (4 MB L2 per XCD)
+    int spmm_order = 1;                   // L2-blocked gather: launch outer vectors longest first: 0 never, 1 auto, 2 always (SCANRS_SPMM_ORDER)
+    uint32_t hot_segment = 512;           // ... and give a workgroup to vectors with >= this many nonzeros per step (0 = never)
     uint64_t blocked_min_nnz = 1ull << 22; // auto: matrices below this stay on the plain gather kernel
     ~Storage();
     // the copy whose outer dimension is the base matrix's rows (true) or cols (false)

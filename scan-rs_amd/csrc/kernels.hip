@@ -238,21 +238,38 @@ __global__ void build_bounds_kernel(const uint64_t *__restrict__ indptr, const u
     bounds[e] = (uint32_t)(lo - s);
 }
 
+// `order` (optional) lists the outer vectors longest first: the launch then starts its longest waves at t = 0
+// instead of wherever the storage order puts them. The first `n_hot` vectors of that list (segments of >= ~512
+// nonzeros per step: popular genes on the gene-major copy) get a whole workgroup: its 4 waves take a quarter of the
+// segment each, partial sums meet in LDS and wave 0 adds them in wave order (deterministic) — otherwise one such
+// wave is the critical path of the whole step.
 template <int NACC>
 __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
     const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices, const uint32_t *__restrict__ values,
     const uint32_t *__restrict__ bounds, uint32_t nb, uint32_t b0, uint32_t b1, int first, int last, uint64_t n_outer,
-    DevMap map, const double *__restrict__ X, uint32_t ldx, uint32_t l, double *out, uint32_t ldo,
-    const double *__restrict__ off_a, uint32_t rank, const double *__restrict__ off_w, uint32_t ldw) {
+    const uint32_t *__restrict__ order, uint32_t n_hot, DevMap map, const double *__restrict__ X, uint32_t ldx, uint32_t l,
+    double *out, uint32_t ldo, const double *__restrict__ off_a, uint32_t rank, const double *__restrict__ off_w, uint32_t ldw) {
+    __shared__ d2 part[3][NACC][64];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t row64 = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (row64 >= n_outer) return;
+    const uint32_t wave = threadIdx.x >> 6;
+    const bool hot = blockIdx.x < n_hot; // block-uniform
+    const uint64_t slot = hot ? (uint64_t)blockIdx.x : (uint64_t)n_hot + ((uint64_t)blockIdx.x - n_hot) * 4u + wave;
+    if (slot >= n_outer) return; // never taken by a hot block
+    const uint64_t row64 = order ? (uint64_t)order[slot] : slot;
     const uint32_t row = (uint32_t)row64;
     const uint32_t *__restrict__ bd = bounds + row64 * (nb + 1);
-    const uint32_t o0 = rfl(bd[b0]), o1 = rfl(bd[b1]);
-    const uint32_t len = o1 - o0;
+    uint32_t o0 = rfl(bd[b0]), o1 = rfl(bd[b1]);
     const bool epilogue = last && rank > 0;
-    if (len == 0 && !first && !epilogue) return;
+    if (!hot && o1 == o0 && !first && !epilogue) return;
+    const bool owner = !hot || wave == 0; // holds the carried sums, applies the epilogue, writes the result
+    if (hot) {
+        uint32_t q = (o1 - o0 + 3u) / 4u;
+        q = (q + 7u) & ~7u;
+        const uint32_t s0 = min(o1, o0 + wave * q);
+        o1 = min(o1, s0 + q);
+        o0 = s0;
+    }
+    const uint32_t len = o1 - o0;
     const uint64_t base = indptr[row64] + o0;
     const uint32_t *__restrict__ ind = indices + base;
     const uint32_t *__restrict__ val = values + base;
@@ -266,7 +283,7 @@ __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
         act[a] = col[a] < l;
         lcol[a] = act[a] ? col[a] : 0u;
         acc[a] = (d2){0.0, 0.0};
-        if (!first && act[a]) acc[a] = *reinterpret_cast<const d2 *>(out + (size_t)row * ldo + col[a]);
+        if (!first && owner && act[a]) acc[a] = *reinterpret_cast<const d2 *>(out + (size_t)row * ldo + col[a]);
     }
     for (uint32_t c = 0; c < len; c += 64u) {
         const uint32_t p = c + lane;
@@ -277,30 +294,51 @@ __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
             f = eval_map(map, val[p], row, idx);
         }
         const uint32_t n = min(64u, len - c);
-        uint32_t j = 0;
-        for (; j + 8u <= n; j += 8u) {
+        // Lanes that own no column sit out the whole gather loop (one exec mask around it, v_readlane still sees
+        // their idx / f). Inside, nothing branches per load: with a per-load `if` hipcc puts s_waitcnt vmcnt(0)
+        // after every gather and the wave runs latency-bound.
+        if (act[0]) {
+            uint32_t j = 0;
+            for (; j + 8u <= n; j += 8u) {
 #pragma unroll
-            for (uint32_t u = 0; u < 8u; u++) {
-                const uint32_t g = rdlane(idx, j + u);
-                const double fv = bcast<double>(f, j + u);
+                for (uint32_t u = 0; u < 8u; u++) {
+                    const uint32_t g = rdlane(idx, j + u);
+                    const double fv = bcast<double>(f, j + u);
+                    const double *__restrict__ xr = X + (size_t)g * ldx;
+#pragma unroll
+                    for (int a = 0; a < NACC; a++) { // no branch: lanes idle in slot a re-read column pair 0 and discard it
+                        const d2 x = *reinterpret_cast<const d2 *>(xr + lcol[a]);
+                        acc[a].x = fma(fv, x.x, acc[a].x);
+                        acc[a].y = fma(fv, x.y, acc[a].y);
+                    }
+                }
+            }
+            for (; j < n; j++) {
+                const uint32_t g = rdlane(idx, j);
+                const double fv = bcast<double>(f, j);
                 const double *__restrict__ xr = X + (size_t)g * ldx;
 #pragma unroll
-                for (int a = 0; a < NACC; a++) { // no branch: idle lanes re-read column pair 0 and discard it
+                for (int a = 0; a < NACC; a++) {
                     const d2 x = *reinterpret_cast<const d2 *>(xr + lcol[a]);
                     acc[a].x = fma(fv, x.x, acc[a].x);
                     acc[a].y = fma(fv, x.y, acc[a].y);
                 }
             }
         }
-        for (; j < n; j++) {
-            const uint32_t g = rdlane(idx, j);
-            const double fv = bcast<double>(f, j);
-            const double *__restrict__ xr = X + (size_t)g * ldx;
+    }
+    if (hot) { // block-uniform: all four waves of a hot block reach the barrier
+        if (wave > 0) {
 #pragma unroll
-            for (int a = 0; a < NACC; a++) { // no branch: idle lanes re-read column pair 0 and discard it
-                const d2 x = *reinterpret_cast<const d2 *>(xr + lcol[a]);
-                acc[a].x = fma(fv, x.x, acc[a].x);
-                acc[a].y = fma(fv, x.y, acc[a].y);
+            for (int a = 0; a < NACC; a++) part[wave - 1][a][lane] = acc[a];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int a = 0; a < NACC; a++) {
+            for (int w = 0; w < 3; w++) {
+                const d2 t = part[w][a][lane];
+                acc[a].x += t.x;
+                acc[a].y += t.y;
             }
         }
     }
@@ -1048,6 +1086,49 @@ static uint32_t ensure_bounds(Storage &st, SparseCopy &cp) {
     return nb;
 }
 
+__global__ void outer_len_kernel(const uint64_t *__restrict__ indptr, uint64_t n_outer, uint32_t *__restrict__ keys,
+                                 uint32_t *__restrict__ ids) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_outer) return;
+    const uint64_t len = indptr[r + 1] - indptr[r];
+    keys[r] = len > 0xffffffffull ? 0xffffffffu : (uint32_t)len;
+    ids[r] = (uint32_t)r;
+}
+
+// outer vectors by descending length (stable: equal lengths keep ascending id), lengths mirrored on the host
+static void ensure_order(Storage &st, SparseCopy &cp) {
+    if (cp.order.n == cp.n_outer && cp.sorted_len.size() == cp.n_outer) return;
+    DevBuf<uint32_t> keys_a, keys_b, ids_a;
+    keys_a.alloc(cp.n_outer);
+    keys_b.alloc(cp.n_outer);
+    ids_a.alloc(cp.n_outer);
+    cp.order.alloc(cp.n_outer);
+    hipLaunchKernelGGL(outer_len_kernel, grid1(cp.n_outer, 256), dim3(256), 0, st.stream, cp.indptr.p, cp.n_outer, keys_a.p, ids_a.p);
+    size_t tmp_bytes = 0;
+    SCANRS_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, keys_a.p, keys_b.p, ids_a.p, cp.order.p, (size_t)cp.n_outer, 0u, 32u,
+                                              st.stream));
+    DevBuf<unsigned char> tmp;
+    tmp.alloc(tmp_bytes ? tmp_bytes : 1);
+    SCANRS_HIP(rocprim::radix_sort_pairs_desc(tmp.p, tmp_bytes, keys_a.p, keys_b.p, ids_a.p, cp.order.p, (size_t)cp.n_outer, 0u, 32u,
+                                              st.stream));
+    cp.sorted_len.resize(cp.n_outer);
+    SCANRS_HIP(hipMemcpyAsync(cp.sorted_len.data(), keys_b.p, cp.n_outer * 4, hipMemcpyDeviceToHost, st.stream));
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+}
+
+// number of leading vectors of `order` with at least `min_len` nonzeros
+static uint32_t count_at_least(const SparseCopy &cp, uint64_t min_len) {
+    uint64_t lo = 0, hi = cp.sorted_len.size();
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)cp.sorted_len[mid] >= min_len)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return (uint32_t)lo;
+}
+
 // L2-blocked gather: see spmm_gather2d_kernel.
 static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
                            double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w,
@@ -1058,12 +1139,19 @@ static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const
     const uint32_t n_chunks = (l + 127u) / 128u;
     uint32_t lc = (l + n_chunks - 1u) / n_chunks;
     lc = (lc + 1u) & ~1u;
-    const dim3 grid((unsigned)((cp.n_outer + 3) / 4)), block(256);
+    // Longest-first pays when a launch is only a few rounds of waves (33 k genes = 1 round of the chip's 8192 wave slots:
+    // -8 % per step); with ~10^6 vectors there is no tail to hide and the permuted rows only scatter the streaming reads (+3 %).
+    const bool ordered = st.spmm_order == 2 || (st.spmm_order == 1 && cp.n_outer <= 65536u);
+    if (ordered) ensure_order(st, cp);
+    const dim3 block(256);
     for (uint32_t c0 = 0; c0 < l; c0 += lc) {
         const uint32_t lw = std::min(lc, l - c0);
         uint32_t m = (uint32_t)(st.l2_tile_bytes / ((size_t)(1u << BT_SHIFT) * lw * 8));
         if (m < 1u) m = 1u;
         const uint32_t steps = (nb + m - 1u) / m;
+        // hot = a vector whose average segment per step reaches hot_segment nonzeros
+        const uint32_t n_hot = ordered && st.hot_segment ? count_at_least(cp, (uint64_t)st.hot_segment * steps) : 0u;
+        const dim3 grid((unsigned)(n_hot + (cp.n_outer - n_hot + 3) / 4));
         const double bytes = ((double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_inner * lw * 8.0 +
                               (double)cp.n_outer * lw * 8.0) / steps;
         const double *offw = off_w ? off_w + c0 : nullptr;
@@ -1073,8 +1161,8 @@ static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const
                                                       : "spmm_gather2d_kernel<1>/short-outer", bytes,
                         (double)cp.nnz * 8.0 * lw / steps);
             hipLaunchKernelGGL((spmm_gather2d_kernel<1>), grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p,
-                               cp.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, sidx + 1 == steps ? 1 : 0, cp.n_outer, map, X + c0,
-                               ldx, lw, out + c0, ldo, off_a, rank, offw, ldw);
+                               cp.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, sidx + 1 == steps ? 1 : 0, cp.n_outer,
+                               ordered ? cp.order.p : nullptr, n_hot, map, X + c0, ldx, lw, out + c0, ldo, off_a, rank, offw, ldw);
         }
     }
     SCANRS_HIP(hipGetLastError());

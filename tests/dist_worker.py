@@ -5,6 +5,8 @@ mode "cpu":  the sharded normalize -> svd_bk schedule the library implements (ce
              SAME collective hook bench.py hands to the library (scanrs_amd.dist.make_allreduce on host
              buffers); result must equal the single-process oracle.
 mode "gpu":  the real C ABI path, two processes sharing one GPU, hook staged through the host.
+mode "nccl": the real C ABI path with the collective served by RCCL on the device buffers themselves (backend
+             "nccl", the hook exactly as bench.py installs it); one GPU per rank, so on a 1-GPU box world = 1.
 Writes a JSON verdict per rank into the directory given on the command line."""
 import ctypes
 import json
@@ -34,7 +36,11 @@ def main():
     from scanrs_amd.dist import make_allreduce, shard_bounds
     from scanrs_amd.synth import synth_counts
 
-    dist.init_process_group("gloo")
+    if mode == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     n_cells, n_genes, k = 1200, 300, 6
     m = synth_counts(n_cells, n_genes, 0.08, 3)  # cells x genes CSR, identical on every rank
@@ -93,10 +99,19 @@ def main():
     else:
         import scanrs_amd as sa
 
-        torch.cuda.set_device(0)
-        dev = torch.device("cuda", 0)
+        if mode == "nccl":
+            dev = torch.device("cuda", torch.cuda.current_device())
+            hook = make_allreduce(dist, dev)
+            for code, dt in ((0, torch.float64), (1, torch.int64)):  # the hook on raw device pointers, both dtypes
+                t = torch.full((1000,), rank + 1, device=dev, dtype=dt)
+                assert hook(t.data_ptr(), t.numel(), code) == 0
+                assert bool(torch.all(t == sum(range(1, world + 1))))
+        else:
+            torch.cuda.set_device(0)
+            dev = torch.device("cuda", 0)
+            hook = make_allreduce(dist, dev, stage_through_host=True)
         g = sa.AdaptiveMat.from_csmat(n_genes, hi - lo, sa.CSC, ip, ix, vv)
-        g.set_shard(rank, world, lo, n_cells, make_allreduce(dist, dev, stage_through_host=True))
+        g.set_shard(rank, world, lo, n_cells, hook)
         sa.normalize(g, sa.Normalization.CellRanger)
         u, s, v = sa.BkSvd().run_pca(g, k, omega=omega)
         verdict["target_umi"] = g.target_umi()

@@ -483,6 +483,39 @@ def test_blocked_kernel_many_steps_and_determinism(sa):
         assert_close(g.rdot(ql), o.rdot(ql), rtol=1e-10, atol=1e-8)
 
 
+@pytest.mark.parametrize("knobs", [{"SCANRS_HOT_SEGMENT": "8"}, {"SCANRS_HOT_SEGMENT": "1", "SCANRS_SPMM_ORDER": "2"},
+                                   {"SCANRS_SPMM_ORDER": "0"}, {"SCANRS_HOT_SEGMENT": "0"}])
+def test_blocked_kernel_hot_vectors_and_launch_order(sa, monkeypatch, knobs):
+    """Launch order (longest vector first) and the workgroup-per-hot-vector split change scheduling and the
+    association of the partial sums, never the result beyond rounding; both stay bitwise repeatable."""
+    for k_, v_ in knobs.items():
+        monkeypatch.setenv(k_, v_)  # read when a handle is created
+    rng = np.random.default_rng(77)
+    dense = random_counts(rng, 50, 5000, 0.02, 30)
+    dense[3, :] = rng.integers(1, 9, size=5000)          # hot vectors: every step has a long segment
+    dense[17, ::2] = 5
+    dense[18, :37] = 2                                   # a segment shorter than one quarter split
+    dense[40, :] = 0
+    for storage in (so.CSR, so.CSC):
+        g, o = pair(sa, dense + 0, storage)
+        g.set_spmm_path(2)
+        f = rng.random(5000) + 0.5
+        g.compose_scale_axis(1, f).apply(sa.FN_LOG2_1P)
+        o = o.compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=1, a=f)).apply(so.OP_LOG2_1P)
+        u, v = rng.standard_normal((50, 1)), rng.standard_normal((1, 5000))
+        g.set_offset(u, v)
+        lo = so.LowRankOffset(o, u, v)
+        for l in (6, 100, 128, 200):
+            q = rng.standard_normal((5000, l))
+            a = g.dot(q)
+            assert_close(a, lo.dot(q), rtol=1e-10, atol=1e-8)
+            assert np.array_equal(a, g.dot(q))
+            ql = rng.standard_normal((l, 50))
+            b = g.rdot(ql)
+            assert_close(b, lo.rdot(ql), rtol=1e-10, atol=1e-8)
+            assert np.array_equal(b, g.rdot(ql))
+
+
 @pytest.mark.parametrize("path", [1, 2])
 def test_bksvd_through_each_product_kernel(sa, path):
     m = _synth(2500, 600, 0.06, 1)

@@ -107,14 +107,14 @@ def test_normalization_from_str(sa):
         sa.Normalization.from_str("nope")
 
 
-def _run_world2(mode, tmp_path):
+def _run_world2(mode, tmp_path, world=2):
     env = dict(os.environ)
     env["MASTER_ADDR"] = "127.0.0.1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(29500 + (os.getpid() % 400)), os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(tmp_path)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    return [json.load(open(os.path.join(tmp_path, f"rank{i}.json"))) for i in range(2)]
+    return [json.load(open(os.path.join(tmp_path, f"rank{i}.json"))) for i in range(world)]
 
 
 def test_world2_sharded_schedule_gloo(tmp_path):
@@ -130,6 +130,17 @@ def test_world2_sharded_c_abi_on_one_gpu(tmp_path):
     assert vs[0]["target_umi"] == vs[1]["target_umi"]
     for v in vs:
         assert v["v_rows"] == 600
+        assert v["s_rel"] < 1e-8 and v["u_abs"] < 1e-6 and v["v_abs"] < 1e-6, v
+
+
+@pytest.mark.gpu
+def test_rccl_hook_serves_the_exchange_steps(tmp_path):
+    """backend "nccl" (RCCL) on the library's own device buffers, one rank per visible GPU (1 on the test box)."""
+    import torch
+
+    world = max(1, min(2, torch.cuda.device_count()))
+    for v in _run_world2("nccl", tmp_path, world=world):
+        assert v["v_rows"] == 1200 // world
         assert v["s_rel"] < 1e-8 and v["u_abs"] < 1e-6 and v["v_abs"] < 1e-6, v
 
 
