@@ -3,7 +3,10 @@
 // bk_svd.rs:94-139): Cholesky + triangular inverse for the CholeskyQR panels, and a symmetric
 // eigensolver (Householder tridiagonalisation + implicit-shift QL) for the projected Gram matrix.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <vector>
 
@@ -206,52 +209,131 @@ bool sym_eig(const double *a_in, int n, double *w, double *z) {
 bool sym_eig_topk(const double *a_in, int n, int k, double *w, double *z) {
     if (n == 0 || k == 0) return true;
     if (k > n) return false;
+    static const bool tr = getenv("SCANRS_TRACE_EIG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!tr) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[eig] %-20s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     std::vector<double> A(a_in, a_in + (size_t)n * n);
     std::vector<double> d(n), e(n, 0.0), tau(n, 0.0);
     std::vector<double> V((size_t)n * n, 0.0);
-    std::vector<double> p(n), v(n);
-    for (int kk = 0; kk < n - 2; kk++) {
-        double *ak = A.data() + (size_t)kk * n;
+    std::vector<double> p(n), v(n), vn(n), pn(n);
+    // Householder tridiagonalisation on the LOWER triangle only, one pass over the trailing block per step: the
+    // rank-2 update of step kk (A -= v p^T + p v^T) and the product p' = A' v' of step kk+1 share the pass — column
+    // kk+1 is updated first (it defines v'), then every row is updated and at once folded into p' (dot for its own
+    // entry, axpy for the entries of the rows above it). 8 n^2 bytes of traffic per step instead of 24 n^2.
+    auto make_reflector = [&](int kk, const double *colv /* entries kk+1..n-1 of column kk, indexed by row */, double *vv) -> bool {
         double scale = 0.0;
-        for (int i = kk + 1; i < n; i++) scale = std::max(scale, std::fabs(ak[i]));
-        if (scale == 0.0) continue;
+        for (int i = kk + 1; i < n; i++) scale = std::max(scale, std::fabs(colv[i]));
+        if (scale == 0.0) {
+            tau[kk] = 0.0;
+            e[kk] = 0.0;
+            return false;
+        }
         double nrm2 = 0.0;
         for (int i = kk + 1; i < n; i++) {
-            v[i] = ak[i] / scale;
-            nrm2 += v[i] * v[i];
+            vv[i] = colv[i] / scale;
+            nrm2 += vv[i] * vv[i];
         }
-        const double alpha = v[kk + 1];
+        const double alpha = vv[kk + 1];
         double beta = std::sqrt(nrm2);
         if (alpha > 0) beta = -beta;
         const double v0 = alpha - beta;
         tau[kk] = (beta - alpha) / beta;
-        for (int i = kk + 2; i < n; i++) v[i] /= v0;
-        v[kk + 1] = 1.0;
+        for (int i = kk + 2; i < n; i++) vv[i] /= v0;
+        vv[kk + 1] = 1.0;
         e[kk] = beta * scale;
-        // p = tau * A22 v as a sum of rows (A22 symmetric): unit-stride axpy form, vectorises without reassociation
-        for (int j = kk + 1; j < n; j++) p[j] = 0.0;
-        for (int i = kk + 1; i < n; i++) {
-            const double *__restrict__ ai = A.data() + (size_t)i * n;
-            double *__restrict__ pp = p.data();
-            const double vi = v[i];
-            for (int j = kk + 1; j < n; j++) pp[j] += vi * ai[j];
-        }
-        for (int j = kk + 1; j < n; j++) p[j] *= tau[kk];
+        return true;
+    };
+    // finish p: p = tau (A v) - (tau/2)(p.v) v, entries kk+1..n-1
+    auto finish_p = [&](int kk, double *pp, const double *vv) {
+        for (int j = kk + 1; j < n; j++) pp[j] *= tau[kk];
         double pv = 0.0;
-        for (int i = kk + 1; i < n; i++) pv += p[i] * v[i];
+        for (int i = kk + 1; i < n; i++) pv += pp[i] * vv[i];
         const double half = 0.5 * tau[kk] * pv;
-        for (int i = kk + 1; i < n; i++) p[i] -= half * v[i];
-        for (int i = kk + 1; i < n; i++) {
-            double *__restrict__ ai = A.data() + (size_t)i * n;
-            const double vi = v[i], pi = p[i];
-            for (int j = kk + 1; j < n; j++) ai[j] -= vi * p[j] + pi * v[j];
+        for (int i = kk + 1; i < n; i++) pp[i] -= half * vv[i];
+    };
+    std::vector<double> colbuf(n);
+    bool have = false; // a reflector (v, p) of step kk is pending application
+    if (n > 2) {
+        for (int i = 1; i < n; i++) colbuf[i] = A[(size_t)i * n];
+        have = make_reflector(0, colbuf.data(), v.data());
+        if (have) { // p = A22 v from the lower triangle
+            for (int j = 1; j < n; j++) p[j] = 0.0;
+            for (int i = 1; i < n; i++) {
+                const double *__restrict__ ai = A.data() + (size_t)i * n;
+                double *__restrict__ pp = p.data();
+                const double vi = v[i];
+                double s = 0.0;
+                {
+#pragma clang fp reassociate(on)
+                    for (int j = 1; j < i; j++) {
+                        s += ai[j] * v[j];
+                        pp[j] += ai[j] * vi;
+                    }
+                }
+                pp[i] += s + ai[i] * vi;
+            }
+            finish_p(0, p.data(), v.data());
+            double *vk = V.data();
+            for (int i = 1; i < n; i++) vk[i] = v[i];
         }
-        double *vk = V.data() + (size_t)kk * n;
-        for (int i = kk + 1; i < n; i++) vk[i] = v[i];
+    }
+    for (int kk = 0; kk < n - 2; kk++) {
+        // apply the pending reflector of step kk to column kk+1 and the diagonal entry (kk+1, kk+1)
+        const int c = kk + 1;
+        if (have) {
+            for (int i = c; i < n; i++) A[(size_t)i * n + c] -= v[i] * p[c] + p[i] * v[c];
+        }
+        bool have_next = false;
+        if (c < n - 2) {
+            for (int i = c + 1; i < n; i++) colbuf[i] = A[(size_t)i * n + c];
+            have_next = make_reflector(c, colbuf.data(), vn.data());
+        }
+        // one pass over rows c+1..n-1, columns c+1..i: update with (v, p), accumulate pn = A' vn
+        if (have_next)
+            for (int j = c + 1; j < n; j++) pn[j] = 0.0;
+        if (have || have_next) {
+            for (int i = c + 1; i < n; i++) {
+                double *__restrict__ ai = A.data() + (size_t)i * n;
+                if (have) {
+                    const double vi = v[i], pi = p[i];
+                    const double *__restrict__ pp = p.data();
+                    const double *__restrict__ vv = v.data();
+                    for (int j = c + 1; j <= i; j++) ai[j] -= vi * pp[j] + pi * vv[j];
+                }
+                if (have_next) {
+                    double *__restrict__ pq = pn.data();
+                    const double *__restrict__ vq = vn.data();
+                    const double vi = vq[i];
+                    double s = 0.0;
+                    {
+#pragma clang fp reassociate(on)
+                        for (int j = c + 1; j < i; j++) {
+                            s += ai[j] * vq[j];
+                            pq[j] += ai[j] * vi;
+                        }
+                    }
+                    pq[i] += s + ai[i] * vi;
+                }
+            }
+        }
+        if (have_next) {
+            finish_p(c, pn.data(), vn.data());
+            double *vk = V.data() + (size_t)c * n;
+            for (int i = c + 1; i < n; i++) vk[i] = vn[i];
+            std::swap(v, vn);
+            std::swap(p, pn);
+        }
+        have = have_next;
     }
     for (int i = 0; i < n; i++) d[i] = A[(size_t)i * n + i];
-    if (n >= 2) e[n - 2] = A[(size_t)(n - 2) * n + (n - 1)];
+    if (n >= 2) e[n - 2] = A[(size_t)(n - 1) * n + (n - 2)];
     const std::vector<double> td = d, te = e; // keep T; QL below destroys its copy
+    lap("tridiagonalise");
 
     // eigenvalues only
     const double eps = 2.220446049250313e-16;
@@ -265,13 +347,13 @@ bool sym_eig_topk(const double *a_in, int n, int k, double *w, double *z) {
             if (m != l) {
                 if (iter++ == 200) return false;
                 double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-                double r = std::hypot(g, 1.0);
+                double r = std::sqrt(g * g + 1.0);
                 g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
                 double s = 1.0, c = 1.0, pp = 0.0;
                 int i;
                 for (i = m - 1; i >= l; i--) {
                     const double f = s * e[i], b = c * e[i];
-                    r = std::hypot(f, g);
+                    r = std::sqrt(f * f + g * g);
                     e[i + 1] = r;
                     if (r == 0.0) {
                         d[i + 1] -= pp;
@@ -294,6 +376,7 @@ bool sym_eig_topk(const double *a_in, int n, int k, double *w, double *z) {
         } while (m != l);
     }
     std::sort(d.begin(), d.end(), [](double x, double y) { return x > y; });
+    lap("QL eigenvalues");
     double tnorm = 0.0;
     for (int i = 0; i < n; i++) tnorm = std::max(tnorm, std::fabs(td[i]) + (i ? std::fabs(te[i - 1]) : 0.0) + (i < n - 1 ? std::fabs(te[i]) : 0.0));
     if (tnorm == 0.0) tnorm = 1.0;
@@ -360,11 +443,17 @@ bool sym_eig_topk(const double *a_in, int n, int k, double *w, double *z) {
                 for (int q2 = 0; q2 < j; q2++) {
                     const double *xq = X.data() + (size_t)q2 * n;
                     double dot = 0.0;
-                    for (int i = 0; i < n; i++) dot += xq[i] * x[i];
+                    {
+#pragma clang fp reassociate(on)
+                        for (int i = 0; i < n; i++) dot += xq[i] * x[i];
+                    }
                     for (int i = 0; i < n; i++) x[i] -= dot * xq[i];
                 }
             double nrm = 0.0;
-            for (int i = 0; i < n; i++) nrm += x[i] * x[i];
+            {
+#pragma clang fp reassociate(on)
+                for (int i = 0; i < n; i++) nrm += x[i] * x[i];
+            }
             nrm = std::sqrt(nrm);
             if (!(nrm > 0.0) || !std::isfinite(nrm)) return false;
             for (int i = 0; i < n; i++) x[i] /= nrm;
@@ -381,19 +470,30 @@ bool sym_eig_topk(const double *a_in, int n, int k, double *w, double *z) {
         }
         for (int i = 0; i < n; i++) xj[i] = x[i];
     }
-    // back-transform: z_j = H_0 H_1 ... H_{n-3} x_j
-    for (int j = 0; j < k; j++) {
-        double *xj = X.data() + (size_t)j * n;
-        for (int kk = n - 3; kk >= 0; kk--) {
-            if (tau[kk] == 0.0) continue;
-            const double *vk = V.data() + (size_t)kk * n;
-            double s = 0.0;
-            for (int i = kk + 1; i < n; i++) s += vk[i] * xj[i];
-            s *= tau[kk];
-            for (int i = kk + 1; i < n; i++) xj[i] -= s * vk[i];
+    lap("inverse iteration");
+    // back-transform: Z = H_0 H_1 ... H_{n-3} X, all k vectors at once in the n x k output layout (row i = entry i
+    // of every vector): per reflector one k-wide sum of scaled rows and one k-wide update of each row
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < k; j++) z[(size_t)i * k + j] = X[(size_t)j * n + i];
+    std::vector<double> sk(k);
+    for (int kk = n - 3; kk >= 0; kk--) {
+        if (tau[kk] == 0.0) continue;
+        const double *vk = V.data() + (size_t)kk * n;
+        double *__restrict__ ss = sk.data();
+        for (int j = 0; j < k; j++) ss[j] = 0.0;
+        for (int i = kk + 1; i < n; i++) {
+            const double *__restrict__ zi = z + (size_t)i * k;
+            const double vi = vk[i];
+            for (int j = 0; j < k; j++) ss[j] += vi * zi[j];
         }
-        for (int i = 0; i < n; i++) z[(size_t)i * k + j] = xj[i];
+        for (int j = 0; j < k; j++) ss[j] *= tau[kk];
+        for (int i = kk + 1; i < n; i++) {
+            double *__restrict__ zi = z + (size_t)i * k;
+            const double vi = vk[i];
+            for (int j = 0; j < k; j++) zi[j] -= vi * ss[j];
+        }
     }
+    lap("back-transform");
     return true;
 }
 
