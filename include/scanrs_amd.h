@@ -80,6 +80,37 @@ int scanrs_mat_create(uint64_t rows, uint64_t cols, int storage, const uint64_t 
 /* Same, the triplet already lives in device memory (copied, not adopted). */
 int scanrs_mat_create_device(uint64_t rows, uint64_t cols, int storage, const uint64_t *d_indptr,
                              const uint32_t *d_indices, const uint32_t *d_values, scanrs_mat **out);
+
+/* One sqz::AdaptiveVec as it lies in memory (sqz/src/vec.rs:1029-1053): the encoded buffers are handed over
+ * untouched and decoded on the device (AbsIter::next, vec.rs:96-117: ascending positions, stored zeros skipped).
+ *   kind      0 D3, 1 D4, 2 D8, 3 D16, 4 V, 5 S3, 6 S4, 7 S8  (declaration order of `enum AdaptiveVec`)
+ *   len       logical length (the matrix's inner dimension)
+ *   n_units   D*: = len; V: stored entries; S*: stored entries (= length of the inner dense value vector)
+ *   data      D3/S3: Dense3.data (u64 words, 21 fields each, vec.rs:895-900); D4/S4: Dense4.data (two nibbles per
+ *             byte, low nibble = even position, vec.rs:761-766); D8/S8, D16: DenseW.data (vec.rs:660-664); V: NULL
+ *   fallback_*  the SimpleSparse fallback of the dense vector (indexes ascending; keyed by position for D*, by
+ *             entry number for S*); for V the vector's own indexes / values (vec.rs:123-127)
+ *   index_bytes, block_starts   CompressedIndexSparse fields (vec.rs:222-227), S* only:
+ *             block_starts has round_up(len,256)/256 + 1 entries */
+typedef struct scanrs_adaptive_vec {
+    uint32_t kind;
+    uint64_t len;
+    uint64_t n_units;
+    const void *data;
+    uint64_t data_bytes;
+    const uint32_t *fallback_indexes;
+    const uint32_t *fallback_values;
+    uint64_t n_fallback;
+    const uint8_t *index_bytes;
+    const uint32_t *block_starts;
+    uint64_t n_block_starts;
+} scanrs_adaptive_vec;
+
+/* AdaptiveMat::new(rows, cols, storage, Vec<AdaptiveVec>) (sqz/src/mat.rs:68-90): `n_vecs` must be the outer
+ * dimension (rows for CSR, cols for CSC) and every vector `len` the inner one. The compressed buffers
+ * (about 4 kB per cell) are uploaded and expanded on the device; the handle is the same as scanrs_mat_create's. */
+int scanrs_mat_create_adaptive(uint64_t rows, uint64_t cols, int storage, const scanrs_adaptive_vec *vecs, uint64_t n_vecs,
+                               scanrs_mat **out);
 /* Drop for AdaptiveMat / LowRankOffset (Rust `Drop`, cf. bhtsne/src/lib.rs:19-23). Null is a no-op. */
 void scanrs_mat_free(scanrs_mat *m);
 

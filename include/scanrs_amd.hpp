@@ -98,6 +98,12 @@ class AdaptiveMat {
         check(scanrs_mat_create(rows, cols, (int)storage, indptr, indices, data, &h));
         return AdaptiveMat(h);
     }
+    // AdaptiveMat::new(rows, cols, storage, Vec<AdaptiveVec>) (mat.rs:68-90): the encoded vectors, decoded on the device
+    static AdaptiveMat from_adaptive_vecs(uint64_t rows, uint64_t cols, Storage storage, const std::vector<scanrs_adaptive_vec> &vecs) {
+        scanrs_mat *h = nullptr;
+        check(scanrs_mat_create_adaptive(rows, cols, (int)storage, vecs.data(), vecs.size(), &h));
+        return AdaptiveMat(h);
+    }
     AdaptiveMat view() const { // mat.rs:242-245
         scanrs_mat *h = nullptr;
         check(scanrs_mat_view(h_, &h));

@@ -153,6 +153,14 @@ class AtomicSnoop:
         return _Snoop(ctypes.cast(self._flag, ctypes.c_void_p), self._cb, None)
 
 
+class AdaptiveVecDesc(ctypes.Structure):
+    """`scanrs_adaptive_vec` (include/scanrs_amd.h): one sqz::AdaptiveVec by its encoded buffers."""
+    _fields_ = [("kind", ctypes.c_uint32), ("len", ctypes.c_uint64), ("n_units", ctypes.c_uint64), ("data", ctypes.c_void_p),
+                ("data_bytes", ctypes.c_uint64), ("fallback_indexes", ctypes.c_void_p), ("fallback_values", ctypes.c_void_p),
+                ("n_fallback", ctypes.c_uint64), ("index_bytes", ctypes.c_void_p), ("block_starts", ctypes.c_void_p),
+                ("n_block_starts", ctypes.c_uint64)]
+
+
 class AdaptiveMat:
     """Device-resident `sqz::AdaptiveMat<N, D, M>` (sqz/src/mat.rs:34-42). Once a low-rank
     offset is installed (`center`, `scale_and_center`, `normalize`) the same object plays
@@ -179,6 +187,43 @@ class AdaptiveMat:
             _lib.scanrs_mat_create(
                 ctypes.c_uint64(rows), ctypes.c_uint64(cols), ctypes.c_int(storage), _p(indptr), _p(indices), _p(data),
                 ctypes.byref(h)))
+        return AdaptiveMat(h.value)
+
+    @staticmethod
+    def from_adaptive_vecs(rows: int, cols: int, storage: int, vecs) -> "AdaptiveMat":
+        """`AdaptiveMat::new(rows, cols, storage, Vec<AdaptiveVec>)` (mat.rs:68-90): `vecs` is one mapping per outer
+        vector with the fields of `scanrs_adaptive_vec` (kind, len, n_units, data, fallback_indexes, fallback_values,
+        index_bytes, block_starts) holding numpy arrays in the reference's in-memory layout; decoded on the device."""
+        n = len(vecs)
+        table = (AdaptiveVecDesc * max(n, 1))()
+        keep = []  # arrays must outlive the call
+
+        def arr(a, dt):
+            if a is None:
+                return None, 0
+            a = np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            return a.ctypes.data_as(ctypes.c_void_p), a.shape[0]
+
+        for i, v in enumerate(vecs):
+            d = table[i]
+            d.kind, d.len, d.n_units = int(v["kind"]), int(v["len"]), int(v["n_units"])
+            data = v.get("data")
+            if data is not None:
+                data = np.ascontiguousarray(data)
+                keep.append(data)
+                d.data, d.data_bytes = data.ctypes.data_as(ctypes.c_void_p), data.nbytes
+            fi, nfi = arr(v.get("fallback_indexes"), np.uint32)
+            fv, nfv = arr(v.get("fallback_values"), np.uint32)
+            if nfi != nfv:
+                raise ScanrsError(6, "fallback indexes / values differ in length")
+            d.fallback_indexes, d.fallback_values, d.n_fallback = fi, fv, nfi
+            ib, _ = arr(v.get("index_bytes"), np.uint8)
+            bs, nbs = arr(v.get("block_starts"), np.uint32)
+            d.index_bytes, d.block_starts, d.n_block_starts = ib, bs, nbs
+        h = ctypes.c_void_p()
+        _check(_lib.scanrs_mat_create_adaptive(ctypes.c_uint64(rows), ctypes.c_uint64(cols), ctypes.c_int(storage), table,
+                                              ctypes.c_uint64(n), ctypes.byref(h)))
         return AdaptiveMat(h.value)
 
     @staticmethod
@@ -591,7 +636,7 @@ def host_sym_eig_topk(a, k):
 
 
 EXPORTED_SYMBOLS = [
-    "scanrs_last_error", "scanrs_device_available", "scanrs_version", "scanrs_mat_create", "scanrs_mat_create_device",
+    "scanrs_last_error", "scanrs_device_available", "scanrs_version", "scanrs_mat_create", "scanrs_mat_create_device", "scanrs_mat_create_adaptive",
     "scanrs_mat_free", "scanrs_mat_view", "scanrs_mat_t", "scanrs_mat_shape", "scanrs_mat_nnz", "scanrs_mat_storage",
     "scanrs_mat_reset_map", "scanrs_mat_compose_scale_axis", "scanrs_mat_apply", "scanrs_mat_set_offset",
     "scanrs_mat_center", "scanrs_mat_scale", "scanrs_mat_scale_and_center", "scanrs_mat_sum_axis_u32",

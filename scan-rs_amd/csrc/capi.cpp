@@ -468,6 +468,23 @@ int scanrs_mat_create_device(uint64_t rows, uint64_t cols, int storage, const ui
                              const uint32_t *d_values, scanrs_mat **out) {
     return guard([&] { create_common(rows, cols, storage, d_indptr, d_indices, d_values, true, out); });
 }
+int scanrs_mat_create_adaptive(uint64_t rows, uint64_t cols, int storage, const scanrs_adaptive_vec *vecs, uint64_t n_vecs,
+                               scanrs_mat **out) {
+    return guard([&] {
+        if (!out) fail(SCANRS_ERR_ARGUMENT, "null output handle");
+        *out = nullptr;
+        need_device();
+        if (storage != SCANRS_CSR && storage != SCANRS_CSC) fail(SCANRS_ERR_ARGUMENT, "storage must be 0 (CSR) or 1 (CSC)");
+        const uint64_t n_outer = storage == SCANRS_CSR ? rows : cols, n_inner = storage == SCANRS_CSR ? cols : rows;
+        if (n_vecs != n_outer) fail(SCANRS_ERR_SHAPE, "one AdaptiveVec per outer vector is required");
+        if (n_vecs > 0 && !vecs) fail(SCANRS_ERR_ARGUMENT, "null vector table");
+        DevBuf<uint64_t> ip;
+        DevBuf<uint32_t> ix, vv;
+        decode_adaptive_vectors(vecs, n_vecs, n_inner, ip, ix, vv);
+        SCANRS_HIP(hipDeviceSynchronize());
+        create_common(rows, cols, storage, ip.p, ix.p, vv.p, true, out); // validates ordering, copies into the handle
+    });
+}
 void scanrs_mat_free(scanrs_mat *m) { delete m; }
 
 int scanrs_mat_view(const scanrs_mat *m, scanrs_mat **out) {

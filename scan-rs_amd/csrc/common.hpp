@@ -327,6 +327,9 @@ void omega_fill(uint64_t seed, uint64_t count, double *out);
 // operator-level helpers shared by capi.cpp and solver.cpp
 // out[rows_v x l] = V * X  (transpose: out[cols_v x l] = V^T * X), offsets and shard reduction included.
 void mat_apply(scanrs_mat *m, bool transpose, const double *dX, uint32_t ldx, uint32_t l, double *dOut, uint32_t ldo);
+// decode.hip
+uint64_t decode_adaptive_vectors(const scanrs_adaptive_vec *vecs, uint64_t n_vecs, uint64_t vec_len, DevBuf<uint64_t> &indptr,
+                                 DevBuf<uint32_t> &indices, DevBuf<uint32_t> &values);
 void allreduce_f64(Storage &st, double *d, uint64_t count);
 void allreduce_u64(Storage &st, unsigned long long *d, uint64_t count);
 // is the view-row dimension the sharded one?
