@@ -59,8 +59,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # SCANRS_BENCH_SHARED_GPU=1 (tests only): every rank uses GPU 0 and the exchange steps go through gloo on host copies,
+    # so the N > 1 code path can be exercised end to end on a 1-GPU box. Never set by the driver.
+    shared_gpu = os.environ.get("SCANRS_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if shared_gpu else dev
     dist = None
     if world > 1 or args.force_collective:
         import torch.distributed as dist_mod
@@ -68,7 +74,10 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import scanrs_amd as sa
     from scanrs_amd.synth import synth_counts_torch
@@ -96,7 +105,7 @@ def main():
     if dist is not None:
         from scanrs_amd.dist import make_allreduce
 
-        mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev))
+        mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev, stage_through_host=shared_gpu))
 
     if args.f32_panels:
         mat.set_panel_precision(1)
@@ -155,10 +164,10 @@ def main():
         events_elapsed = time.perf_counter() - t0
     mat.profile_enable(False)
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        nn = torch.tensor([nnz_local], device=dev, dtype=torch.int64)
+        nn = torch.tensor([nnz_local], device=red_dev, dtype=torch.int64)
         dist.all_reduce(nn)
         nnz_global = int(nn.item())
     else:

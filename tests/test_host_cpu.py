@@ -144,6 +144,39 @@ def test_rccl_hook_serves_the_exchange_steps(tmp_path):
         assert v["s_rel"] < 1e-8 and v["u_abs"] < 1e-6 and v["v_abs"] < 1e-6, v
 
 
+def _bench_line(extra_env, launcher, tmp_path, gpus):
+    env = dict(os.environ)
+    env.update(extra_env)
+    args = ["--gpus", str(gpus), "--steps", "1", "--warmup", "1", "--cells", "6000", "--genes", "1500", "--density", "0.04", "--k", "8",
+            "--no-cpu-baseline"]
+    cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_equal_one_rank(tmp_path):
+    """bench.py's N > 1 flow (shard bounds, per-rank synthetic shard, set_shard, max-over-ranks timing) end to end with two
+    ranks sharing the one GPU of the test box (gloo-staged exchange): same global matrix, same singular values."""
+    one = _bench_line({}, [], tmp_path, 1)
+    port = str(29500 + (os.getpid() % 400) + 401)
+    two = _bench_line({"SCANRS_BENCH_SHARED_GPU": "1"},
+                      ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                       "--master-port", port], tmp_path, 2)
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["nnz"] == one["config"]["nnz"]
+    a, b = np.array(one["config"]["sigma_top3"]), np.array(two["config"]["sigma_top3"])
+    assert np.max(np.abs(a - b) / a) < 1e-9
+    for d in (one, two):
+        for key in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config", "roofline",
+                    "cpu_baseline", "vs_baseline", "steps", "warmup"):
+            assert key in d
+        assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+
+
 def test_host_sym_eig_topk(sa):
     rng = np.random.default_rng(5)
     for n, k in ((1, 1), (2, 2), (7, 3), (64, 64), (200, 20)):
