@@ -39,8 +39,10 @@ def parse():
     ap.add_argument("--pcie", action="store_true", help="also time one step that copies U and V to the host")
     ap.add_argument("--f32-panels", action="store_true",
                     help="opt-in fast mode: gathered panels rounded to f32, f64 sums (NOT the headline configuration)")
-    ap.add_argument("--spmm-path", type=int, default=0, help="0 auto, 1 plain gather, 2 L2-blocked gather, 3 LDS-tiled (experimental)")
+    ap.add_argument("--spmm-path", type=int, default=0, help="0 auto, 1 plain gather, 2 L2-blocked gather")
     ap.add_argument("--also-randsvd", action="store_true", help="also time one RandSvd{10, 2} PCA (SURVEY.md §8d: reported alongside)")
+    ap.add_argument("--also-irlba", action="store_true",
+                    help="also time one Irlba{tol 1e-4, 50} run on the log-normalised (un-centred) matrix, the only input irlba.rs takes")
     ap.add_argument("--force-collective", action="store_true",
                     help="N=1 only: serve the exchange steps through RCCL (world 1) anyway, to price the hook itself")
     ap.add_argument("--events-in-timed-region", action="store_true",
@@ -197,6 +199,20 @@ def main():
         barrier()
         randsvd_ms = (time.perf_counter() - t0) * 1e3
 
+    irlba_ms = irlba_mprod = None
+    if args.also_irlba and world == 1:
+        import ctypes
+
+        mat.reset_map()
+        sa.log_normalize_with_size_factor(mat, None, sa.FN_LOG2_1P)
+        mp = ctypes.c_uint32()
+        barrier()
+        t0 = time.perf_counter()
+        sa._check(sa._lib.scanrs_pca_irlba(mat._h, ctypes.c_uint32(args.k), ctypes.c_double(1e-4), ctypes.c_uint32(50), None, None, None,
+                                           s_out.ctypes.data_as(ctypes.c_void_p), None, ctypes.byref(mp)))
+        barrier()
+        irlba_ms, irlba_mprod = (time.perf_counter() - t0) * 1e3, int(mp.value)
+
     # ---- roofline of the dominant kernel -------------------------------------------------------------------
     roof = None
     if prof:
@@ -289,6 +305,9 @@ def main():
             out["config"]["pcie_inclusive_cells_per_s"] = round(pcie, 1)
         if randsvd_ms is not None:
             out["config"]["randsvd_l10_it2_ms"] = round(randsvd_ms, 1)
+        if irlba_ms is not None:
+            out["config"]["irlba_tol1e-4_ms"] = round(irlba_ms, 1)
+            out["config"]["irlba_matrix_products"] = irlba_mprod
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -133,9 +133,11 @@ int main(int argc, char **argv) {
     CK(hipGetDeviceProperties(&prop, 0));
     const int n_cu = prop.multiProcessorCount;
     printf("device %s, %d CUs, slice rows %u\n", prop.name, n_cu, rows);
+    const uint32_t len_a = argc > 3 ? (uint32_t)atoi(argv[3]) : 112u, len_b = argc > 4 ? (uint32_t)atoi(argv[4]) : 1024u;
     for (uint32_t l : {100u, 128u, 64u}) {
-        for (uint32_t len : {112u, 1024u}) {
-            const uint64_t no = len == 112u ? n_outer : n_outer / 8;
+        if (argc > 3 && l != 100u) continue;
+        for (uint32_t len : {len_a, len_b}) {
+            const uint64_t no = len <= 128u ? n_outer : n_outer / 8;
             const uint32_t ld = l;
             std::vector<uint32_t> hi(no * len);
             std::vector<double> hw(no * len);
