@@ -206,10 +206,12 @@ def main():
         mat.reset_map()
         sa.log_normalize_with_size_factor(mat, None, sa.FN_LOG2_1P)
         mp = ctypes.c_uint32()
+        u_out, v_out = np.zeros((args.genes, args.k)), np.zeros((n_local, args.k))  # irlba returns host arrays (irlba.rs:71-76)
         barrier()
         t0 = time.perf_counter()
-        sa._check(sa._lib.scanrs_pca_irlba(mat._h, ctypes.c_uint32(args.k), ctypes.c_double(1e-4), ctypes.c_uint32(50), None, None, None,
-                                           s_out.ctypes.data_as(ctypes.c_void_p), None, ctypes.byref(mp)))
+        sa._check(sa._lib.scanrs_pca_irlba(mat._h, ctypes.c_uint32(args.k), ctypes.c_double(1e-4), ctypes.c_uint32(50), None, None,
+                                           u_out.ctypes.data_as(ctypes.c_void_p), s_out.ctypes.data_as(ctypes.c_void_p),
+                                           v_out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(mp)))
         barrier()
         irlba_ms, irlba_mprod = (time.perf_counter() - t0) * 1e3, int(mp.value)
 
@@ -221,7 +223,7 @@ def main():
         achieved = st["algorithmic_bytes"] / (st["total_ms"] * 1e-3) / 1e9 if st["total_ms"] > 0 else 0.0
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes (profiles/, separate --pmc runs), headline workload only
-            with open(os.path.join(ROOT, "profiles", "r01d_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01e_pmc_traffic.json")) as f:
                 pm = json.load(f)["kernels"].get(name)
             if pm and args.cells == 1_000_000 and args.genes == 33_000 and world == 1:
                 traffic = round(pm["hbm_bytes_per_launch_corrected"])
