@@ -26,6 +26,58 @@ typedef uint32_t u2 __attribute__((ext_vector_type(2)));
 // nonzero per lane. `outer`/`inner` are positions in the copy being walked.
 __device__ __forceinline__ double a_ln_a_over_b(double a, double b) { return a == 0.0 ? 0.0 : a * log(a / b); }
 
+// Logarithms of the normalisation maps (`(x + 1.0).ln() / .log2() / .log10()`, scan-rs/src/normalization.rs:172-176).
+// One log per nonzero per pass is most of the VALU work of the scan-like kernels, and ocml's f64 log is ~100 VALU
+// instructions (double-double arithmetic for < 1 ulp). This is the fdlibm e_log.c kernel — argument reduced to
+// m in [sqrt(1/2), sqrt(2)), s = f/(2+f), degree-14 odd polynomial, error < 2^-58 before the last roundings — with the
+// division done by v_rcp_f64 + two Newton steps + one residual correction: ~45 instructions, result within 2 ulp of
+// the correctly rounded value (checked against numpy in tests/test_gpu_parity.py). Arguments outside
+// [1e-300, 1e300] (zero, negative, inf, NaN, subnormal) take the library routine.
+__device__ __forceinline__ double log_core(double x, double &kd) {
+    int e;
+    double m = frexp(x, &e); // [0.5, 1)
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    kd = (double)e;
+    const double f = m - 1.0;
+    const double d = 2.0 + f;
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    double s = f * r;
+    s = fma(fma(-d, s, f), r, s);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 =
+        z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    return f - (hfsq - s * (hfsq + R)); // log(m)
+}
+__device__ __forceinline__ bool log_fast_range(double x) { return x >= 1e-300 && x <= 1e300; }
+__device__ __forceinline__ double map_log2(double x) {
+    if (!log_fast_range(x)) return log2(x);
+    double kd;
+    const double lm = log_core(x, kd);
+    return fma(lm, 1.44269504088896338700e+00, kd);
+}
+__device__ __forceinline__ double map_ln(double x) {
+    if (!log_fast_range(x)) return log(x);
+    double kd;
+    const double lm = log_core(x, kd);
+    return fma(kd, 6.93147180369123816490e-01, lm + kd * 1.90821492927058770002e-10); // k ln2_hi + (log m + k ln2_lo)
+}
+__device__ __forceinline__ double map_log10(double x) {
+    if (!log_fast_range(x)) return log10(x);
+    double kd;
+    const double lm = log_core(x, kd);
+    // k log10(2) + log(m) / ln(10), log10(2) split so that k * hi is exact
+    return fma(kd, 3.01029995663611771306e-01, fma(lm, 4.34294481903251816668e-01, kd * 3.69423907715893078616e-13));
+}
+
+constexpr int SCAN_U = 4; // strides of 64 nonzeros in flight per trip of the scan-like passes (SpMV, sums, moments)
+
 __device__ __forceinline__ double eval_map(const DevMap &m, uint32_t v, uint32_t outer, uint32_t inner) {
     double x = (double)v;
     for (int i = 0; i < m.n; i++) {
@@ -35,13 +87,13 @@ __device__ __forceinline__ double eval_map(const DevMap &m, uint32_t v, uint32_t
             x = op.a[op.a_outer ? outer : inner] * x;
             break;
         case OP_LN_1P:
-            x = log(x + 1.0);
+            x = map_ln(x + 1.0);
             break;
         case OP_LOG2_1P:
-            x = log2(x + 1.0);
+            x = map_log2(x + 1.0);
             break;
         case OP_LOG10_1P:
-            x = log10(x + 1.0);
+            x = map_log10(x + 1.0);
             break;
         case OP_SQUARE:
             x = x * x;
@@ -509,11 +561,31 @@ __global__ __launch_bounds__(256) void spmv_kernel(const uint32_t *__restrict__ 
     const uint32_t *__restrict__ ind = indices + it.start;
     const uint32_t *__restrict__ val = values + it.start;
     double s0 = 0.0, s1 = 0.0;
-    for (uint32_t p = lane; p < it.len; p += 64u) {
-        const uint32_t g = ind[p];
-        const double f = eval_map(map, val[p], it.row, g);
-        s0 = fma(f, X[(size_t)g * ldx], s0);
-        if (l > 1) s1 = fma(f, X[(size_t)g * ldx + 1], s1);
+    // SCAN_U strides of the vector per trip, every load of a trip issued before the first use (clamped position instead
+    // of a branch): one round trip to memory per 4 x 64 nonzeros instead of two per 64 — these passes are latency-bound
+    for (uint32_t p0 = lane; p0 < it.len; p0 += 64u * SCAN_U) {
+        uint32_t g[SCAN_U], vv[SCAN_U];
+        bool ok[SCAN_U];
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++) {
+            const uint32_t p = p0 + 64u * u;
+            ok[u] = p < it.len;
+            const uint32_t q = ok[u] ? p : it.len - 1u;
+            g[u] = ind[q];
+            vv[u] = val[q];
+        }
+        double x0[SCAN_U], x1[SCAN_U];
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++) {
+            x0[u] = X[(size_t)g[u] * ldx];
+            x1[u] = l > 1 ? X[(size_t)g[u] * ldx + 1] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++) {
+            const double f = eval_map(map, vv[u], it.row, g[u]);
+            s0 = ok[u] ? fma(f, x0[u], s0) : s0;
+            if (l > 1) s1 = ok[u] ? fma(f, x1[u], s1) : s1;
+        }
     }
     s0 = wave_sum(s0);
     if (l > 1) s1 = wave_sum(s1);
@@ -530,6 +602,68 @@ __global__ __launch_bounds__(256) void spmv_kernel(const uint32_t *__restrict__ 
             slab[(size_t)it.slab * ldo] = s0;
             slab[(size_t)it.slab * ldo + 1] = s1;
         }
+    }
+}
+
+// Blocked sparse x vector: the gathered vector (and any inner-indexed scale of the map) is walked in slices that stay
+// L2-resident, exactly as row_reduce2d_kernel does for the moments — a straight pass over a gene-major copy turns every
+// nonzero into a 64-byte miss on the 8 MB barcode-indexed vector. `order` lists the vectors longest first.
+__global__ __launch_bounds__(256) void spmv2d_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                     const uint32_t *__restrict__ values, const uint32_t *__restrict__ bounds,
+                                                     uint32_t nb, uint32_t b0, uint32_t b1, int first, int last, uint64_t n_outer,
+                                                     const uint32_t *__restrict__ order, DevMap map, const double *__restrict__ X,
+                                                     uint32_t ldx, uint32_t l, double *__restrict__ out, uint32_t ldo,
+                                                     const double *__restrict__ off_a, uint32_t rank,
+                                                     const double *__restrict__ off_w, uint32_t ldw) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t slot = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (slot >= n_outer) return;
+    const uint64_t row = order ? (uint64_t)order[slot] : slot;
+    const uint32_t *__restrict__ bd = bounds + row * (nb + 1);
+    const uint32_t o0 = bd[b0], len = bd[b1] - o0;
+    const bool epilogue = last && rank > 0;
+    if (len == 0 && !first && !epilogue) return;
+    const uint64_t base = indptr[row] + o0;
+    double s0 = 0.0, s1 = 0.0;
+    for (uint32_t p0 = lane; p0 < len; p0 += 64u * SCAN_U) {
+        uint32_t g[SCAN_U], vv[SCAN_U];
+        bool ok[SCAN_U];
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++) {
+            const uint32_t p = p0 + 64u * u;
+            ok[u] = p < len;
+            const uint64_t q = base + (ok[u] ? p : len - 1u);
+            g[u] = indices[q];
+            vv[u] = values[q];
+        }
+        double x0[SCAN_U], x1[SCAN_U];
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++) {
+            x0[u] = X[(size_t)g[u] * ldx];
+            x1[u] = l > 1 ? X[(size_t)g[u] * ldx + 1] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++) {
+            const double f = eval_map(map, vv[u], (uint32_t)row, g[u]);
+            s0 = ok[u] ? fma(f, x0[u], s0) : s0;
+            if (l > 1) s1 = ok[u] ? fma(f, x1[u], s1) : s1;
+        }
+    }
+    s0 = wave_sum(s0);
+    if (l > 1) s1 = wave_sum(s1);
+    if (lane == 0) {
+        if (!first) {
+            s0 += out[row * ldo];
+            if (l > 1) s1 += out[row * ldo + 1];
+        }
+        if (epilogue)
+            for (uint32_t q = 0; q < rank; q++) {
+                const double aq = off_a[row * rank + q];
+                s0 += aq * off_w[(size_t)q * ldw];
+                if (l > 1) s1 += aq * off_w[(size_t)q * ldw + 1];
+            }
+        out[row * ldo] = s0;
+        if (l > 1) out[row * ldo + 1] = s1;
     }
 }
 
@@ -558,10 +692,23 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(const uint32_t *__restr
         }
     } else {
         double s = 0.0, s2 = 0.0;
-        for (uint32_t p = lane; p < it.len; p += 64u) {
-            const double x = eval_map(map, val[p], it.row, ind[p]);
-            s += x;
-            if constexpr (MODE == 2) s2 = fma(x, x, s2);
+        for (uint32_t p0 = lane; p0 < it.len; p0 += 64u * SCAN_U) {
+            uint32_t g[SCAN_U], vv[SCAN_U];
+            bool ok[SCAN_U];
+#pragma unroll
+            for (int u = 0; u < SCAN_U; u++) {
+                const uint32_t p = p0 + 64u * u;
+                ok[u] = p < it.len;
+                const uint32_t q = ok[u] ? p : it.len - 1u;
+                g[u] = ind[q];
+                vv[u] = val[q];
+            }
+#pragma unroll
+            for (int u = 0; u < SCAN_U; u++) {
+                const double x = eval_map(map, vv[u], it.row, g[u]);
+                s = ok[u] ? s + x : s;
+                if constexpr (MODE == 2) s2 = ok[u] ? fma(x, x, s2) : s2;
+            }
         }
         s = wave_sum(s);
         if constexpr (MODE == 2) s2 = wave_sum(s2);
@@ -596,10 +743,23 @@ __global__ __launch_bounds__(256) void row_reduce2d_kernel(const uint64_t *__res
     if (len == 0 && !first) return;
     const uint64_t base = indptr[row] + o0;
     double s = 0.0, s2 = 0.0;
-    for (uint32_t p = lane; p < len; p += 64u) {
-        const double x = eval_map(map, values[base + p], (uint32_t)row, indices[base + p]);
-        s += x;
-        if constexpr (MODE == 2) s2 = fma(x, x, s2);
+    for (uint32_t p0 = lane; p0 < len; p0 += 64u * SCAN_U) {
+        uint32_t g[SCAN_U], vv[SCAN_U];
+        bool ok[SCAN_U];
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++) {
+            const uint32_t p = p0 + 64u * u;
+            ok[u] = p < len;
+            const uint64_t q = base + (ok[u] ? p : len - 1u);
+            g[u] = indices[q];
+            vv[u] = values[q];
+        }
+#pragma unroll
+        for (int u = 0; u < SCAN_U; u++) {
+            const double x = eval_map(map, vv[u], (uint32_t)row, g[u]);
+            s = ok[u] ? s + x : s;
+            if constexpr (MODE == 2) s2 = ok[u] ? fma(x, x, s2) : s2;
+        }
     }
     s = wave_sum(s);
     if constexpr (MODE == 2) s2 = wave_sum(s2);
@@ -1216,11 +1376,31 @@ void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const doubl
     }
     if (l <= 2 && l > 0 && cp.n_outer > 0) {
         if ((ldx & 1u) || (ldo & 1u)) fail(SCANRS_ERR_ARGUMENT, "panel leading dimensions must be even");
+        const bool long_outer = cp.n_outer >= cp.n_inner;
+        if (st.spmm_path != 1 && cp.nnz >= st.blocked_min_nnz && cp.n_inner >= (1ull << 19)) {
+            // the vector does not fit an XCD's L2: walk it in 2 MB slices (base tiles of 1024 positions x ldx x 8 B)
+            const uint32_t nb = ensure_bounds(st, cp);
+            const uint32_t m = std::max(1u, 256u / ldx);
+            const uint32_t steps = (nb + m - 1u) / m;
+            const bool ordered = st.spmm_order == 2 || (st.spmm_order == 1 && cp.n_outer <= 65536u);
+            if (ordered) ensure_order(st, cp);
+            const dim3 grid((unsigned)((cp.n_outer + 3) / 4)), block(256);
+            const double bytes = ((double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)(cp.n_inner + cp.n_outer) * l * 8.0) / steps;
+            for (uint32_t sidx = 0; sidx < steps; sidx++) {
+                const uint32_t b0 = sidx * m, b1 = std::min(nb, b0 + m);
+                ProfScope ps(st, long_outer ? "spmv2d_kernel/long-outer" : "spmv2d_kernel/short-outer", bytes);
+                hipLaunchKernelGGL(spmv2d_kernel, grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p, cp.bounds.p, nb, b0, b1,
+                                   sidx == 0 ? 1 : 0, sidx + 1 == steps ? 1 : 0, cp.n_outer, ordered ? cp.order.p : nullptr, map, X, ldx, l, out,
+                                   ldo, off_a, rank, off_w, ldw);
+            }
+            SCANRS_HIP(hipGetLastError());
+            return;
+        }
         double *slab = nullptr;
         if (cp.n_slab) slab = st.scratch.get<double>("spmm_slab", (size_t)cp.n_slab * ldo);
         const dim3 grid((cp.n_items + 3u) / 4u), block(256);
         {
-            ProfScope ps(st, "spmv_kernel", (double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)(cp.n_inner + cp.n_outer) * l * 8.0);
+            ProfScope ps(st, long_outer ? "spmv_kernel/long-outer" : "spmv_kernel/short-outer", (double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)(cp.n_inner + cp.n_outer) * l * 8.0);
             hipLaunchKernelGGL(spmv_kernel, grid, block, 0, st.stream, cp.indices.p, cp.values.p, cp.items.p, cp.n_items, map, X, ldx,
                                l, out, ldo, slab, off_a, rank, off_w, ldw);
         }

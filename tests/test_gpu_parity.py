@@ -516,6 +516,70 @@ def test_blocked_kernel_hot_vectors_and_launch_order(sa, monkeypatch, knobs):
             assert np.array_equal(b, g.rdot(ql))
 
 
+def test_blocked_spmv_matches_plain_and_oracle(sa):
+    """Ix1 products (the ones IRLBA runs, mat.rs:1092-1112,1150-1170) on a matrix whose inner dimension exceeds an XCD's
+    L2 as a vector: the blocked SpMV (slices of the vector, sums carried through the output) against the plain kernel
+    and the oracle, with a map that gathers an inner-indexed scale and a rank-1 offset."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(8)
+    rows, cols, nnz = 48, 700_000, 4_600_000
+    r = rng.integers(0, rows, size=nnz)
+    r[: nnz // 3] = 5  # one vector far longer than the rest
+    c = rng.integers(0, cols, size=nnz)
+    m = sp.csr_matrix((rng.integers(1, 9, size=nnz).astype(np.uint32), (r, c)), shape=(rows, cols))
+    m.sum_duplicates()
+    m.sort_indices()
+    f = rng.random(cols) + 0.5
+    outs = []
+    for path in (1, 0):
+        g = sa.AdaptiveMat.from_csmat(rows, cols, sa.CSR, m.indptr, m.indices, m.data)
+        g.set_spmm_path(path)
+        g.compose_scale_axis(1, f).apply(sa.FN_LOG2_1P)
+        u, v = rng.standard_normal((rows, 1)), rng.standard_normal((1, cols))
+        if path == 1:
+            uv = (u, v)
+        g.set_offset(*uv)
+        x = np.random.default_rng(1).standard_normal(cols)
+        x2 = np.random.default_rng(2).standard_normal((cols, 2))
+        outs.append((g.dot(x), g.dot(x2), g.dot(x)))
+    o = so.AdaptiveMat(rows, cols, so.CSR, m.indptr, m.indices, m.data)
+    o = o.compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=1, a=f)).apply(so.OP_LOG2_1P)
+    lo = so.LowRankOffset(o, *uv)
+    x = np.random.default_rng(1).standard_normal(cols)
+    x2 = np.random.default_rng(2).standard_normal((cols, 2))
+    ref1, ref2 = lo.dot(x.reshape(-1, 1)).ravel(), lo.dot(x2)
+    for y1, y2, y1b in outs:
+        assert_close(np.ravel(y1), ref1, rtol=1e-10, atol=1e-7)
+        assert_close(y2, ref2, rtol=1e-10, atol=1e-7)
+        assert np.array_equal(y1, y1b)  # repeatable bit for bit
+
+
+@pytest.mark.parametrize("fn,ref", [("FN_LOG2_1P", np.log2), ("FN_LN_1P", np.log), ("FN_LOG10_1P", np.log10)])
+def test_map_logarithms_within_2_ulp(sa, fn, ref):
+    """The kernels evaluate `(x + 1.0).ln() / log2() / log10()` (normalization.rs:172-176) with their own fdlibm-style
+    routine instead of the ~100-instruction library call; it must stay within 2 ulp of the correctly rounded value
+    over the whole range a count x scale product can take, and be exact where the library is (x = 0 -> 0)."""
+    rng = np.random.default_rng(12)
+    rows, cols = 64, 4096
+    vals = rng.integers(1, 2**31, size=(rows, cols), dtype=np.uint32)
+    vals[:, :512] = rng.integers(1, 16, size=(rows, 512))  # the counts that actually occur
+    scale = np.exp(rng.uniform(np.log(1e-18), np.log(1e12), size=cols))
+    scale[:8] = [1.0, 0.5, 2.0, 1e-17, 1e-300, 1e300, 3.0, 1.0 / 3.0]
+    g, _ = pair(sa, vals, so.CSR)
+    g.compose_scale_axis(1, scale).apply(getattr(sa, fn))
+    got = g.to_dense()
+    arg = vals.astype(np.float64) * scale + 1.0  # the argument exactly as the kernel forms it (one rounding each)
+    with np.errstate(over="ignore"):
+        want = ref(arg)
+    finite = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), finite)
+    ulp = np.spacing(np.abs(want[finite]))
+    err = np.abs(got[finite] - want[finite]) / np.where(ulp > 0, ulp, 1.0)
+    assert err.max() <= 2.0, err.max()
+    assert np.all(got[arg == 1.0] == 0.0)
+
+
 @pytest.mark.parametrize("path", [1, 2])
 def test_bksvd_through_each_product_kernel(sa, path):
     m = _synth(2500, 600, 0.06, 1)
