@@ -214,6 +214,19 @@ int scanrs_pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t max_iter, 
 /* The panel the two randomized drivers draw for a given seed (count values, row-major fill order). */
 int scanrs_omega_fill(uint64_t seed, uint64_t count, double *out);
 
+/* ---- nearest neighbours of the PCA scores: scan_rs::nn (scan-rs/src/nn.rs) -------------- */
+
+/* knn(v, k) (nn.rs:38-57): for every row of the n x d row-major matrix `points` the indices of its k nearest OTHER rows
+ * by Euclidean distance, nearest first; rows of `out` (n x k) are padded with UINT32_MAX when fewer than k exist
+ * (`T::max_value()`, nn.rs:66). Exact (exhaustive search in f64 on the device); exactly equidistant neighbours come in
+ * ascending index order. k <= 128, d <= 128. */
+int scanrs_knn(const double *points, uint64_t n, uint32_t d, uint32_t k, uint32_t *out);
+/* find_nn(v, k, tree, include_self) (nn.rs:63-83): the k nearest of `points` (the tree's point set, n_p x d) to each
+ * row of `queries` (n_q x d). As in the reference, include_self = 0 drops the point whose INDEX equals the query's
+ * row number, which is only meaningful when the two sets are the same. */
+int scanrs_find_nn(const double *queries, uint64_t n_q, const double *points, uint64_t n_p, uint32_t d, uint32_t k,
+                   int include_self, uint32_t *out);
+
 /* ---- multi-GPU: one process per GPU, cells range-partitioned ----------- */
 
 /* In-place sum all-reduce of `count` elements of device memory across ranks.

@@ -193,6 +193,13 @@ inline AdaptiveMat normalize_with_size_factor(AdaptiveMat mat, Normalization nor
 inline AdaptiveMat binom_deviance_resid(AdaptiveMat mat) { return normalize(std::move(mat), Normalization::BinomialDeviance); }
 inline AdaptiveMat binom_pearson_resid(AdaptiveMat mat) { return normalize(std::move(mat), Normalization::BinomialPearson); }
 
+// nn::knn (scan-rs/src/nn.rs:38-57): k nearest other rows of the cells x d matrix, nearest first
+inline std::vector<uint32_t> knn(const Array2 &v, size_t k) {
+    std::vector<uint32_t> out(v.rows * k);
+    check(scanrs_knn(v.data.data(), v.rows, (uint32_t)v.cols, (uint32_t)k, out.data()));
+    return out;
+}
+
 namespace detail {
 inline void progress_tramp(void *ctx, double f) {
     auto *s = static_cast<Snoop *>(ctx);

@@ -153,6 +153,26 @@ class AtomicSnoop:
         return _Snoop(ctypes.cast(self._flag, ctypes.c_void_p), self._cb, None)
 
 
+def knn(v, k: int):
+    """`nn::knn(v, k)` (scan-rs/src/nn.rs:38-57): (cells x k) u32 indices of the k nearest other rows of `v`, nearest first."""
+    v = _f64(np.atleast_2d(v))
+    n, d = v.shape
+    out = np.zeros((n, k), dtype=np.uint32)
+    _check(_lib.scanrs_knn(_p(v), ctypes.c_uint64(n), ctypes.c_uint32(d), ctypes.c_uint32(k), _p(out)))
+    return out
+
+
+def find_nn(v, k: int, tree_points, include_self: bool):
+    """`nn::find_nn(v, k, ball_tree, include_self)` (nn.rs:63-83); the "tree" is the point set itself."""
+    v, t = _f64(np.atleast_2d(v)), _f64(np.atleast_2d(tree_points))
+    if v.shape[1] != t.shape[1]:
+        raise ScanrsError(1, "Dimension mismatch")
+    out = np.zeros((v.shape[0], k), dtype=np.uint32)
+    _check(_lib.scanrs_find_nn(_p(v), ctypes.c_uint64(v.shape[0]), _p(t), ctypes.c_uint64(t.shape[0]), ctypes.c_uint32(v.shape[1]),
+                               ctypes.c_uint32(k), ctypes.c_int(1 if include_self else 0), _p(out)))
+    return out
+
+
 class AdaptiveVecDesc(ctypes.Structure):
     """`scanrs_adaptive_vec` (include/scanrs_amd.h): one sqz::AdaptiveVec by its encoded buffers."""
     _fields_ = [("kind", ctypes.c_uint32), ("len", ctypes.c_uint64), ("n_units", ctypes.c_uint64), ("data", ctypes.c_void_p),
@@ -636,7 +656,7 @@ def host_sym_eig_topk(a, k):
 
 
 EXPORTED_SYMBOLS = [
-    "scanrs_last_error", "scanrs_device_available", "scanrs_version", "scanrs_mat_create", "scanrs_mat_create_device", "scanrs_mat_create_adaptive",
+    "scanrs_last_error", "scanrs_device_available", "scanrs_version", "scanrs_mat_create", "scanrs_mat_create_device", "scanrs_mat_create_adaptive", "scanrs_knn", "scanrs_find_nn",
     "scanrs_mat_free", "scanrs_mat_view", "scanrs_mat_t", "scanrs_mat_shape", "scanrs_mat_nnz", "scanrs_mat_storage",
     "scanrs_mat_reset_map", "scanrs_mat_compose_scale_axis", "scanrs_mat_apply", "scanrs_mat_set_offset",
     "scanrs_mat_center", "scanrs_mat_scale", "scanrs_mat_scale_and_center", "scanrs_mat_sum_axis_u32",

@@ -918,6 +918,23 @@ int scanrs_omega_fill(uint64_t seed, uint64_t count, double *out) {
     });
 }
 
+// ---- nearest neighbours (scan-rs/src/nn.rs) ------------------------------------------------------------------------------
+int scanrs_knn(const double *points, uint64_t n, uint32_t d, uint32_t k, uint32_t *out) {
+    return guard([&] {
+        if ((!points && n) || (!out && n && k)) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        need_device();
+        knn_host(points, n, points, n, d, k, true, out);
+    });
+}
+int scanrs_find_nn(const double *queries, uint64_t n_q, const double *points, uint64_t n_p, uint32_t d, uint32_t k, int include_self,
+                   uint32_t *out) {
+    return guard([&] {
+        if ((!queries && n_q) || (!points && n_p) || (!out && n_q && k)) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        need_device();
+        knn_host(queries, n_q, points, n_p, d, k, include_self == 0, out);
+    });
+}
+
 // ---- multi-GPU ----------------------------------------------------------------------------------------------------
 int scanrs_mat_set_shard(scanrs_mat *m, uint32_t rank, uint32_t world, uint64_t outer_begin, uint64_t outer_global,
                          scanrs_allreduce_fn allreduce, void *ctx) {
