@@ -77,6 +77,11 @@ const char *scanrs_version(void);
  * (AbsIter semantics, sqz/src/vec.rs:113). The map is MatrixIntoMap. */
 int scanrs_mat_create(uint64_t rows, uint64_t cols, int storage, const uint64_t *indptr, const uint32_t *indices,
                       const uint32_t *values, scanrs_mat **out);
+/* The reader's fallback for 10x matrix files whose indices are not sorted within a cell
+ * (`new_from_unsorted_csc`, hdf5-io/src/matrix.rs:66-75): same as scanrs_mat_create, but every outer vector is first
+ * sorted by index on the device. Repeated indices inside one vector are still an error. */
+int scanrs_mat_create_unsorted(uint64_t rows, uint64_t cols, int storage, const uint64_t *indptr, const uint32_t *indices,
+                               const uint32_t *values, scanrs_mat **out);
 /* Same, the triplet already lives in device memory (copied, not adopted). */
 int scanrs_mat_create_device(uint64_t rows, uint64_t cols, int storage, const uint64_t *d_indptr,
                              const uint32_t *d_indices, const uint32_t *d_values, scanrs_mat **out);

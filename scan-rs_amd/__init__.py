@@ -192,8 +192,9 @@ class AdaptiveMat:
 
     # -- constructors ----------------------------------------------------------------
     @staticmethod
-    def from_csmat(rows: int, cols: int, storage: int, indptr, indices, data) -> "AdaptiveMat":
-        """`AdaptiveMat::from_csmat` (mat.rs:92-124): host indptr(u64) / indices(u32) / data(u32)."""
+    def from_csmat(rows: int, cols: int, storage: int, indptr, indices, data, unsorted: bool = False) -> "AdaptiveMat":
+        """`AdaptiveMat::from_csmat` (mat.rs:92-124): host indptr(u64) / indices(u32) / data(u32).
+        unsorted=True: indices may be in any order inside an outer vector (hdf5-io/src/matrix.rs:66-75 fallback)."""
         indptr = np.ascontiguousarray(indptr, dtype=np.uint64)
         indices = np.ascontiguousarray(indices, dtype=np.uint32)
         data = np.ascontiguousarray(data, dtype=np.uint32)
@@ -203,10 +204,8 @@ class AdaptiveMat:
         if indices.shape[0] != data.shape[0] or (indptr.shape[0] and int(indptr[-1]) != indices.shape[0]):
             raise ScanrsError(6, "indices/data length does not match indptr")
         h = ctypes.c_void_p()
-        _check(
-            _lib.scanrs_mat_create(
-                ctypes.c_uint64(rows), ctypes.c_uint64(cols), ctypes.c_int(storage), _p(indptr), _p(indices), _p(data),
-                ctypes.byref(h)))
+        fn = _lib.scanrs_mat_create_unsorted if unsorted else _lib.scanrs_mat_create
+        _check(fn(ctypes.c_uint64(rows), ctypes.c_uint64(cols), ctypes.c_int(storage), _p(indptr), _p(indices), _p(data), ctypes.byref(h)))
         return AdaptiveMat(h.value)
 
     @staticmethod
@@ -656,7 +655,7 @@ def host_sym_eig_topk(a, k):
 
 
 EXPORTED_SYMBOLS = [
-    "scanrs_last_error", "scanrs_device_available", "scanrs_version", "scanrs_mat_create", "scanrs_mat_create_device", "scanrs_mat_create_adaptive", "scanrs_knn", "scanrs_find_nn",
+    "scanrs_last_error", "scanrs_device_available", "scanrs_version", "scanrs_mat_create", "scanrs_mat_create_unsorted", "scanrs_mat_create_device", "scanrs_mat_create_adaptive", "scanrs_knn", "scanrs_find_nn",
     "scanrs_mat_free", "scanrs_mat_view", "scanrs_mat_t", "scanrs_mat_shape", "scanrs_mat_nnz", "scanrs_mat_storage",
     "scanrs_mat_reset_map", "scanrs_mat_compose_scale_axis", "scanrs_mat_apply", "scanrs_mat_set_offset",
     "scanrs_mat_center", "scanrs_mat_scale", "scanrs_mat_scale_and_center", "scanrs_mat_sum_axis_u32",

@@ -223,7 +223,7 @@ static std::shared_ptr<DevBuf<double>> upload_vec(Storage &st, const double *h, 
 }
 
 static void create_common(uint64_t rows, uint64_t cols, int storage, const uint64_t *indptr, const uint32_t *indices,
-                          const uint32_t *values, bool device_src, scanrs_mat **out) {
+                          const uint32_t *values, bool device_src, scanrs_mat **out, bool sort_first = false) {
     if (!out) fail(SCANRS_ERR_ARGUMENT, "null output handle");
     *out = nullptr;
     need_device();
@@ -262,6 +262,7 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
         SCANRS_HIP(hipMemcpy(cp.indices.p, indices, cp.nnz * 4, kind));
         SCANRS_HIP(hipMemcpy(cp.values.p, values, cp.nnz * 4, kind));
     }
+    if (sort_first) sort_outer_vectors(*st, cp);
     uint64_t zeros = 0, bad = 0;
     validate_copy(*st, cp, &zeros, &bad);
     if (bad) fail(SCANRS_ERR_ARGUMENT, "indices must be in range and strictly ascending within each outer vector (%llu violations)", (unsigned long long)bad);
@@ -463,6 +464,10 @@ const char *scanrs_version(void) { return "scanrs_amd 0.1.0 (gfx950)"; }
 int scanrs_mat_create(uint64_t rows, uint64_t cols, int storage, const uint64_t *indptr, const uint32_t *indices,
                       const uint32_t *values, scanrs_mat **out) {
     return guard([&] { create_common(rows, cols, storage, indptr, indices, values, false, out); });
+}
+int scanrs_mat_create_unsorted(uint64_t rows, uint64_t cols, int storage, const uint64_t *indptr, const uint32_t *indices,
+                               const uint32_t *values, scanrs_mat **out) {
+    return guard([&] { create_common(rows, cols, storage, indptr, indices, values, false, out, true); });
 }
 int scanrs_mat_create_device(uint64_t rows, uint64_t cols, int storage, const uint64_t *d_indptr, const uint32_t *d_indices,
                              const uint32_t *d_values, scanrs_mat **out) {

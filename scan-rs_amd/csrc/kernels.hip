@@ -1699,6 +1699,28 @@ void compact_nonzeros(Storage &st, SparseCopy &cp) {
     (void)st;
 }
 
+// Sorts (index, count) pairs by index inside every outer vector: the repair the reference applies to 10x matrix files
+// whose indices are unsorted within a cell (`new_from_unsorted_csc`, hdf5-io/src/matrix.rs:66-75).
+void sort_outer_vectors(Storage &st, SparseCopy &cp) {
+    if (cp.nnz == 0) return;
+    if (cp.nnz > 0xFFFFFFFFull || cp.n_outer > 0xFFFFFFFFull) fail(SCANRS_ERR_SHAPE, "unsorted input beyond 2^32-1 nonzeros is not supported");
+    DevBuf<uint32_t> keys_out, vals_out;
+    keys_out.alloc(cp.nnz);
+    vals_out.alloc(cp.nnz);
+    uint32_t end_bit = 1;
+    while (end_bit < 32u && (cp.n_inner >> end_bit) != 0) end_bit++;
+    size_t tmp_bytes = 0;
+    SCANRS_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, cp.indices.p, keys_out.p, cp.values.p, vals_out.p, (unsigned)cp.nnz,
+                                                   (unsigned)cp.n_outer, cp.indptr.p, cp.indptr.p + 1, 0u, end_bit, st.stream));
+    DevBuf<unsigned char> tmp;
+    tmp.alloc(tmp_bytes ? tmp_bytes : 1);
+    SCANRS_HIP(rocprim::segmented_radix_sort_pairs(tmp.p, tmp_bytes, cp.indices.p, keys_out.p, cp.values.p, vals_out.p, (unsigned)cp.nnz,
+                                                   (unsigned)cp.n_outer, cp.indptr.p, cp.indptr.p + 1, 0u, end_bit, st.stream));
+    SCANRS_HIP(hipMemcpyAsync(cp.indices.p, keys_out.p, cp.nnz * 4, hipMemcpyDeviceToDevice, st.stream));
+    SCANRS_HIP(hipMemcpyAsync(cp.values.p, vals_out.p, cp.nnz * 4, hipMemcpyDeviceToDevice, st.stream));
+    SCANRS_HIP(hipStreamSynchronize(st.stream));
+}
+
 void build_transposed_copy(Storage &st, const SparseCopy &src, SparseCopy &dst) {
     dst.n_outer = src.n_inner;
     dst.n_inner = src.n_outer;

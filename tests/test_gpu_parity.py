@@ -580,6 +580,31 @@ def test_map_logarithms_within_2_ulp(sa, fn, ref):
     assert np.all(got[arg == 1.0] == 0.0)
 
 
+def test_unsorted_indices_are_repaired_like_the_reader_fallback(sa):
+    """hdf5-io/src/matrix.rs:66-75: matrix files with unsorted indices inside a cell go through
+    `new_from_unsorted_csc`; scanrs_mat_create_unsorted sorts every outer vector on the device."""
+    rng = np.random.default_rng(31)
+    dense = random_counts(rng, 60, 900, 0.15, 50)
+    dense[7, :] = 0
+    ip, ix, vv = [0], [], []
+    for r in range(dense.shape[0]):
+        c = np.nonzero(dense[r])[0]
+        c = c[rng.permutation(len(c))]  # any order
+        ix.extend(c.tolist())
+        vv.extend(dense[r, c].tolist())
+        ip.append(len(ix))
+    for storage in (sa.CSR, sa.CSC):
+        rows, cols = (60, 900) if storage == sa.CSR else (900, 60)
+        with pytest.raises(sa.ScanrsError):
+            sa.AdaptiveMat.from_csmat(rows, cols, storage, ip, ix, vv)  # the strict constructor refuses it
+        g = sa.AdaptiveMat.from_csmat(rows, cols, storage, ip, ix, vv, unsorted=True)
+        want = dense if storage == sa.CSR else dense.T
+        assert np.array_equal(g.to_dense().astype(np.uint32), want)
+    # a repeated index inside one vector stays an error
+    with pytest.raises(sa.ScanrsError):
+        sa.AdaptiveMat.from_csmat(1, 10, sa.CSR, [0, 3], [4, 2, 4], [1, 1, 1], unsorted=True)
+
+
 @pytest.mark.parametrize("path", [1, 2])
 def test_bksvd_through_each_product_kernel(sa, path):
     m = _synth(2500, 600, 0.06, 1)
