@@ -416,10 +416,6 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
         c.sync();
         progress_check(snoop, (double)i / (double)n_iter * 0.8);
     }
-    if (reuse) {
-        Tick tk("bk: last block product");
-        mat_apply(m, to_t_transpose, P, ldb, b, T + (size_t)(n_iter - 1) * b, ldq);
-    }
     // Q = qr(K).Q: block i is already orthonormal; orthogonalise it against blocks < i.
     std::vector<double> cfull((size_t)q * q, 0.0);
     for (uint32_t i = 0; i < q; i++) cfull[(size_t)i * q + i] = 1.0;
@@ -453,6 +449,11 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
             if (!(colmax[j] < cmax_limit)) bad.push_back(j);
         if (trace_on()) {
             fprintf(stderr, "[scanrs trace] bk: %zu of %u projection columns recomputed directly\n", bad.size(), q);
+            for (uint32_t blk = 0; blk < n_iter; blk++) {
+                int cnt = 0;
+                for (uint32_t j = blk * b; j < (blk + 1) * b; j++) cnt += !(colmax[j] < cmax_limit);
+                fprintf(stderr, "[scanrs trace] bk:   block %u: %d\n", blk, cnt);
+            }
             for (double thr : {1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10}) {
                 int cnt = 0;
                 for (uint32_t j = 0; j < q; j++) cnt += !(colmax[j] < thr);
@@ -460,12 +461,36 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
             }
         }
     }
+    // The last Krylov block: its half-product op(A) K_{n-1} exists only to feed T'_{n-1}. When (as on every matrix
+    // measured: the newest block is where the numerical dependence shows) most of that block is recomputed directly
+    // anyway, computing ALL of it directly — in the same sparse pass as the other bad columns — costs no more
+    // 128-column passes than the half-product plus the repair pass, and usually one fewer.
+    bool last_direct = false;
+    if (reuse) {
+        const uint32_t last_lo = (n_iter - 1) * b;
+        uint32_t bad_other = 0;
+        for (uint32_t j : bad) bad_other += j < last_lo;
+        auto chunks = [](uint32_t x) { return (x + 127u) / 128u; };
+        const uint32_t cost_half = chunks(b) + chunks((uint32_t)bad.size()), cost_direct = chunks(b + bad_other);
+        last_direct = cost_direct <= cost_half && n_iter >= 2;
+        if (last_direct) {
+            std::vector<uint32_t> merged;
+            for (uint32_t j : bad)
+                if (j < last_lo) merged.push_back(j);
+            for (uint32_t j = last_lo; j < q; j++) merged.push_back(j);
+            bad.swap(merged);
+        } else {
+            Tick tk("bk: last block product");
+            mat_apply(m, to_t_transpose, P, ldb, b, T + (size_t)(n_iter - 1) * b, ldq);
+        }
+        if (trace_on()) fprintf(stderr, "[scanrs trace] bk: last block %s\n", last_direct ? "computed directly with the repair pass" : "through its half-product");
+    }
     {
         Tick tk("bk: projection");
-        if (reuse && bad.size() * 2 < q) {
+        if (reuse && (bad.size() * 2 < q || last_direct)) {
             // in place, last block first: T'_j = T[:, 0:(j+1)b] * C[0:(j+1)b, block j]
             std::vector<double> W;
-            for (uint32_t j = n_iter - 1; j >= 1; j--) {
+            for (uint32_t j = n_iter - 1 - (last_direct ? 1u : 0u); j >= 1; j--) {
                 const uint32_t nr = (j + 1) * b;
                 W.assign((size_t)nr * b, 0.0);
                 for (uint32_t r = 0; r < nr; r++)
