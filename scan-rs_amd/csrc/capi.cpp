@@ -118,10 +118,18 @@ Profile::~Profile() {
 // ---- Storage -------------------------------------------------------------------------------------
 Storage::~Storage() {
     if (host_stage) (void)hipHostFree(host_stage);
+    if (aux_stream) {
+        (void)hipStreamSynchronize(aux_stream);
+        (void)hipStreamDestroy(aux_stream);
+    }
     if (stream) {
         (void)hipStreamSynchronize(stream);
         (void)hipStreamDestroy(stream);
     }
+}
+hipStream_t Storage::aux() {
+    if (!aux_stream) SCANRS_HIP(hipStreamCreate(&aux_stream));
+    return aux_stream;
 }
 SparseCopy &Storage::copy_with_outer_rows(bool outer_rows) {
     const bool primary_outer_rows = storage == SCANRS_CSR;

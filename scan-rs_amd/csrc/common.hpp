@@ -177,6 +177,8 @@ struct Storage {
     SparseCopy other; // the transposed orientation, built on first use
     bool has_other = false;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr; // small dense work that overlaps a sparse pass (svd_bk's cross-block orthogonalisation)
+    hipStream_t aux();
     Scratch scratch;
     // GF(2) jump tables of the device-side seeded-panel generator (solver.cpp / omega_jump_kernel)
     DevBuf<uint64_t> jump_tab;

@@ -185,6 +185,21 @@ struct Ctx {
     }
 };
 
+// Everything launched through the handle inside the scope goes to `other` (kernels, scratch zero-fills, events);
+// the host thread is the only user of the handle, so this is a plain save / restore.
+struct StreamSwap {
+    Storage &st;
+    hipStream_t saved, saved_scratch;
+    StreamSwap(Storage &s, hipStream_t other) : st(s), saved(s.stream), saved_scratch(s.scratch.stream) {
+        st.stream = other;
+        st.scratch.stream = other;
+    }
+    ~StreamSwap() {
+        st.stream = saved;
+        st.scratch.stream = saved_scratch;
+    }
+};
+
 // upload a compact host matrix (rows x l) into a padded device panel
 static void upload_panel(Ctx &c, const double *h, uint64_t rows, uint32_t l, double *d, uint32_t ld) {
     if (rows == 0 || l == 0) return;
@@ -404,34 +419,49 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
     // and T' = (op(A) K) C with Q = K C (C small, tracked on the host through the orthonormalisation).
     const bool reuse = (b % 2u) == 0u;
     double *T = c.dev("bk_T", (size_t)dt * ldq);
+    // Q = qr(K).Q: block i is already orthonormal; orthogonalise it against blocks < i (in block order), tracking
+    // Q = K C in `cfull`
+    std::vector<double> cfull((size_t)q * q, 0.0);
+    for (uint32_t i = 0; i < q; i++) cfull[(size_t)i * q + i] = 1.0;
+    double *Bj = c.dev("bk_Bj", (size_t)ds * ldb);
+    double *Btmp = c.dev("bk_Btmp", (size_t)ds * ldb);
+    uint32_t next_block = 1;
+    auto orth_block_on = [&](Ctx &cx, uint32_t i) {
+        std::vector<double> coef((size_t)q * b, 0.0);
+        launch_copy_cols(cx.st, K + (size_t)i * b, ldq, Bj, ldb, ds, b);
+        for (uint32_t j = 0; j < b; j++) coef[(size_t)(i * b + j) * b + j] = 1.0;
+        orth_against(cx, K, ldq, i * b, Bj, Btmp, ldb, b, ds, false, &coef, &cfull, q);
+        launch_copy_cols(cx.st, Bj, ldb, K + (size_t)i * b, ldq, ds, b);
+        for (uint32_t r = 0; r < q; r++)
+            for (uint32_t j = 0; j < b; j++) cfull[(size_t)r * q + i * b + j] = coef[(size_t)r * b + j];
+        next_block = i + 1;
+    };
+    auto orth_block = [&](uint32_t i) { // on the auxiliary stream, finished (host-synchronised) on return
+        StreamSwap sw(c.st, c.st.aux());
+        Ctx cx(m);
+        orth_block_on(cx, i);
+        cx.sync();
+    };
     for (uint32_t i = 0; i < n_iter; i++) {
         Tick tk("bk: iteration");
         // m >= n: B = qr((A B)^T A)^T .Q  (bk_svd.rs:94);  n > m: T = (B A)^T; B = qr(A T).Q^T  (bk_svd.rs:122-123)
         double *Yi = (reuse && i >= 1) ? T + (size_t)(i - 1) * b : Y;
         const uint32_t ldy = (reuse && i >= 1) ? ldq : ldb;
         mat_apply(m, to_t_transpose, P, ldb, b, Yi, ldy);
+        // Q = qr(K).Q block by block: block i-1 is complete since the end of the previous iteration, so it is made
+        // orthogonal to blocks < i-1 now, on the auxiliary stream, while the sparse pass just queued occupies the
+        // main one (host round trips of the small factorizations hidden behind ~40 ms of gather work).
+        if (i >= 2) orth_block(i - 1);
         mat_apply(m, !to_t_transpose, Yi, ldy, b, P, ldb);
         orth_cholqr(c, P, Ptmp, ldb, b, ds, false);
         launch_copy_cols(c.st, P, ldb, K + (size_t)i * b, ldq, ds, b);
         c.sync();
         progress_check(snoop, (double)i / (double)n_iter * 0.8);
     }
-    // Q = qr(K).Q: block i is already orthonormal; orthogonalise it against blocks < i.
-    std::vector<double> cfull((size_t)q * q, 0.0);
-    for (uint32_t i = 0; i < q; i++) cfull[(size_t)i * q + i] = 1.0;
+    // the last block (and everything, when there was no iteration to hide behind) on the main stream
     {
         Tick tk("bk: orth(K)");
-        double *Bj = c.dev("bk_Bj", (size_t)ds * ldb);
-        std::vector<double> coef;
-        for (uint32_t i = 1; i < n_iter; i++) {
-            launch_copy_cols(c.st, K + (size_t)i * b, ldq, Bj, ldb, ds, b);
-            coef.assign((size_t)q * b, 0.0);
-            for (uint32_t j = 0; j < b; j++) coef[(size_t)(i * b + j) * b + j] = 1.0;
-            orth_against(c, K, ldq, i * b, Bj, Ptmp, ldb, b, ds, false, &coef, &cfull, q);
-            launch_copy_cols(c.st, Bj, ldb, K + (size_t)i * b, ldq, ds, b);
-            for (uint32_t r = 0; r < q; r++)
-                for (uint32_t j = 0; j < b; j++) cfull[(size_t)r * q + i * b + j] = coef[(size_t)r * b + j];
-        }
+        for (uint32_t i = next_block; i < n_iter; i++) orth_block_on(c, i);
         c.sync();
     }
     progress_check(snoop, 0.82);
