@@ -2,7 +2,7 @@
 //
 // The reference builds a ball tree (ball_tree crate) over the rows of a cells x d matrix and asks it for the k+1
 // nearest points of every row, dropping the row itself. Same result here by exhaustive search: one thread per
-// query (its d coordinates in registers), the point set streamed through LDS in tiles, the squared distance as the
+// query (its d coordinates in registers), the candidate point wave-uniform in SGPRs (scalar loads), the squared distance as the
 // reference forms it (sum of squared differences, nn.rs:14-21 — not the |p|^2 + |q|^2 - 2 p.q expansion, whose
 // cancellation would reorder near neighbours), a sorted k-list per thread in private memory. f64 vector FMA bound:
 // n_q x n x d multiply-adds. Ties keep ascending index order (the rule of the reference's own test oracle,
@@ -23,8 +23,6 @@ template <int DMAX, int THREADS>
 __global__ __launch_bounds__(THREADS) void knn_kernel(const double *__restrict__ queries, uint64_t n_q, const double *__restrict__ points,
                                                      uint64_t n_p, uint32_t d, uint32_t k, int skip_same_index,
                                                      uint32_t *__restrict__ out) {
-    constexpr uint32_t TP = 4096u / DMAX; // points per LDS tile (32 KB)
-    __shared__ double tile[TP * DMAX];
     const uint64_t qi = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
     const bool live = qi < n_q;
     double q[DMAX];
@@ -34,48 +32,52 @@ __global__ __launch_bounds__(THREADS) void knn_kernel(const double *__restrict__
     uint32_t best_i[KMAX];
     uint32_t have = 0;
     double worst = DBL_MAX; // distance a candidate has to beat once the list is full
-    for (uint64_t p0 = 0; p0 < n_p; p0 += TP) {
-        const uint32_t np = (uint32_t)min((uint64_t)TP, n_p - p0);
-        __syncthreads();
-        for (uint32_t e = threadIdx.x; e < TP * DMAX; e += THREADS) {
-            const uint32_t pp = e / DMAX, j = e % DMAX;
-            tile[e] = (pp < np && j < d) ? points[(p0 + pp) * d + j] : 0.0;
-        }
-        __syncthreads();
-        if (!live) continue;
-        for (uint32_t pp = 0; pp < np; pp++) {
-            const double *__restrict__ pt = tile + pp * DMAX;
-            double s = 0.0;
+    // `points` is the (n_p x DMAX) zero-padded copy: the candidate's coordinates are wave-uniform, so they arrive through
+    // the scalar cache into SGPRs (s_load_dwordx16) and every lane's VALU work is just subtract + fma per coordinate
+    for (uint64_t pi = 0; pi < n_p; pi++) {
+        const double *__restrict__ pt = points + pi * DMAX;
+        double s = 0.0;
 #pragma unroll
-            for (int j = 0; j < DMAX; j++) {
-                const double t = pt[j] - q[j];
-                s = fma(t, t, s);
-            }
-            const uint64_t pi = p0 + pp;
-            if (skip_same_index && pi == qi) continue;
-            if (have == k && !(s < worst)) continue;
-            // sorted insertion; equal distances stay in index order because candidates arrive in index order
-            uint32_t pos = have < k ? have : k - 1u;
-            while (pos > 0 && best_d[pos - 1] > s) {
-                best_d[pos] = best_d[pos - 1];
-                best_i[pos] = best_i[pos - 1];
-                pos--;
-            }
-            best_d[pos] = s;
-            best_i[pos] = (uint32_t)pi;
-            if (have < k) have++;
-            if (have == k) worst = best_d[k - 1];
+        for (int j = 0; j < DMAX; j++) {
+            const double t = pt[j] - q[j];
+            s = fma(t, t, s);
         }
+        if (!live || (skip_same_index && pi == qi)) continue;
+        if (have == k && !(s < worst)) continue;
+        // sorted insertion; equal distances stay in index order because candidates arrive in index order
+        uint32_t pos = have < k ? have : k - 1u;
+        while (pos > 0 && best_d[pos - 1] > s) {
+            best_d[pos] = best_d[pos - 1];
+            best_i[pos] = best_i[pos - 1];
+            pos--;
+        }
+        best_d[pos] = s;
+        best_i[pos] = (uint32_t)pi;
+        if (have < k) have++;
+        if (have == k) worst = best_d[k - 1];
     }
     if (!live) return;
     for (uint32_t i = 0; i < k; i++) out[qi * k + i] = i < have ? best_i[i] : 0xFFFFFFFFu; // T::max_value() padding, nn.rs:66
 }
 
+__global__ void pad_points_kernel(const double *__restrict__ src, uint64_t n, uint32_t d, uint32_t dmax, double *__restrict__ dst) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * dmax) return;
+    const uint64_t r = e / dmax;
+    const uint32_t j = (uint32_t)(e % dmax);
+    dst[e] = j < d ? src[r * d + j] : 0.0;
+}
+
 template <int DMAX, int THREADS>
 void launch(const double *dq, uint64_t n_q, const double *dp, uint64_t n_p, uint32_t d, uint32_t k, int skip, uint32_t *dout,
             hipStream_t s) {
+    DevBuf<double> padded;
+    padded.alloc(n_p * DMAX ? n_p * DMAX : 1);
+    if (n_p)
+        hipLaunchKernelGGL(pad_points_kernel, dim3((unsigned)((n_p * DMAX + 255) / 256)), dim3(256), 0, s, dp, n_p, d, (uint32_t)DMAX, padded.p);
     const dim3 grid((unsigned)((n_q + THREADS - 1) / THREADS)), block(THREADS);
-    hipLaunchKernelGGL((knn_kernel<DMAX, THREADS>), grid, block, 0, s, dq, n_q, dp, n_p, d, k, skip, dout);
+    hipLaunchKernelGGL((knn_kernel<DMAX, THREADS>), grid, block, 0, s, dq, n_q, padded.p, n_p, d, k, skip, dout);
+    SCANRS_HIP(hipStreamSynchronize(s)); // `padded` is released on return
 }
 
 } // namespace
