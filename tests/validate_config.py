@@ -2,7 +2,7 @@
 synthetic matrix and the SAME start panel.  Default = configs[1]: 100k cells x 33k genes @ 3 %, top-50 PCA.
 The oracle needs minutes of one host core at this size, so this is a script (result quoted in DESIGN.md), not a test.
 
-    python tools/validate_config.py [cells] [genes] [density] [k]
+    python tests/validate_config.py [cells] [genes] [density] [k]
 """
 import os
 import sys
