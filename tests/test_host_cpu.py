@@ -42,11 +42,17 @@ def test_no_cpu_fallback_without_device(sa):
 
 
 def test_product_path_never_imports_the_oracle():
-    for dirpath, _, files in os.walk(os.path.join(ROOT, "scan-rs_amd")):
-        for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
-                txt = open(os.path.join(dirpath, f), errors="replace").read()
-                assert "scanrs_oracle" not in txt and "liboracle" not in txt, f
+    names = ("scanrs_oracle", "liboracle", "import adaptive_vec", "knn_oracle", "oracle/")  # everything under oracle/
+    for top in ("scan-rs_amd", "tools", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                    txt = open(os.path.join(dirpath, f), errors="replace").read()
+                    assert not any(n in txt for n in names), f
+    # bench.py may touch the oracle in its cpu_baseline leg only
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    first = bench.index("scanrs_oracle")
+    assert "no_cpu_baseline" in bench[bench.rfind("\n    if ", 0, first):first]
 
 
 def test_host_cholesky_and_inverse(sa):
