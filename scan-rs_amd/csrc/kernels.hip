@@ -1364,6 +1364,22 @@ static void launch_spmm_2d_f32(Storage &st, SparseCopy &cp, const DevMap &map, c
     SCANRS_HIP(hipGetLastError());
 }
 
+// Xs[i, :] = a[i] * X[i, :] (a trailing inner-indexed ScaleAxis of the map folded into the gathered panel)
+__global__ void scale_rows_kernel(const double *__restrict__ X, uint32_t ldx, uint64_t rows, uint32_t l, const double *__restrict__ a,
+                                  double *__restrict__ Xs) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * ldx) return;
+    const uint64_t r = e / ldx;
+    const uint32_t c = (uint32_t)(e % ldx);
+    Xs[e] = c < l ? a[r] * X[e] : 0.0;
+}
+void launch_scale_rows(Storage &st, const double *X, uint32_t ldx, uint64_t rows, uint32_t l, const double *a, double *Xs) {
+    if (rows == 0) return;
+    ProfScope ps(st, "scale_rows", (double)rows * l * 16.0);
+    hipLaunchKernelGGL(scale_rows_kernel, grid1(rows * ldx, 256), dim3(256), 0, st.stream, X, ldx, rows, l, a, Xs);
+    SCANRS_HIP(hipGetLastError());
+}
+
 void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
                      double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw) {
     const bool want_2d = st.spmm_path == 2 || (st.spmm_path == 0 && cp.nnz >= st.blocked_min_nnz && l >= 16);
