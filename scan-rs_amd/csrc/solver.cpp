@@ -442,6 +442,34 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
         orth_block_on(cx, i);
         cx.sync();
     };
+    // T'_j = (op(A) K)[:, 0:(j+1)b] * C[0:(j+1)b, block j] for the blocks whose coefficients are known before the end: a
+    // dense MFMA GEMM queued on the auxiliary stream behind the pass that delivers the last half-product it reads, so it
+    // runs beside the next (gather-bound) sparse pass. Out of place (S): later blocks still need the half-products in T.
+    const uint32_t n_early = (reuse && n_iter >= 3) ? n_iter - 2 : 0; // blocks 1 .. n_iter-2
+    const uint32_t ld_s = even_up(std::max(1u, n_early * b));
+    double *S = n_early ? c.dev("bk_S", (size_t)dt * ld_s) : nullptr;
+    struct Ev {
+        hipEvent_t e = nullptr;
+        Ev() { SCANRS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
+        ~Ev() { (void)hipEventDestroy(e); }
+    } ev_pass, ev_proj;
+    std::vector<char> projected(n_iter, 0);
+    auto project_block_early = [&](uint32_t j) { // T block j (written by the pass just queued on the main stream) is ready at ev_pass
+        const uint32_t nr = (j + 1) * b;
+        std::vector<double> W((size_t)nr * b);
+        for (uint32_t r = 0; r < nr; r++)
+            for (uint32_t cc = 0; cc < b; cc++) W[(size_t)r * b + cc] = cfull[(size_t)r * q + j * b + cc];
+        StreamSwap sw(c.st, c.st.aux());
+        Ctx cx(m);
+        char key[32];
+        snprintf(key, sizeof(key), "bk_projw%u", j);
+        double *dW = cx.dev(key, (size_t)nr * b);
+        cx.h2d(dW, W.data(), W.size());
+        SCANRS_HIP(hipStreamWaitEvent(cx.s, ev_pass.e, 0));
+        launch_gemm_nn(cx.st, T, ldq, nr, dW, b, b, dt, 1.0, 0.0, nullptr, 0, S + (size_t)(j - 1) * b, ld_s);
+        SCANRS_HIP(hipEventRecord(ev_proj.e, cx.s));
+        projected[j] = 1;
+    };
     for (uint32_t i = 0; i < n_iter; i++) {
         Tick tk("bk: iteration");
         // m >= n: B = qr((A B)^T A)^T .Q  (bk_svd.rs:94);  n > m: T = (B A)^T; B = qr(A T).Q^T  (bk_svd.rs:122-123)
@@ -451,7 +479,13 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
         // Q = qr(K).Q block by block: block i-1 is complete since the end of the previous iteration, so it is made
         // orthogonal to blocks < i-1 now, on the auxiliary stream, while the sparse pass just queued occupies the
         // main one (host round trips of the small factorizations hidden behind ~40 ms of gather work).
-        if (i >= 2) orth_block(i - 1);
+        if (i >= 2) {
+            orth_block(i - 1);
+            if (n_early && i - 1 <= n_early) {
+                SCANRS_HIP(hipEventRecord(ev_pass.e, c.s)); // after the pass that wrote T block i-1
+                project_block_early(i - 1);
+            }
+        }
         mat_apply(m, !to_t_transpose, Yi, ldy, b, P, ldb);
         orth_cholqr(c, P, Ptmp, ldb, b, ds, false);
         launch_copy_cols(c.st, P, ldb, K + (size_t)i * b, ldq, ds, b);
@@ -521,6 +555,7 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
             // in place, last block first: T'_j = T[:, 0:(j+1)b] * C[0:(j+1)b, block j]
             std::vector<double> W;
             for (uint32_t j = n_iter - 1 - (last_direct ? 1u : 0u); j >= 1; j--) {
+                if (projected[j]) continue; // done early, waiting in S
                 const uint32_t nr = (j + 1) * b;
                 W.assign((size_t)nr * b, 0.0);
                 for (uint32_t r = 0; r < nr; r++)
@@ -529,6 +564,13 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
                 c.h2d(dW, W.data(), W.size());
                 launch_gemm_nn(c.st, T, ldq, nr, dW, b, b, dt, 1.0, 0.0, nullptr, 0, Y, ldb);
                 launch_copy_cols(c.st, Y, ldb, T + (size_t)j * b, ldq, dt, b);
+            }
+            bool any_early = false;
+            for (uint32_t j = 1; j < n_iter; j++) any_early = any_early || projected[j];
+            if (any_early) {
+                SCANRS_HIP(hipStreamWaitEvent(c.s, ev_proj.e, 0)); // the last early GEMM (they are ordered on the auxiliary stream)
+                for (uint32_t j = 1; j < n_iter; j++)
+                    if (projected[j]) launch_copy_cols(c.st, S + (size_t)(j - 1) * b, ld_s, T + (size_t)j * b, ldq, dt, b);
             }
             if (!bad.empty()) {
                 const uint32_t nbad = (uint32_t)bad.size(), ldbad = even_up(nbad);
@@ -542,6 +584,9 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
                 launch_permute_cols(c.st, Tbad, ldbad, T, ldq, dt, d_idx, nbad, true);
             }
         } else {
+            bool any_early = false;
+            for (uint32_t j = 1; j < n_iter; j++) any_early = any_early || projected[j];
+            if (any_early) SCANRS_HIP(hipStreamWaitEvent(c.s, ev_proj.e, 0)); // they read T, which is overwritten now
             mat_apply(m, to_t_transpose, K, ldq, q, T, ldq);
         }
         c.sync();
