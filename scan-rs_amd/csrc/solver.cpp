@@ -487,6 +487,10 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
             }
         }
         mat_apply(m, !to_t_transpose, Yi, ldy, b, P, ldb);
+        if (trace_on()) { // separate the wait for the two passes from the factorization in the trace
+            Tick tw("  passes (wait)");
+            c.sync();
+        }
         orth_cholqr(c, P, Ptmp, ldb, b, ds, false);
         launch_copy_cols(c.st, P, ldb, K + (size_t)i * b, ldq, ds, b);
         c.sync();
