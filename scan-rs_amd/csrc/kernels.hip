@@ -78,9 +78,9 @@ __device__ __forceinline__ double map_log10(double x) {
 
 constexpr int SCAN_U = 4; // strides of 64 nonzeros in flight per trip of the scan-like passes (SpMV, sums, moments)
 
-__device__ __forceinline__ double eval_map(const DevMap &m, uint32_t v, uint32_t outer, uint32_t inner) {
-    double x = (double)v;
-    for (int i = 0; i < m.n; i++) {
+// the chain from link `start` on, applied to x
+__device__ __forceinline__ double eval_map_from(const DevMap &m, int start, double x, uint32_t outer, uint32_t inner) {
+    for (int i = start; i < m.n; i++) {
         const DevOp &op = m.ops[i];
         switch (op.kind) {
         case OP_SCALE_AXIS:
@@ -122,6 +122,29 @@ __device__ __forceinline__ double eval_map(const DevMap &m, uint32_t v, uint32_t
         }
     }
     return x;
+}
+__device__ __forceinline__ double eval_map(const DevMap &m, uint32_t v, uint32_t outer, uint32_t inner) {
+    return eval_map_from(m, 0, (double)v, outer, inner);
+}
+// A chain that STARTS with a ScaleAxis indexed by the outer position (the barcode scale while walking a cell's vector)
+// multiplies every count of the vector by the same number: it is read once per vector instead of once per nonzero per
+// link evaluation (same product, same rounding).
+struct RowMap {
+    int start;
+    double pre;
+};
+__device__ __forceinline__ RowMap row_map(const DevMap &m, uint32_t outer) {
+    RowMap r;
+    r.start = 0;
+    r.pre = 1.0;
+    if (m.n > 0 && m.ops[0].kind == OP_SCALE_AXIS && m.ops[0].a_outer) {
+        r.start = 1;
+        r.pre = m.ops[0].a[outer];
+    }
+    return r;
+}
+__device__ __forceinline__ double eval_map(const DevMap &m, const RowMap &rm, uint32_t v, uint32_t outer, uint32_t inner) {
+    return eval_map_from(m, rm.start, rm.start ? rm.pre * (double)v : (double)v, outer, inner);
 }
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -188,6 +211,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const uint32_t *__rest
     const uint64_t start = ((uint64_t)rfl((uint32_t)(it.start >> 32)) << 32) | rfl((uint32_t)it.start);
     const uint32_t *__restrict__ ind = indices + start;
     const uint32_t *__restrict__ val = values + start;
+    const RowMap rm = row_map(map, row);
 
     uint32_t col[NACC], lcol[NACC];
     bool act[NACC];
@@ -207,7 +231,7 @@ __global__ __launch_bounds__(256) void spmm_gather_kernel(const uint32_t *__rest
         if (p < len) {
             idx = ind[p];
             if constexpr (sizeof(T) == 8) {
-                f = eval_map(map, val[p], row, idx);
+                f = eval_map(map, rm, val[p], row, idx);
             } else {
                 f = val[p];
             }
@@ -325,6 +349,7 @@ __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
     const uint64_t base = indptr[row64] + o0;
     const uint32_t *__restrict__ ind = indices + base;
     const uint32_t *__restrict__ val = values + base;
+    const RowMap rm = row_map(map, row);
 
     uint32_t col[NACC], lcol[NACC];
     bool act[NACC];
@@ -343,7 +368,7 @@ __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
         double f = 0.0;
         if (p < len) {
             idx = ind[p];
-            f = eval_map(map, val[p], row, idx);
+            f = eval_map(map, rm, val[p], row, idx);
         }
         const uint32_t n = min(64u, len - c);
         // Lanes that own no column sit out the whole gather loop (one exec mask around it, v_readlane still sees
@@ -441,6 +466,7 @@ __global__ __launch_bounds__(256) void spmm_gather2d_f32_kernel(
     const uint64_t base = indptr[row64] + o0;
     const uint32_t *__restrict__ ind = indices + base;
     const uint32_t *__restrict__ val = values + base;
+    const RowMap rm = row_map(map, row);
     const uint32_t half = lane >> 5, sub = lane & 31u;
     const uint32_t col = sub * 4u;
     const bool act = col < l;
@@ -459,7 +485,7 @@ __global__ __launch_bounds__(256) void spmm_gather2d_f32_kernel(
         double f = 0.0;
         if (p < len) {
             idx = ind[p];
-            f = eval_map(map, val[p], row, idx);
+            f = eval_map(map, rm, val[p], row, idx);
         }
         const uint32_t n = min(64u, len - c);
         // lanes past the chunk hold idx 0 / f 0, so an odd tail simply adds 0 * row 0 in the upper half
@@ -560,6 +586,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(const uint32_t *__restrict__ 
     const Item it = items[wid];
     const uint32_t *__restrict__ ind = indices + it.start;
     const uint32_t *__restrict__ val = values + it.start;
+    const RowMap rm = row_map(map, it.row);
     double s0 = 0.0, s1 = 0.0;
     // SCAN_U strides of the vector per trip, every load of a trip issued before the first use (clamped position instead
     // of a branch): one round trip to memory per 4 x 64 nonzeros instead of two per 64 — these passes are latency-bound
@@ -582,7 +609,7 @@ __global__ __launch_bounds__(256) void spmv_kernel(const uint32_t *__restrict__ 
         }
 #pragma unroll
         for (int u = 0; u < SCAN_U; u++) {
-            const double f = eval_map(map, vv[u], it.row, g[u]);
+            const double f = eval_map(map, rm, vv[u], it.row, g[u]);
             s0 = ok[u] ? fma(f, x0[u], s0) : s0;
             if (l > 1) s1 = ok[u] ? fma(f, x1[u], s1) : s1;
         }
@@ -605,16 +632,25 @@ __global__ __launch_bounds__(256) void spmv_kernel(const uint32_t *__restrict__ 
     }
 }
 
+__global__ void interleave_kernel(const double *__restrict__ x2, const double *__restrict__ a, uint64_t n, double *__restrict__ z) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    z[2 * i] = x2[2 * i]; // the vector sits in slot 0 of its even-ld rows
+    z[2 * i + 1] = a[i];
+}
+
 // Blocked sparse x vector: the gathered vector (and any inner-indexed scale of the map) is walked in slices that stay
 // L2-resident, exactly as row_reduce2d_kernel does for the moments — a straight pass over a gene-major copy turns every
 // nonzero into a 64-byte miss on the 8 MB barcode-indexed vector. `order` lists the vectors longest first.
 __global__ __launch_bounds__(256) void spmv2d_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
                                                      const uint32_t *__restrict__ values, const uint32_t *__restrict__ bounds,
                                                      uint32_t nb, uint32_t b0, uint32_t b1, int first, int last, uint64_t n_outer,
-                                                     const uint32_t *__restrict__ order, DevMap map, const double *__restrict__ X,
-                                                     uint32_t ldx, uint32_t l, double *__restrict__ out, uint32_t ldo,
-                                                     const double *__restrict__ off_a, uint32_t rank,
+                                                     const uint32_t *__restrict__ order, DevMap map, int fused_scale,
+                                                     const double *__restrict__ X, uint32_t ldx, uint32_t l, double *__restrict__ out,
+                                                     uint32_t ldo, const double *__restrict__ off_a, uint32_t rank,
                                                      const double *__restrict__ off_w, uint32_t ldw) {
+    // fused_scale (l == 1 only): X is the vector interleaved with the operand of the map's first link, an inner-indexed
+    // ScaleAxis — (x[i], a[i]) in the two slots of the even-ld row — so ONE 16-byte gather per nonzero brings both
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t slot = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     if (slot >= n_outer) return;
@@ -624,6 +660,7 @@ __global__ __launch_bounds__(256) void spmv2d_kernel(const uint64_t *__restrict_
     const bool epilogue = last && rank > 0;
     if (len == 0 && !first && !epilogue) return;
     const uint64_t base = indptr[row] + o0;
+    const RowMap rm = row_map(map, (uint32_t)row);
     double s0 = 0.0, s1 = 0.0;
     for (uint32_t p0 = lane; p0 < len; p0 += 64u * SCAN_U) {
         uint32_t g[SCAN_U], vv[SCAN_U];
@@ -637,6 +674,20 @@ __global__ __launch_bounds__(256) void spmv2d_kernel(const uint64_t *__restrict_
             vv[u] = values[q];
         }
         double x0[SCAN_U], x1[SCAN_U];
+        if (fused_scale) {
+#pragma unroll
+            for (int u = 0; u < SCAN_U; u++) {
+                const d2 z = *reinterpret_cast<const d2 *>(X + (size_t)g[u] * 2u);
+                x0[u] = z.x;
+                x1[u] = z.y; // a[inner]
+            }
+#pragma unroll
+            for (int u = 0; u < SCAN_U; u++) {
+                const double f = eval_map_from(map, 1, x1[u] * (double)vv[u], (uint32_t)row, g[u]);
+                s0 = ok[u] ? fma(f, x0[u], s0) : s0;
+            }
+            continue;
+        }
 #pragma unroll
         for (int u = 0; u < SCAN_U; u++) {
             x0[u] = X[(size_t)g[u] * ldx];
@@ -644,7 +695,7 @@ __global__ __launch_bounds__(256) void spmv2d_kernel(const uint64_t *__restrict_
         }
 #pragma unroll
         for (int u = 0; u < SCAN_U; u++) {
-            const double f = eval_map(map, vv[u], (uint32_t)row, g[u]);
+            const double f = eval_map(map, rm, vv[u], (uint32_t)row, g[u]);
             s0 = ok[u] ? fma(f, x0[u], s0) : s0;
             if (l > 1) s1 = ok[u] ? fma(f, x1[u], s1) : s1;
         }
@@ -667,6 +718,62 @@ __global__ __launch_bounds__(256) void spmv2d_kernel(const uint64_t *__restrict_
     }
 }
 
+// Sparse x vector on the LONG side (10^6 cell vectors against a gene-indexed vector of a few hundred KB): the vector is
+// too big for one LDS and, gathered from L2, costs one 64-line vector-memory instruction per 64 nonzeros. It is cut into
+// <= 144 KB parts (whole bounds tiles); a 16-wave workgroup stages one part in LDS, walks its share of the outer vectors
+// through it (ds_read_b64 gathers), and carries the partial sums through `out` between parts.
+__global__ __launch_bounds__(1024) void spmv_lds_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                        const uint32_t *__restrict__ values, const uint32_t *__restrict__ bounds,
+                                                        uint32_t nb, uint32_t tiles_per_part, uint32_t n_parts, uint64_t n_outer,
+                                                        uint64_t rows_per_block, DevMap map, const double *__restrict__ X, uint32_t ldx,
+                                                        uint64_t n_inner, double *__restrict__ out, uint32_t ldo,
+                                                        const double *__restrict__ off_a, uint32_t rank,
+                                                        const double *__restrict__ off_w, uint32_t ldw) {
+    extern __shared__ double xs[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_block, r1 = min(n_outer, r0 + rows_per_block);
+    const uint32_t part_len = tiles_per_part << BT_SHIFT;
+    for (uint32_t p = 0; p < n_parts; p++) {
+        const uint64_t g0 = (uint64_t)p * part_len;
+        const uint32_t glen = (uint32_t)min((uint64_t)part_len, n_inner - g0);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < glen; i += 1024u) xs[i] = X[(g0 + i) * ldx];
+        __syncthreads();
+        const uint32_t b0 = p * tiles_per_part, b1 = min(nb, b0 + tiles_per_part);
+        for (uint64_t row = r0 + wave; row < r1; row += 16u) {
+            const uint32_t *__restrict__ bd = bounds + row * (nb + 1);
+            const uint32_t o0 = bd[b0], len = bd[b1] - o0;
+            const uint64_t base = indptr[row] + o0;
+            const RowMap rm = row_map(map, (uint32_t)row);
+            double s0 = 0.0;
+            for (uint32_t q0 = lane; q0 < len; q0 += 64u * SCAN_U) {
+                uint32_t g[SCAN_U], vv[SCAN_U];
+                bool ok[SCAN_U];
+#pragma unroll
+                for (int u = 0; u < SCAN_U; u++) {
+                    const uint32_t q = q0 + 64u * u;
+                    ok[u] = q < len;
+                    const uint64_t e = base + (ok[u] ? q : len - 1u);
+                    g[u] = indices[e];
+                    vv[u] = values[e];
+                }
+#pragma unroll
+                for (int u = 0; u < SCAN_U; u++) {
+                    const double f = eval_map(map, rm, vv[u], (uint32_t)row, g[u]);
+                    s0 = ok[u] ? fma(f, xs[g[u] - (uint32_t)g0], s0) : s0;
+                }
+            }
+            s0 = wave_sum(s0);
+            if (lane == 0) {
+                if (p > 0) s0 += out[row * ldo];
+                if (p + 1 == n_parts)
+                    for (uint32_t q = 0; q < rank; q++) s0 += off_a[row * rank + q] * off_w[(size_t)q * ldw];
+                out[row * ldo] = s0;
+            }
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void row_reduce_kernel(const uint32_t *__restrict__ indices,
                                                          const uint32_t *__restrict__ values,
@@ -680,6 +787,7 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(const uint32_t *__restr
     const Item it = items[wid];
     const uint32_t *__restrict__ ind = indices + it.start;
     const uint32_t *__restrict__ val = values + it.start;
+    const RowMap rm = row_map(map, it.row);
     if constexpr (MODE == 0) {
         uint32_t s = 0;
         for (uint32_t p = lane; p < it.len; p += 64u) s += val[p];
@@ -705,7 +813,7 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(const uint32_t *__restr
             }
 #pragma unroll
             for (int u = 0; u < SCAN_U; u++) {
-                const double x = eval_map(map, vv[u], it.row, g[u]);
+                const double x = eval_map(map, rm, vv[u], it.row, g[u]);
                 s = ok[u] ? s + x : s;
                 if constexpr (MODE == 2) s2 = ok[u] ? fma(x, x, s2) : s2;
             }
@@ -742,6 +850,7 @@ __global__ __launch_bounds__(256) void row_reduce2d_kernel(const uint64_t *__res
     const uint32_t o0 = bd[b0], len = bd[b1] - o0;
     if (len == 0 && !first) return;
     const uint64_t base = indptr[row] + o0;
+    const RowMap rm = row_map(map, (uint32_t)row);
     double s = 0.0, s2 = 0.0;
     for (uint32_t p0 = lane; p0 < len; p0 += 64u * SCAN_U) {
         uint32_t g[SCAN_U], vv[SCAN_U];
@@ -756,7 +865,7 @@ __global__ __launch_bounds__(256) void row_reduce2d_kernel(const uint64_t *__res
         }
 #pragma unroll
         for (int u = 0; u < SCAN_U; u++) {
-            const double x = eval_map(map, vv[u], (uint32_t)row, g[u]);
+            const double x = eval_map(map, rm, vv[u], (uint32_t)row, g[u]);
             s = ok[u] ? s + x : s;
             if constexpr (MODE == 2) s2 = ok[u] ? fma(x, x, s2) : s2;
         }
@@ -1402,13 +1511,45 @@ void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const doubl
             if (ordered) ensure_order(st, cp);
             const dim3 grid((unsigned)((cp.n_outer + 3) / 4)), block(256);
             const double bytes = ((double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)(cp.n_inner + cp.n_outer) * l * 8.0) / steps;
+            // the map's first link reads a[inner] per nonzero (the barcode scale): pair it with x[inner] in one 16-byte slot
+            const bool fuse = l == 1 && ldx == 2 && map.n >= 1 && map.ops[0].kind == OP_SCALE_AXIS && !map.ops[0].a_outer;
+            const double *Xk = X;
+            if (fuse) {
+                double *z = st.scratch.get<double>("spmv_z", (size_t)cp.n_inner * 2);
+                hipLaunchKernelGGL(interleave_kernel, grid1(cp.n_inner, 256), block, 0, st.stream, X, map.ops[0].a, cp.n_inner, z);
+                Xk = z;
+            }
             for (uint32_t sidx = 0; sidx < steps; sidx++) {
                 const uint32_t b0 = sidx * m, b1 = std::min(nb, b0 + m);
                 ProfScope ps(st, long_outer ? "spmv2d_kernel/long-outer" : "spmv2d_kernel/short-outer", bytes);
                 hipLaunchKernelGGL(spmv2d_kernel, grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p, cp.bounds.p, nb, b0, b1,
-                                   sidx == 0 ? 1 : 0, sidx + 1 == steps ? 1 : 0, cp.n_outer, ordered ? cp.order.p : nullptr, map, X, ldx, l, out,
-                                   ldo, off_a, rank, off_w, ldw);
+                                   sidx == 0 ? 1 : 0, sidx + 1 == steps ? 1 : 0, cp.n_outer, ordered ? cp.order.p : nullptr, map, fuse ? 1 : 0, Xk,
+                                   ldx, l, out, ldo, off_a, rank, off_w, ldw);
             }
+            SCANRS_HIP(hipGetLastError());
+            return;
+        }
+        static const bool lds_ok = !(getenv("SCANRS_SPMV_LDS") && atoi(getenv("SCANRS_SPMV_LDS")) == 0);
+        if (lds_ok && l == 1 && st.spmm_path != 1 && cp.nnz >= st.blocked_min_nnz && cp.n_outer >= (1ull << 16) && cp.n_inner >= 8192 &&
+            cp.n_inner <= 8u * 18432u) {
+            // vector of 64 KB .. 1.1 MB against many outer vectors: LDS-staged parts
+            const uint32_t nb = ensure_bounds(st, cp);
+            const uint32_t n_parts = (uint32_t)((cp.n_inner + 18431) / 18432);
+            const uint32_t tiles_per_part = (uint32_t)(((cp.n_inner + n_parts - 1) / n_parts + (1u << BT_SHIFT) - 1) >> BT_SHIFT);
+            const size_t shmem = ((size_t)tiles_per_part << BT_SHIFT) * 8;
+            static bool attr_set = false;
+            if (!attr_set) {
+                SCANRS_HIP(hipFuncSetAttribute((const void *)spmv_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_set = true;
+            }
+            int dev = 0, n_cu = 256;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+            const uint32_t n_blocks = (uint32_t)std::min<uint64_t>((uint64_t)n_cu * 4u, (cp.n_outer + 15) / 16);
+            const uint64_t rows_per_block = (cp.n_outer + n_blocks - 1) / n_blocks;
+            ProfScope ps(st, "spmv_lds_kernel/long-outer", (double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)(cp.n_inner + cp.n_outer) * 8.0);
+            hipLaunchKernelGGL(spmv_lds_kernel, dim3(n_blocks), dim3(1024), shmem, st.stream, cp.indptr.p, cp.indices.p, cp.values.p, cp.bounds.p, nb,
+                               tiles_per_part, n_parts, cp.n_outer, rows_per_block, map, X, ldx, cp.n_inner, out, ldo, off_a, rank, off_w, ldw);
             SCANRS_HIP(hipGetLastError());
             return;
         }

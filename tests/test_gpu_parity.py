@@ -605,6 +605,37 @@ def test_unsorted_indices_are_repaired_like_the_reader_fallback(sa):
         sa.AdaptiveMat.from_csmat(1, 10, sa.CSR, [0, 3], [4, 2, 4], [1, 1, 1], unsorted=True)
 
 
+def test_lds_staged_spmv_matches_plain_and_oracle(sa):
+    """The other Ix1 product of IRLBA: many outer vectors against a vector of a few hundred KB, staged through LDS in
+    parts (3 here) with the partial sums carried through the output; against the plain kernel and the oracle."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(9)
+    rows, cols, nnz = 70_000, 40_000, 4_700_000
+    r = rng.integers(0, rows, size=nnz)
+    c = rng.integers(0, cols, size=nnz)
+    m = sp.csr_matrix((rng.integers(1, 9, size=nnz).astype(np.uint32), (r, c)), shape=(rows, cols))
+    m.sum_duplicates()
+    m.sort_indices()
+    fr, fc = rng.random(rows) + 0.5, rng.random(cols) + 0.5
+    u, v = rng.standard_normal((rows, 1)), rng.standard_normal((1, cols))
+    x = rng.standard_normal(cols)
+    outs = []
+    for path in (1, 0):
+        g = sa.AdaptiveMat.from_csmat(rows, cols, sa.CSR, m.indptr, m.indices, m.data)
+        g.set_spmm_path(path)
+        g.compose_scale_axis(0, fr).apply(sa.FN_LOG2_1P).compose_scale_axis(1, fc)  # outer scale, log, inner scale (folded)
+        g.set_offset(u, v)
+        y = g.dot(x)
+        assert np.array_equal(y, g.dot(x))
+        outs.append(np.ravel(y))
+    o = so.AdaptiveMat(rows, cols, so.CSR, m.indptr, m.indices, m.data)
+    o = o.compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=0, a=fr)).apply(so.OP_LOG2_1P).compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=1, a=fc))
+    ref = so.LowRankOffset(o, u, v).dot(x.reshape(-1, 1)).ravel()
+    for y in outs:
+        assert_close(y, ref, rtol=1e-10, atol=1e-8)
+
+
 @pytest.mark.parametrize("path", [1, 2])
 def test_bksvd_through_each_product_kernel(sa, path):
     m = _synth(2500, 600, 0.06, 1)
