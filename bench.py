@@ -223,7 +223,7 @@ def main():
         achieved = st["algorithmic_bytes"] / (st["total_ms"] * 1e-3) / 1e9 if st["total_ms"] > 0 else 0.0
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes (profiles/, separate --pmc runs), headline workload only
-            with open(os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")) as f:
                 pm = json.load(f)["kernels"].get(name)
             if pm and args.cells == 1_000_000 and args.genes == 33_000 and world == 1:
                 traffic = round(pm["hbm_bytes_per_launch_corrected"])
