@@ -33,6 +33,21 @@ def test_library_exports_every_header_symbol(sa):
     assert declared == set(sa.EXPORTED_SYMBOLS)
 
 
+def test_headers_are_plain_c99_and_cxx17(tmp_path):
+    """The boundary is a C ABI: scanrs_amd.h must go through a C compiler untouched, the mirror through a C++17 one."""
+    inc = os.path.join(ROOT, "include")
+    c_src = tmp_path / "t.c"
+    c_src.write_text('#include "scanrs_amd.h"\nint main(void) { scanrs_adaptive_vec v; v.kind = 0; return (int)v.kind + SCANRS_OK; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(c_src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cc_src = tmp_path / "t.cpp"
+    cc_src.write_text('#include "scanrs_amd.hpp"\nint main() { scanrs::BkSvd b; return b.n_iter == 5 ? 0 : 1; }\n')
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc, str(cc_src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_no_cpu_fallback_without_device(sa):
     if sa.device_available():
         pytest.skip("a GPU is present")
