@@ -120,6 +120,15 @@ def main():
         verdict["u_abs"] = float(np.max(np.abs(u * sign - u_ref)))
         verdict["v_abs"] = float(np.max(np.abs(v * sign - v_ref[lo:hi])))
         verdict["v_rows"] = int(v.shape[0])
+        # the randomized driver on the same shards (rand_svd.rs:54-129): Omega given explicitly, l = max(k + 4, 10 k)
+        l = max(k + 4, 10 * k)
+        om = so.omega_panel((l, n_genes), 1)
+        ur, sr, vr = sa.RandSvd().run_pca(g, k, omega=om)
+        uo, s_o, vo = so.RandSvd().run_pca(so.normalize(full, "cellranger"), k, omega=om)
+        verdict["rand_s_rel"] = float(np.max(np.abs(sr - s_o) / s_o))
+        sign = np.sign(np.sum(ur * uo, axis=0))
+        verdict["rand_u_abs"] = float(np.max(np.abs(ur * sign - uo)))
+        verdict["rand_v_abs"] = float(np.max(np.abs(vr * sign - vo[lo:hi])))
     with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
         json.dump(verdict, f)
     dist.barrier()

@@ -152,6 +152,7 @@ def test_world2_sharded_c_abi_on_one_gpu(tmp_path):
     for v in vs:
         assert v["v_rows"] == 600
         assert v["s_rel"] < 1e-8 and v["u_abs"] < 1e-6 and v["v_abs"] < 1e-6, v
+        assert v["rand_s_rel"] < 1e-8 and v["rand_u_abs"] < 1e-6 and v["rand_v_abs"] < 1e-6, v
 
 
 @pytest.mark.gpu
@@ -163,6 +164,7 @@ def test_rccl_hook_serves_the_exchange_steps(tmp_path):
     for v in _run_world2("nccl", tmp_path, world=world):
         assert v["v_rows"] == 1200 // world
         assert v["s_rel"] < 1e-8 and v["u_abs"] < 1e-6 and v["v_abs"] < 1e-6, v
+        assert v["rand_s_rel"] < 1e-8 and v["rand_u_abs"] < 1e-6 and v["rand_v_abs"] < 1e-6, v
 
 
 def _bench_line(extra_env, launcher, tmp_path, gpus):
