@@ -74,6 +74,10 @@ def main():
         import torch.distributed as dist_mod
 
         dist = dist_mod
+        # the image exports NCCL_DEBUG=VERSION, and RCCL prints that banner with printf on stdout in every rank — stdout
+        # carries the ONE JSON line, so the banner level (only that one) is switched off; INFO/TRACE etc. are left alone
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = ""
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if shared_gpu:
