@@ -3,18 +3,25 @@
 
 One "step" = one pass of the hot path over the whole matrix already resident in HBM:
 reset the lazy map -> normalize(CellRanger) -> BkSvd{2.0, 5}.run_pca(k), through the C ABI
-(include/scanrs_amd.h).  Default workload = BASELINE.json configs[2]: 1M cells x 33k genes @ 3 % nnz,
-k = 50, on 1 GPU; with --gpus N the same global matrix is range-partitioned over the ranks by cells
-(strong scaling; one process per GPU, torch.distributed/RCCL all-reduce supplied to the library as a
-callback).  Rank 0 prints ONE JSON line.
+(include/scanrs_amd.h). Default workload = BASELINE.json configs[2]: 1M cells x 33k genes @ 3 % nnz, k = 50, 1 GPU.
 
-Also reported:  roofline  — HBM roofline of the dominant kernel (the gather SpMM), algorithmic bytes per
-launch / average launch duration measured with HIP events on the library's stream; cpu_baseline — the
-CPU oracle (port of the reference's serial schedule) timed on a bounded sample on rank 0, N = 1 only.
+`python bench.py --gpus N` works as typed: with N > 1 and no WORLD_SIZE in the environment it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child BEFORE anything touches the GPU and relays
+rank 0's JSON line; under torchrun (the driver's form) every rank takes LOCAL_RANK's GPU. The same global matrix is
+range-partitioned over the ranks by nonzeros (scanrs_plan_shards; strong scaling); the exchange steps run inside the
+library (RCCL over xGMI, `scanrs_comm_*`), torch.distributed (gloo) is only the control plane (id broadcast, barriers,
+max over ranks). Rank 0 prints ONE JSON line.
+
+`value` is the device-resident rate (U and V left in HBM, reachable through scanrs_pca_result_device);
+`config.host_delivered_cells_per_s` is the rate of a step that also copies U and V to host arrays, as the reference's
+run_pca signature returns them. Also reported: roofline — HBM roofline of the dominant kernel, algorithmic bytes per
+launch / average launch duration measured with HIP events on the library's stream; cpu_baseline — the CPU oracle
+(port of the reference's serial schedule) on 1 core and on all cores, bounded samples, rank 0 at N = 1 only.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+PMC_PROFILE = "r02_pmc_traffic.json"  # committed PMC passes (separate --pmc runs) the `traffic` field is read from
 
 
 def parse():
@@ -34,69 +42,161 @@ def parse():
     ap.add_argument("--density", type=float, default=0.03)
     ap.add_argument("--k", type=int, default=50)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--cpu-cells", type=int, default=8000, help="cells of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-cells", type=int, default=16000, help="cells of the 1-core CPU-baseline sample")
+    ap.add_argument("--cpu-cells-all", type=int, default=100000, help="cells of the all-core CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pcie", action="store_true", help="also time one step that copies U and V to the host")
+    ap.add_argument("--no-host-delivery", action="store_true", help="skip the extra step that copies U and V to the host")
     ap.add_argument("--f32-panels", action="store_true",
                     help="opt-in fast mode: gathered panels rounded to f32, f64 sums (NOT the headline configuration)")
     ap.add_argument("--spmm-path", type=int, default=0, help="0 auto, 1 plain gather, 2 L2-blocked gather")
     ap.add_argument("--also-randsvd", action="store_true", help="also time one RandSvd{10, 2} PCA (SURVEY.md §8d: reported alongside)")
     ap.add_argument("--also-irlba", action="store_true",
                     help="also time one Irlba{tol 1e-4, 50} run on the log-normalised (un-centred) matrix, the only input irlba.rs takes")
+    ap.add_argument("--also-knn", type=int, default=0, metavar="K", help="also time scanrs_knn_device (K neighbours) on the device-resident scores")
     ap.add_argument("--force-collective", action="store_true",
-                    help="N=1 only: serve the exchange steps through RCCL (world 1) anyway, to price the hook itself")
+                    help="N=1 only: serve the exchange steps through RCCL (world 1) anyway, to price the transport itself")
     ap.add_argument("--events-in-timed-region", action="store_true",
                     help="record the per-launch HIP events inside the K timed steps instead of in a second pass of K steps")
+    ap.add_argument("--sqz-bench", action="store_true",
+                    help="instead: the reference's only benchmark (sqz/benches/my_benchmark.rs): u32 CSR / CSC 1000 x 10000 times 10000 x 16")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` typed by hand (no torchrun): start the N ranks as a CHILD process group before this
+    process has touched the GPU (never exec after HIP initialisation) and relay their single JSON line."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line:
+        print(line)
+    else:
+        sys.stderr.write(p.stdout)
+    sys.exit(p.returncode if p.returncode else (0 if line else 1))
+
+
+def sqz_bench(args):
+    """sqz/benches/my_benchmark.rs:7-35: `mat_densemat_mult` of a random 1000 x 10000 u32 AdaptiveMat (gen_rand.rs:24-61:
+    every vector keeps Uniform(0, len) index draws from [1, len), deduplicated; values in [1, 50)) with a dense
+    10000 x 16 u32 matrix (values in [0, 100)), once stored CSR and once CSC."""
+    import numpy as np
+
+    import scanrs_amd as sa
+
+    rows, cols, rng_range, cols2 = 1000, 10000, 50, 16
+    rng = np.random.default_rng(0)
+    res = {}
+    for name, storage in (("csr-mul 1k", sa.CSR), ("csc-mul 1k", sa.CSC)):
+        n_outer, n_inner = (rows, cols) if storage == sa.CSR else (cols, rows)
+        ip, ix, vv = [0], [], []
+        for _ in range(n_outer):
+            nnz = int(rng.integers(0, n_inner)) if n_inner else 0
+            idx = np.unique(rng.integers(1, n_inner, size=nnz)) if nnz else np.zeros(0, dtype=np.int64)
+            ix.append(idx.astype(np.uint32))
+            vv.append(rng.integers(1, rng_range, size=idx.shape[0]).astype(np.uint32))
+            ip.append(ip[-1] + idx.shape[0])
+        ip, ix, vv = np.array(ip, dtype=np.uint64), np.concatenate(ix), np.concatenate(vv)
+        m2 = rng.integers(0, 100, size=(cols, cols2)).astype(np.uint32)
+        g = sa.AdaptiveMat.from_csmat(rows, cols, storage, ip, ix, vv)
+        out = g.dot(m2)  # warm (uploads, transposed copy where the kernel wants it)
+        g.profile_reset()
+        g.profile_enable(True)
+        t0 = time.perf_counter()
+        reps = 20
+        for _ in range(reps):
+            out = g.dot(m2)
+        wall = (time.perf_counter() - t0) / reps
+        g.profile_enable(False)
+        prof = g.profile_get()
+        kern = sum(v["total_ms"] for k, v in prof.items() if "spmm" in k or "slab" in k) / reps
+        cpu = None
+        if not args.no_cpu_baseline:  # the CPU port timed beside it (and used as the checker of the device result)
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import scanrs_oracle as so
+
+            o = so.AdaptiveMat(rows, cols, so.CSR if storage == sa.CSR else so.CSC, ip, ix, vv)
+            so.build()
+            t0 = time.perf_counter()
+            ref = o.dot(m2)
+            cpu = time.perf_counter() - t0
+            assert np.array_equal(out, ref), "u32 product differs from the oracle"
+        nnz = int(ip[-1])
+        res[name] = {"nnz": nnz, "gpu_call_ms": round(wall * 1e3, 3), "gpu_kernel_ms": round(kern, 4), "cpu_port_1core_ms": None if cpu is None else round(cpu * 1e3, 2),
+                     "kernel_GBps_algorithmic": round((nnz * 8 + (n_outer + 1) * 8 + (cols + rows) * cols2 * 4) / (kern * 1e-3) / 1e9, 1) if kern > 0 else None}
+    print(json.dumps({"metric": "sqz/benches/my_benchmark.rs mirror: u32 mat_densemat_mult 1000x10000 (x) 10000x16", "unit": "ms per product",
+                      "results": res, "note": "gpu_call_ms includes the host->device copy of the dense operand and the device->host copy of "
+                      "the result (scanrs_mat_dot_u32 takes host pointers as prod.rs takes ArrayViews); bit-exact against the oracle"}))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    # SCANRS_BENCH_SHARED_GPU=1 (tests only): every rank uses GPU 0 and the exchange steps go through gloo on host copies,
-    # so the N > 1 code path can be exercised end to end on a 1-GPU box. Never set by the driver.
+    # SCANRS_BENCH_SHARED_GPU=1 (tests only): every rank uses GPU 0 and the exchange steps go through the host hook on
+    # gloo (RCCL cannot put two ranks on one device), so the N > 1 flow runs end to end on a 1-GPU box. Never set by the driver.
     shared_gpu = os.environ.get("SCANRS_BENCH_SHARED_GPU") == "1"
     if shared_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    red_dev = torch.device("cpu") if shared_gpu else dev
     dist = None
-    if world > 1 or args.force_collective:
+    if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        # the image exports NCCL_DEBUG=VERSION, and RCCL prints that banner with printf on stdout in every rank — stdout
-        # carries the ONE JSON line, so the banner level (only that one) is switched off; INFO/TRACE etc. are left alone
-        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = ""
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if shared_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("gloo", rank=rank, world_size=world)  # control plane only
+    # the image exports NCCL_DEBUG=VERSION and RCCL prints that banner with printf on stdout in every rank — stdout
+    # carries the ONE JSON line, so the banner level (only that one) is switched off; INFO/TRACE etc. are left alone
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = ""
 
     import scanrs_amd as sa
     from scanrs_amd.synth import synth_counts_torch
 
     if not sa.device_available():
         raise SystemExit("bench.py needs a gfx950 device (no CPU fallback)")
+    if args.sqz_bench:
+        return sqz_bench(args)
 
-    # ---- synthetic shard, generated in device memory -------------------------------------------------
+    # ---- synthetic shard, generated in device memory; partition balanced by nonzeros ----------------------------
     from scanrs_amd.dist import shard_bounds
 
     lo, hi = shard_bounds(args.cells, world)[rank]
     t0 = time.time()
     indptr, indices, values = synth_counts_torch(args.cells, args.genes, args.density, args.seed, dev, lo, hi)
+    if world > 1:
+        # scanrs_plan_shards on the global per-cell counts (every rank holds the counts of its equal-count range)
+        counts = (indptr[1:] - indptr[:-1]).cpu()
+        per = (args.cells + world - 1) // world
+        padded = torch.zeros(per, dtype=torch.int64)
+        padded[: counts.shape[0]] = counts
+        gathered = [torch.zeros(per, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(gathered, padded)
+        allc = torch.cat(gathered)[: args.cells].numpy()
+        gip = np.zeros(args.cells + 1, dtype=np.uint64)
+        np.cumsum(allc, out=gip[1:])
+        bounds = sa.plan_shards(gip, world)
+        nlo, nhi = int(bounds[rank]), int(bounds[rank + 1])
+        if (nlo, nhi) != (lo, hi):
+            del indptr, indices, values
+            torch.cuda.empty_cache()
+            lo, hi = nlo, nhi
+            indptr, indices, values = synth_counts_torch(args.cells, args.genes, args.density, args.seed, dev, lo, hi)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     nnz_local = int(indptr[-1].item())
@@ -108,36 +208,40 @@ def main():
     del indptr, indices, values
     torch.cuda.empty_cache()
 
-    if dist is not None:
+    comm = None
+    transport = "none (1 GPU)"
+    if world > 1 and shared_gpu:
         from scanrs_amd.dist import make_allreduce
 
-        mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev, stage_through_host=shared_gpu))
+        mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev, stage_through_host=True))
+        transport = "host hook over gloo (test mode: ranks share one GPU)"
+    elif world > 1 or args.force_collective:
+        uid = [sa.Comm.unique_id() if rank == 0 else None]
+        if dist is not None:
+            dist.broadcast_object_list(uid, src=0)
+        comm = sa.Comm(uid[0], rank, world)
+        mat.set_shard_comm(comm, lo, args.cells)
+        transport = "RCCL all-reduce enqueued by the library on its own stream (scanrs_comm_*)"
 
     if args.f32_panels:
         mat.set_panel_precision(1)
     if args.spmm_path:
         mat.set_spmm_path(args.spmm_path)
     bk = sa.BkSvd()  # k_multiplier 2.0, n_iter 5: the solver scan-rs-cmd uses (tools/src/bin/cmd.rs:70)
-    s_out = np.zeros(args.k)
 
     def step(download=False):
-        import ctypes
-
         mat.reset_map()
         sa.normalize(mat, sa.Normalization.CellRanger)
         if download:
             return bk.run_pca(mat, args.k)
-        sa._check(
-            sa._lib.scanrs_pca_bk(
-                mat._h, ctypes.c_uint32(args.k), ctypes.c_double(bk.k_multiplier), ctypes.c_uint32(bk.n_iter),
-                ctypes.c_uint64(0), None, None, None, s_out.ctypes.data_as(ctypes.c_void_p), None))
-        return None, s_out.copy(), None
+        s, _res = bk.run_pca_device(mat, args.k)
+        return None, s, None
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
         torch.cuda.synchronize()
         mat.sync()
+        if dist is not None:
+            dist.barrier()
 
     # first pass also builds the transposed (gene-major) copy: data layout preparation, part of setup
     step()
@@ -147,7 +251,7 @@ def main():
         step()
     barrier()
     # Timed region: exactly K steps between barriers. The per-launch HIP events that feed the roofline leg put
-    # a marker packet before and after each of the ~1700 launches of a step, which costs a few percent of wall
+    # a marker packet before and after every launch of a step, which costs a few percent of wall
     # time, so by default they are recorded in a second pass of K steps right after the timed one
     # (same inputs, same launches); --events-in-timed-region records them inside the timed steps instead.
     mat.profile_reset()
@@ -159,6 +263,7 @@ def main():
         _, sig, _ = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     events_elapsed = elapsed
     if not args.events_in_timed_region:
         mat.profile_enable(True)
@@ -169,31 +274,56 @@ def main():
         barrier()
         events_elapsed = time.perf_counter() - t0
     mat.profile_enable(False)
+    rank_ms = [elapsed_local / args.steps * 1e3]
     if dist is not None:
-        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        nn = torch.tensor([nnz_local], device=red_dev, dtype=torch.int64)
-        dist.all_reduce(nn)
-        nnz_global = int(nn.item())
+        nn = torch.tensor([nnz_local], dtype=torch.int64)
+        gl = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(gl, nn)
+        nnz_ranks = [int(x.item()) for x in gl]
+        tl = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([rank_ms[0]], dtype=torch.float64))
+        rank_ms = [float(x.item()) for x in tl]
     else:
-        nnz_global = nnz_local
+        nnz_ranks = [nnz_local]
+    nnz_global = sum(nnz_ranks)
     prof = mat.profile_get()
     ms_per_step = elapsed / args.steps * 1e3
     value = args.cells * args.steps / elapsed
 
-    pcie = None
-    if args.pcie:
+    # the factors of the timed steps are reachable: PcaResult in HBM (Missing #4 of the round-1 verdict)
+    res = sa.pca_result_device(mat)
+    v_t = torch.as_tensor(sa.DevArray(res.d_v, n_local * res.ld_v), device=dev).view(n_local, res.ld_v)[:, : res.k]
+    vnorm = (v_t * v_t).sum(dim=0).cpu()
+    if dist is not None:
+        dist.all_reduce(vnorm)
+    v_col_norm_err = float((vnorm - 1.0).abs().max().item())
+
+    host_ms = None
+    if not args.no_host_delivery:
         barrier()
         t0 = time.perf_counter()
         step(download=True)
         barrier()
-        pcie = args.cells / (time.perf_counter() - t0)
+        th = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(th, op=dist.ReduceOp.MAX)
+        host_ms = float(th.item()) * 1e3
+
+    knn_ms = None
+    if args.also_knn and world == 1:
+        barrier()
+        t0 = time.perf_counter()
+        sa.knn_device(res.d_v, n_local, res.ld_v, res.k, args.also_knn)
+        knn_ms = (time.perf_counter() - t0) * 1e3
 
     randsvd_ms = None
     if args.also_randsvd and world == 1:
         import ctypes
 
+        s_out = np.zeros(args.k)
         mat.reset_map()
         sa.normalize(mat, sa.Normalization.CellRanger)
         barrier()
@@ -207,6 +337,7 @@ def main():
     if args.also_irlba and world == 1:
         import ctypes
 
+        s_out = np.zeros(args.k)
         mat.reset_map()
         sa.log_normalize_with_size_factor(mat, None, sa.FN_LOG2_1P)
         mp = ctypes.c_uint32()
@@ -222,15 +353,18 @@ def main():
     # ---- roofline of the dominant kernel -------------------------------------------------------------------
     roof = None
     if prof:
-        dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+        kern = {k: v for k, v in prof.items() if not k.startswith("allreduce")}
+        dom = max(kern.items(), key=lambda kv: kv[1]["total_ms"])
         name, st = dom
         achieved = st["algorithmic_bytes"] / (st["total_ms"] * 1e-3) / 1e9 if st["total_ms"] > 0 else 0.0
-        traffic = None
+        traffic = traffic_src = None
         try:  # HBM bytes per launch from the committed PMC passes (profiles/, separate --pmc runs), headline workload only
-            with open(os.path.join(ROOT, "profiles", "r01h_pmc_traffic.json")) as f:
-                pm = json.load(f)["kernels"].get(name)
+            with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as f:
+                pj = json.load(f)
+            pm = pj["kernels"].get(name)
             if pm and args.cells == 1_000_000 and args.genes == 33_000 and world == 1:
                 traffic = round(pm["hbm_bytes_per_launch_corrected"])
+                traffic_src = f"profiles/{PMC_PROFILE} (committed rocprofv3 --pmc passes of this command, commit {pj.get('commit', '?')}; NOT measured in this run)"
         except (OSError, ValueError, KeyError):
             traffic = None
         roof = {
@@ -241,49 +375,71 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": traffic,
+            "traffic_source": traffic_src,
             "launches_per_step": st["launches"] / args.steps,
             "avg_launch_ms": round(st["total_ms"] / max(1, st["launches"]), 4),
             "algorithmic_bytes_per_launch": round(st["algorithmic_bytes"] / max(1, st["launches"])),
             # the product is bound by the on-chip gather of panel rows (L2 -> CU), not by HBM: DESIGN.md §4.
             # ceiling: 16.8-18.8 TB/s chip-wide for L2-resident indexed rows (MI355X_MICROARCH.md, "Indexed rows")
             "onchip_gather": {
-                "achieved_TBps": round(st["onchip_gather_bytes"] / (st["total_ms"] * 1e-3) / 1e12, 2) if st["total_ms"] > 0 else None,
+                "achieved_TBps": round(st["onchip_gather_bytes"] / (st["total_ms"] * 1e-3) / 1e12, 2) if st["total_ms"] > 0 and st["onchip_gather_bytes"] else None,
                 "ceiling_TBps": 17.8,
                 "bytes_per_launch": round(st["onchip_gather_bytes"] / max(1, st["launches"])),
             },
             "kernel_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
+            "launches_per_step_all": {k: round(v["launches"] / args.steps, 1) for k, v in sorted(prof.items())},
             "events_pass_ms_per_step": round(events_elapsed / args.steps * 1e3, 2),
         }
 
-    # ---- CPU baseline: the oracle (single thread, the reference's serial schedule) on a bounded sample --------
+    # ---- CPU baseline: the oracle (the reference's serial schedule) on bounded samples: 1 core, then all cores -------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import scanrs_oracle as so
         from threadpoolctl import threadpool_limits
 
-        nc = min(args.cpu_cells, args.cells)
-        ip, ix, vv = synth_counts_torch(args.cells, args.genes, args.density, args.seed, dev, 0, nc)
-        ip, ix, vv = ip.cpu().numpy().astype(np.uint64), ix.cpu().numpy().astype(np.uint32), vv.cpu().numpy().astype(np.uint32)
         so.build()
-        with threadpool_limits(limits=1):
-            t0 = time.perf_counter()
-            om = so.AdaptiveMat(args.genes, nc, so.CSC, ip, ix, vv)
-            a = so.normalize(om, "cellranger")
-            so.BkSvd().run_pca(a, min(args.k, nc))
-            t_cpu = time.perf_counter() - t0
+        nproc = os.cpu_count() or 1
+
+        def cpu_run(nc, threads):
+            ip, ix, vv = synth_counts_torch(args.cells, args.genes, args.density, args.seed, dev, 0, nc)
+            ip, ix, vv = ip.cpu().numpy().astype(np.uint64), ix.cpu().numpy().astype(np.uint32), vv.cpu().numpy().astype(np.uint32)
+            so.set_threads(threads)
+            try:
+                with threadpool_limits(limits=threads):
+                    t0 = time.perf_counter()
+                    om = so.AdaptiveMat(args.genes, nc, so.CSC, ip, ix, vv)
+                    a = so.normalize(om, "cellranger")
+                    so.BkSvd().run_pca(a, min(args.k, nc))
+                    return time.perf_counter() - t0
+            finally:
+                so.set_threads(1)
+
+        nc1 = min(args.cpu_cells, args.cells)
+        t1 = cpu_run(nc1, 1)
         cpu = {
-            "value": round(nc / t_cpu, 2),
+            "value": round(nc1 / t1, 2),
             "unit": "cells/s",
             "cores": 1,
             "kind": "port",
-            "sample": f"first {nc} cells of the same synthetic matrix ({args.genes} genes, {args.density:.0%} nnz), "
-                      f"normalize(CellRanger) + BkSvd k={min(args.k, nc)}, oracle C loops + LAPACK pinned to 1 thread, {t_cpu:.1f} s",
+            "host_cores_available": nproc,
+            "sample": f"first {nc1} cells of the same synthetic matrix ({args.genes} genes, {args.density:.0%} nnz), "
+                      f"normalize(CellRanger) + BkSvd k={min(args.k, nc1)}, oracle C loops + LAPACK pinned to 1 thread "
+                      f"(the reference is single-threaded with sequential MKL), {t1:.1f} s",
         }
+        if nproc > 1:
+            nca = min(args.cpu_cells_all, args.cells)
+            ta = cpu_run(nca, nproc)
+            cpu["all_cores"] = {
+                "value": round(nca / ta, 2), "unit": "cells/s", "cores": nproc, "kind": "port",
+                "sample": f"first {nca} cells, same schedule with the sparse loops dealt over {nproc} OpenMP threads "
+                          f"(scatter loops through per-thread output copies) and LAPACK on {nproc} threads, {ta:.1f} s",
+            }
 
     if rank == 0:
+        ar_ms = sum(v["total_ms"] for k, v in prof.items() if k.startswith("allreduce")) / args.steps if prof else 0.0
         out = {
-            "metric": "cells/sec for top-50 PCA on 1M x 33k @3% nnz; achieved HBM GB/s vs roofline",
+            "metric": f"cells/sec for top-{args.k} PCA on {args.cells}x{args.genes} @{args.density:.0%} nnz; achieved HBM GB/s vs roofline",
             "value": round(value, 1),
             "unit": "cells/s",
             "n_gpus": world,
@@ -299,23 +455,37 @@ def main():
                 "workload": f"{args.cells} cells x {args.genes} genes, {args.density:.0%} nnz synthetic sqz CSC, "
                             f"normalize(CellRanger) + BkSvd(k_multiplier=2, n_iter=5) top-{args.k} PCA",
                 "nnz": nnz_global,
-                "parallelism": f"cells range-partitioned over {world} GPU(s)" + (", all-reduce per product" if world > 1 else ""),
+                "parallelism": f"cells range-partitioned by nonzeros over {world} GPU(s)" + (", one sum all-reduce per contracting product" if world > 1 else ""),
+                "transport": transport,
+                "result_delivery": "value: U, V left in HBM (scanrs_pca_result_device); host_delivered_*: the same step with U, V copied to host arrays",
+                "v_col_norm_err_device_result": v_col_norm_err,
                 "setup_s": round(t_setup, 2),
+                "setup_includes": "upload, first normalize + PCA, and building the transposed (gene-major) copy of the matrix: both orientations stay in HBM (2 x 8 B per nonzero + bounds tables)",
                 "datagen_s": round(t_gen, 2),
                 "sigma_top3": [round(float(x), 6) for x in (sig[:3] if sig is not None else [])],
+                "per_rank_ms_per_step": [round(x, 2) for x in rank_ms],
+                "per_rank_nnz": nnz_ranks,
+                "allreduce_ms_per_step_rank0": round(ar_ms, 3),
             },
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        if pcie is not None:
-            out["config"]["pcie_inclusive_cells_per_s"] = round(pcie, 1)
+        if host_ms is not None:
+            out["config"]["host_delivered_cells_per_s"] = round(args.cells / (host_ms * 1e-3), 1)
+            out["config"]["host_delivered_ms_per_step"] = round(host_ms, 2)
+        if knn_ms is not None:
+            out["config"][f"knn{args.also_knn}_device_scores_ms"] = round(knn_ms, 1)
         if randsvd_ms is not None:
             out["config"]["randsvd_l10_it2_ms"] = round(randsvd_ms, 1)
         if irlba_ms is not None:
             out["config"]["irlba_tol1e-4_ms"] = round(irlba_ms, 1)
             out["config"]["irlba_matrix_products"] = irlba_mprod
         print(json.dumps(out))
+    del mat
+    if comm is not None:
+        comm.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -216,6 +216,13 @@ int scanrs_pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_i
  * null -> seeded normal. mprod (may be null) receives the "number of matrix products" (irlba.rs:212). */
 int scanrs_pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t max_iter, const double *v0,
                      const scanrs_snoop *snoop, double *u, double *s, double *v, uint32_t *mprod);
+/* PcaResult of the last scanrs_pca_bk / scanrs_pca_rand call on this handle as it lies in device memory
+ * (dim_red/mod.rs:47 returns owned arrays; a device consumer — scanrs_knn_device below, a clustering kernel of the
+ * caller — takes them from here without the PCIe round trip): *d_u is rows x k with leading dimension *ld_u
+ * (elements, row-major), *d_v is cols x k (the local columns of a sharded handle). The memory belongs to the handle
+ * and is valid until its next PCA call or scanrs_mat_free. Any output pointer may be null. */
+int scanrs_pca_result_device(scanrs_mat *m, const double **d_u, uint32_t *ld_u, const double **d_v, uint32_t *ld_v,
+                             uint32_t *k);
 /* The panel the two randomized drivers draw for a given seed (count values, row-major fill order). */
 int scanrs_omega_fill(uint64_t seed, uint64_t count, double *out);
 
@@ -232,6 +239,10 @@ int scanrs_knn(const double *points, uint64_t n, uint32_t d, uint32_t k, uint32_
 int scanrs_find_nn(const double *queries, uint64_t n_q, const double *points, uint64_t n_p, uint32_t d, uint32_t k,
                    int include_self, uint32_t *out);
 
+/* scanrs_knn on points already in device memory (n x d, row-major, leading dimension ld >= d elements), e.g. the
+ * scores scanrs_pca_result_device hands out; `out` (n x k) is a host array. */
+int scanrs_knn_device(const double *d_points, uint64_t n, uint32_t ld, uint32_t d, uint32_t k, uint32_t *out);
+
 /* ---- multi-GPU: one process per GPU, cells range-partitioned ----------- */
 
 /* In-place sum all-reduce of `count` elements of device memory across ranks.
@@ -244,6 +255,36 @@ typedef int (*scanrs_allreduce_fn)(void *ctx, void *d_buf, uint64_t count, int d
  * shape keeps the local count; reductions over the outer dimension become global. */
 int scanrs_mat_set_shard(scanrs_mat *m, uint32_t rank, uint32_t world, uint64_t outer_begin, uint64_t outer_global,
                          scanrs_allreduce_fn allreduce, void *ctx);
+/* The library's own transport for the exchange steps (replaces the host hook above): RCCL over xGMI, loaded when the
+ * first communicator is made. One process per GPU: rank 0 draws the 128-byte id (scanrs_comm_get_unique_id), the
+ * host program passes it to the other ranks by any channel it has, every rank calls scanrs_comm_create with its
+ * device current, then scanrs_mat_set_shard_comm on its handle. The collectives are enqueued on the handle's own
+ * stream (no host synchronisation). The communicator is borrowed by the handle and must outlive it. */
+typedef struct scanrs_comm scanrs_comm;
+#define SCANRS_COMM_ID_BYTES 128
+int scanrs_comm_get_unique_id(uint8_t *id /* SCANRS_COMM_ID_BYTES */);
+int scanrs_comm_create(const uint8_t *id, uint32_t rank, uint32_t world, scanrs_comm **out);
+void scanrs_comm_free(scanrs_comm *c);
+int scanrs_mat_set_shard_comm(scanrs_mat *m, scanrs_comm *comm, uint32_t rank, uint32_t world, uint64_t outer_begin,
+                              uint64_t outer_global);
+
+/* Single-process form (SURVEY.md §8b `mat_create(..., n_gpus)`; Cell Ranger is one process, tools/src/bin/cmd.rs:61-70):
+ * the whole matrix is handed over once, its outer vectors are range-partitioned by nonzeros over `n_shards` devices
+ * (`devices` null = 0 .. n_shards-1; ids may repeat, several shards then share a device), every shard is driven by a
+ * host thread of the library during a call, and the exchange steps are a one-shot reduce-scatter + all-gather over
+ * peer-mapped memory. Outputs as in scanrs_pca_bk: u rows x k, s k, v cols x k for the WHOLE matrix. */
+typedef struct scanrs_multi scanrs_multi;
+int scanrs_multi_create(uint64_t rows, uint64_t cols, int storage, const uint64_t *indptr, const uint32_t *indices,
+                        const uint32_t *values, uint32_t n_shards, const int *devices, scanrs_multi **out);
+void scanrs_multi_free(scanrs_multi *mm);
+int scanrs_multi_n_shards(const scanrs_multi *mm, uint32_t *n);
+/* shard i: its handle (owned by mm; use it from a thread whose current device is *device), its range of outer vectors */
+int scanrs_multi_shard(scanrs_multi *mm, uint32_t i, scanrs_mat **shard, int *device, uint64_t *outer_begin, uint64_t *outer_end);
+int scanrs_multi_normalize(scanrs_multi *mm, int normalization, const uint32_t *size_factors);
+int scanrs_multi_pca_bk(scanrs_multi *mm, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
+                        const scanrs_snoop *snoop, double *u, double *s, double *v);
+int scanrs_multi_pca_rand(scanrs_multi *mm, uint32_t k, double l_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
+                          double *u, double *s, double *v);
 /* nnz-balanced contiguous partition of the outer dimension: bounds has world+1 entries. */
 int scanrs_plan_shards(const uint64_t *indptr, uint64_t n_outer, uint32_t world, uint64_t *bounds);
 

@@ -17,7 +17,27 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* All-core variant for bench.py's "generous" CPU baseline (1 core = the reference, which is
+ * single-threaded with sequential MKL; all cores = what a maintainer could get from rayon). 1 (default) keeps every loop
+ * below exactly the serial reference order — the parity pins are taken in that mode. With T > 1 threads the outer
+ * vectors are dealt to the threads; loops that scatter (output indexed by the INNER position) accumulate into
+ * per-thread copies of the output that are summed in thread order afterwards, so sums are re-associated. */
+static int g_threads = 1;
+void oracle_set_threads(int t) { g_threads = t < 1 ? 1 : t; }
+int oracle_get_threads(void) { return g_threads; }
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 /* ---- MatrixMap programs (sqz/src/matrix_map.rs) -------------------------
  * A lazily composed map chain (ComposedMap :145-197) is flattened into an op
@@ -124,6 +144,53 @@ void oracle_map_values(int storage_csc, size_t n_outer, const uint64_t *indptr, 
 void oracle_spmm_f64(int storage_csc, size_t n_outer, const uint64_t *indptr, const uint32_t *indices,
                      const uint32_t *values, const oracle_op *ops, int n_ops, const double *rhs,
                      size_t l, double *out) {
+#ifdef _OPENMP
+    if (g_threads > 1) {
+        if (!storage_csc) {
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 64)
+            for (size_t row = 0; row < n_outer; row++) {
+                double *o = out + row * l;
+                for (uint64_t p = indptr[row]; p < indptr[row + 1]; p++) {
+                    if (values[p] == 0) continue;
+                    size_t ind = indices[p];
+                    double lval = eval_map(ops, n_ops, values[p], row, ind);
+                    const double *r = rhs + ind * l;
+                    for (size_t j = 0; j < l; j++) o[j] = o[j] + r[j] * lval;
+                }
+            }
+        } else {
+            /* scatter: the number of output rows is the largest inner index + 1 */
+            size_t n_inner = 0;
+            for (uint64_t p = 0; p < indptr[n_outer]; p++)
+                if ((size_t)indices[p] + 1 > n_inner) n_inner = (size_t)indices[p] + 1;
+            const int T = g_threads;
+            double *priv = (double *)calloc((size_t)T * n_inner * l, sizeof(double));
+#pragma omp parallel num_threads(T)
+            {
+                double *mine = priv + (size_t)omp_get_thread_num() * n_inner * l;
+#pragma omp for schedule(static)
+                for (size_t col = 0; col < n_outer; col++) {
+                    const double *r = rhs + col * l;
+                    for (uint64_t p = indptr[col]; p < indptr[col + 1]; p++) {
+                        if (values[p] == 0) continue;
+                        size_t ind = indices[p];
+                        double lval = eval_map(ops, n_ops, values[p], ind, col);
+                        double *o = mine + ind * l;
+                        for (size_t j = 0; j < l; j++) o[j] = o[j] + r[j] * lval;
+                    }
+                }
+#pragma omp for schedule(static)
+                for (size_t e = 0; e < n_inner * l; e++) {
+                    double acc = out[e];
+                    for (int t = 0; t < T; t++) acc += priv[(size_t)t * n_inner * l + e];
+                    out[e] = acc;
+                }
+            }
+            free(priv);
+        }
+        return;
+    }
+#endif
     if (!storage_csc) {
         for (size_t row = 0; row < n_outer; row++) {
             double *o = out + row * l;
@@ -177,11 +244,20 @@ void oracle_spmm_u32(int storage_csc, size_t n_outer, const uint64_t *indptr, co
     }
 }
 
+void oracle_sum_sq_axis_f64(int storage_csc, size_t n_outer, const uint64_t *indptr, const uint32_t *indices,
+                            const uint32_t *values, const oracle_op *ops, int n_ops, int axis, double *sum, double *sumsq);
+
 /* sum_axis, sqz/src/mat.rs:377-406: axis 0 -> per-column sums, axis 1 -> per-row sums,
  * accumulated in storage order.  out zero-initialised by the caller. */
 void oracle_sum_axis_f64(int storage_csc, size_t n_outer, const uint64_t *indptr, const uint32_t *indices,
                          const uint32_t *values, const oracle_op *ops, int n_ops, int axis,
                          double *out) {
+#ifdef _OPENMP
+    if (g_threads > 1) {
+        oracle_sum_sq_axis_f64(storage_csc, n_outer, indptr, indices, values, ops, n_ops, axis, out, NULL);
+        return;
+    }
+#endif
     for (size_t o = 0; o < n_outer; o++) {
         for (uint64_t p = indptr[o]; p < indptr[o + 1]; p++) {
             if (values[p] == 0) continue;
@@ -210,6 +286,60 @@ void oracle_sum_axis_u32(int storage_csc, size_t n_outer, const uint64_t *indptr
 void oracle_sum_sq_axis_f64(int storage_csc, size_t n_outer, const uint64_t *indptr, const uint32_t *indices,
                             const uint32_t *values, const oracle_op *ops, int n_ops, int axis,
                             double *sum, double *sumsq) {
+#ifdef _OPENMP
+    if (g_threads > 1) {
+        const int outer_axis = storage_csc ? 0 : 1; /* the axis whose index is the outer vector */
+        if (axis == outer_axis) {
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 256)
+            for (size_t o = 0; o < n_outer; o++) {
+                double s1 = 0.0, s2 = 0.0;
+                for (uint64_t p = indptr[o]; p < indptr[o + 1]; p++) {
+                    if (values[p] == 0) continue;
+                    size_t r = storage_csc ? indices[p] : o;
+                    size_t c = storage_csc ? o : indices[p];
+                    double v = eval_map(ops, n_ops, values[p], r, c);
+                    s1 += v;
+                    s2 += v * v;
+                }
+                sum[o] += s1;
+                if (sumsq) sumsq[o] += s2;
+            }
+        } else {
+            size_t n_inner = 0;
+            for (uint64_t p = 0; p < indptr[n_outer]; p++)
+                if ((size_t)indices[p] + 1 > n_inner) n_inner = (size_t)indices[p] + 1;
+            const int T = g_threads;
+            double *priv = (double *)calloc((size_t)T * n_inner * 2, sizeof(double));
+#pragma omp parallel num_threads(T)
+            {
+                double *m1 = priv + (size_t)omp_get_thread_num() * n_inner * 2, *m2 = m1 + n_inner;
+#pragma omp for schedule(static)
+                for (size_t o = 0; o < n_outer; o++) {
+                    for (uint64_t p = indptr[o]; p < indptr[o + 1]; p++) {
+                        if (values[p] == 0) continue;
+                        size_t r = storage_csc ? indices[p] : o;
+                        size_t c = storage_csc ? o : indices[p];
+                        double v = eval_map(ops, n_ops, values[p], r, c);
+                        m1[indices[p]] += v;
+                        m2[indices[p]] += v * v;
+                    }
+                }
+#pragma omp for schedule(static)
+                for (size_t e = 0; e < n_inner; e++) {
+                    double a1 = sum[e], a2 = sumsq ? sumsq[e] : 0.0;
+                    for (int t = 0; t < T; t++) {
+                        a1 += priv[(size_t)t * n_inner * 2 + e];
+                        a2 += priv[(size_t)t * n_inner * 2 + n_inner + e];
+                    }
+                    sum[e] = a1;
+                    if (sumsq) sumsq[e] = a2;
+                }
+            }
+            free(priv);
+        }
+        return;
+    }
+#endif
     for (size_t o = 0; o < n_outer; o++) {
         for (uint64_t p = indptr[o]; p < indptr[o + 1]; p++) {
             if (values[p] == 0) continue;

@@ -47,7 +47,7 @@ def build(force: bool = False) -> str:
     """Compile the C restatement (gcc, -ffp-contract=off so `o + r*lval` is not fused)."""
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(_SRC_PATH):
         subprocess.check_call(
-            ["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", _LIB_PATH, _SRC_PATH, "-lm"]
+            ["gcc", "-O2", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-o", _LIB_PATH, _SRC_PATH, "-lm"]
         )
     return _LIB_PATH
 
@@ -71,6 +71,18 @@ def _clib():
     if _lib is None:
         _lib = ctypes.CDLL(build())
     return _lib
+
+
+def set_threads(t: int) -> int:
+    """Threads of the sparse loops (bench.py's all-core CPU baseline). 1 = the serial reference order (default, the
+    mode every parity pin is taken in); returns the thread count in force."""
+    lib = _clib()
+    lib.oracle_set_threads(ctypes.c_int(int(t)))
+    return int(lib.oracle_get_threads())
+
+
+def max_threads() -> int:
+    return int(_clib().oracle_max_threads())
 
 
 def _ptr(a: Optional[np.ndarray]):

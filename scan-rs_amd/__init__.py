@@ -460,6 +460,14 @@ class AdaptiveMat:
                 ctypes.c_uint64(outer_global), cb if cb is not None else ctypes.cast(None, _ALLREDUCE_FN), None))
         return self
 
+    def set_shard_comm(self, comm: "Comm", outer_begin: int, outer_global: int):
+        """Sharded handle over the library's own transport (`scanrs_mat_set_shard_comm`): RCCL collectives on the handle's
+        stream. `comm` must outlive the handle's sharded calls."""
+        _check(_lib.scanrs_mat_set_shard_comm(self._h, comm._c, ctypes.c_uint32(comm.rank), ctypes.c_uint32(comm.world),
+                                              ctypes.c_uint64(outer_begin), ctypes.c_uint64(outer_global)))
+        self._keep.append(comm)
+        return self
+
     def profile_enable(self, on: bool = True):
         _check(_lib.scanrs_profile_enable(self._h, ctypes.c_int(int(on))))
 
@@ -578,6 +586,138 @@ class BkSvd:
 
     run_pca_cancellable = run_pca
 
+    def run_pca_device(self, matrix: AdaptiveMat, k: int, omega=None, snoop: Optional[AtomicSnoop] = None, seed: int = 0):
+        """The same call with U and V left in device memory: returns (s, PcaResultDevice). The factors are reached through
+        `scanrs_pca_result_device` (pointers + leading dimensions) — for a device consumer such as `knn_device`."""
+        s = np.zeros(max(k, 0))
+        om = None if omega is None else _f64(omega)
+        sref, _keep = _snoop_arg(snoop)
+        _check(
+            _lib.scanrs_pca_bk(
+                matrix._h, ctypes.c_uint32(k), ctypes.c_double(self.k_multiplier), ctypes.c_uint32(self.n_iter),
+                ctypes.c_uint64(seed), _p(om), sref, None, _p(s), None))
+        return s, pca_result_device(matrix)
+
+
+class Comm:
+    """`scanrs_comm`: the library's RCCL communicator of the one-process-per-GPU form. Rank 0 draws the id with
+    `Comm.unique_id()` and the host program hands the 128 bytes to the other ranks (bench.py: a torch.distributed
+    broadcast on the gloo control plane); every rank then builds `Comm(id, rank, world)` with its device current."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (ctypes.c_uint8 * Comm.ID_BYTES)()
+        _check(_lib.scanrs_comm_get_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, uid: bytes, rank: int, world: int):
+        if len(uid) != Comm.ID_BYTES:
+            raise ScanrsError(6, "unique id must be 128 bytes")
+        self.rank, self.world = int(rank), int(world)
+        self._c = ctypes.c_void_p()
+        buf = (ctypes.c_uint8 * Comm.ID_BYTES).from_buffer_copy(uid)
+        _check(_lib.scanrs_comm_create(buf, ctypes.c_uint32(rank), ctypes.c_uint32(world), ctypes.byref(self._c)))
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c:
+            _lib.scanrs_comm_free(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiMat:
+    """`scanrs_multi`: the single-process multi-GPU form (one handle for the whole matrix, the library shards it by
+    nonzeros over `devices` and drives every shard from its own host thread). `devices` may repeat an id."""
+
+    def __init__(self, rows, cols, storage, indptr, indices, values, n_shards: int, devices=None):
+        ip = np.ascontiguousarray(indptr, dtype=np.uint64)
+        ix = np.ascontiguousarray(indices, dtype=np.uint32)
+        vv = np.ascontiguousarray(values, dtype=np.uint32)
+        self.rows, self.cols, self.storage, self.n_shards = int(rows), int(cols), int(storage), int(n_shards)
+        dv = None if devices is None else (ctypes.c_int * n_shards)(*[int(d) for d in devices])
+        self._h = ctypes.c_void_p()
+        _check(_lib.scanrs_multi_create(ctypes.c_uint64(rows), ctypes.c_uint64(cols), ctypes.c_int(storage), _p(ip), _p(ix), _p(vv),
+                                        ctypes.c_uint32(n_shards), dv, ctypes.byref(self._h)))
+
+    def shard_ranges(self):
+        out = []
+        for i in range(self.n_shards):
+            lo, hi, dev = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_int()
+            _check(_lib.scanrs_multi_shard(self._h, ctypes.c_uint32(i), None, ctypes.byref(dev), ctypes.byref(lo), ctypes.byref(hi)))
+            out.append((dev.value, lo.value, hi.value))
+        return out
+
+    def normalize(self, normalization: int, size_factors=None):
+        sf = None if size_factors is None else np.ascontiguousarray(size_factors, dtype=np.uint32)
+        _check(_lib.scanrs_multi_normalize(self._h, ctypes.c_int(int(normalization)), _p(sf)))
+        return self
+
+    def run_pca_bk(self, k: int, k_multiplier: float = 2.0, n_iter: int = 5, omega=None, seed: int = 0, snoop=None):
+        u, s, v = np.zeros((self.rows, k)), np.zeros(k), np.zeros((self.cols, k))
+        om = None if omega is None else _f64(omega)
+        sref, _keep = _snoop_arg(snoop)
+        _check(_lib.scanrs_multi_pca_bk(self._h, ctypes.c_uint32(k), ctypes.c_double(k_multiplier), ctypes.c_uint32(n_iter),
+                                        ctypes.c_uint64(seed), _p(om), sref, _p(u), _p(s), _p(v)))
+        return u, s, v
+
+    def run_pca_rand(self, k: int, l_multiplier: float = 10.0, n_iter: int = 2, omega=None, seed: int = 0):
+        u, s, v = np.zeros((self.rows, k)), np.zeros(k), np.zeros((self.cols, k))
+        om = None if omega is None else _f64(omega)
+        _check(_lib.scanrs_multi_pca_rand(self._h, ctypes.c_uint32(k), ctypes.c_double(l_multiplier), ctypes.c_uint32(n_iter),
+                                          ctypes.c_uint64(seed), _p(om), _p(u), _p(s), _p(v)))
+        return u, s, v
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            _lib.scanrs_multi_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DevArray:
+    """A run of `n` f64 values of device memory at raw address `ptr` as a __cuda_array_interface__ object
+    (torch.as_tensor(DevArray(...), device=...) views it without a copy)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str = "<f8"):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class PcaResultDevice:
+    """Where the last PCA of a handle left its factors in HBM (`scanrs_pca_result_device`): raw device addresses,
+    leading dimensions in elements; `u` is rows x k, `v` cols x k. Valid until the handle's next PCA call."""
+
+    def __init__(self, d_u, ld_u, d_v, ld_v, k, rows, cols):
+        self.d_u, self.ld_u, self.d_v, self.ld_v, self.k, self.rows, self.cols = d_u, ld_u, d_v, ld_v, k, rows, cols
+
+
+def pca_result_device(matrix: "AdaptiveMat") -> PcaResultDevice:
+    d_u, d_v = ctypes.c_void_p(), ctypes.c_void_p()
+    ld_u, ld_v, k = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+    _check(_lib.scanrs_pca_result_device(matrix._h, ctypes.byref(d_u), ctypes.byref(ld_u), ctypes.byref(d_v), ctypes.byref(ld_v),
+                                         ctypes.byref(k)))
+    r, c = matrix.shape()
+    return PcaResultDevice(d_u.value, ld_u.value, d_v.value, ld_v.value, k.value, r, c)
+
+
+def knn_device(d_points: int, n: int, ld: int, d: int, k: int):
+    """`nn::knn` on scores that already live in device memory (e.g. PcaResultDevice.d_v / ld_v): (n x k) u32 host array."""
+    out = np.zeros((n, k), dtype=np.uint32)
+    _check(_lib.scanrs_knn_device(ctypes.c_void_p(d_points), ctypes.c_uint64(n), ctypes.c_uint32(ld), ctypes.c_uint32(d),
+                                  ctypes.c_uint32(k), _p(out)))
+    return out
+
 
 class RandSvd:
     """`RandSvd` (dim_red/rand_svd.rs:13-50)."""
@@ -662,7 +802,8 @@ EXPORTED_SYMBOLS = [
     "scanrs_mat_sum_axis_f64", "scanrs_mat_mean_axis", "scanrs_mat_mean_var_axis", "scanrs_mat_to_dense",
     "scanrs_mat_dot", "scanrs_mat_rdot", "scanrs_mat_dot_u32", "scanrs_mat_rdot_u32", "scanrs_mat_dot_device",
     "scanrs_normalize", "scanrs_log_normalize", "scanrs_log1p_normalize_fixed_point", "scanrs_mat_target_umi",
-    "scanrs_pca_bk", "scanrs_pca_rand", "scanrs_pca_irlba", "scanrs_omega_fill", "scanrs_mat_set_shard",
+    "scanrs_pca_bk", "scanrs_pca_rand", "scanrs_pca_irlba", "scanrs_pca_result_device", "scanrs_knn_device", "scanrs_omega_fill", "scanrs_mat_set_shard", "scanrs_mat_set_shard_comm", "scanrs_comm_get_unique_id", "scanrs_comm_create", "scanrs_comm_free",
+    "scanrs_multi_create", "scanrs_multi_free", "scanrs_multi_n_shards", "scanrs_multi_shard", "scanrs_multi_normalize", "scanrs_multi_pca_bk", "scanrs_multi_pca_rand",
     "scanrs_plan_shards", "scanrs_profile_enable", "scanrs_profile_reset", "scanrs_profile_get", "scanrs_mat_sync", "scanrs_mat_set_spmm_path", "scanrs_mat_set_panel_precision",
     "scanrs_host_chol_upper", "scanrs_host_inv_upper", "scanrs_host_sym_eig", "scanrs_host_sym_eig_topk",
 ]

@@ -141,16 +141,23 @@ SparseCopy &Storage::copy_with_outer_rows(bool outer_rows) {
     return other;
 }
 
-void allreduce_f64(Storage &st, double *d, uint64_t count) {
+// One exchange step. With the library's own transport (scanrs_mat_set_shard_comm) the collective is enqueued on the
+// handle's stream; the host hook form synchronises first (the hook's runtime knows nothing of our stream).
+static void allreduce_any(Storage &st, void *d, uint64_t count, int dtype) {
     if (!st.shard.active()) return;
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
-    if (st.shard.allreduce(st.shard.ctx, d, count, 0) != 0) fail(SCANRS_ERR_DEVICE, "all-reduce callback failed");
+    if (st.prof.on) st.prof.begin(st.stream, dtype == 0 ? "allreduce_f64" : "allreduce_u64", (double)count * 8.0);
+    if (st.shard.comm) {
+        comm_allreduce(st, st.shard.comm, d, count, dtype);
+    } else if (st.shard.allreduce) {
+        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        if (st.shard.allreduce(st.shard.ctx, d, count, dtype) != 0) fail(SCANRS_ERR_DEVICE, "all-reduce callback failed");
+    } else {
+        fail(SCANRS_ERR_ARGUMENT, "sharded handle without a transport");
+    }
+    if (st.prof.on) st.prof.end(st.stream);
 }
-void allreduce_u64(Storage &st, unsigned long long *d, uint64_t count) {
-    if (!st.shard.active()) return;
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
-    if (st.shard.allreduce(st.shard.ctx, d, count, 1) != 0) fail(SCANRS_ERR_DEVICE, "all-reduce callback failed");
-}
+void allreduce_f64(Storage &st, double *d, uint64_t count) { allreduce_any(st, d, count, 0); }
+void allreduce_u64(Storage &st, unsigned long long *d, uint64_t count) { allreduce_any(st, d, count, 1); }
 // primary's outer dimension is the sharded one: base rows when CSR, base cols when CSC
 static bool base_rows_sharded(const Storage &st) { return st.shard.active() && st.storage == SCANRS_CSR; }
 static bool base_cols_sharded(const Storage &st) { return st.shard.active() && st.storage == SCANRS_CSC; }
@@ -935,6 +942,18 @@ int scanrs_pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t max_iter, 
         pca_irlba(m, nu, tol, max_iter, v0, snoop, u, s, v, mprod);
     });
 }
+int scanrs_pca_result_device(scanrs_mat *m, const double **d_u, uint32_t *ld_u, const double **d_v, uint32_t *ld_v, uint32_t *k) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        const Storage::PcaDev &r = m->st->pca_dev;
+        if (!r.u || !r.v || r.k == 0) fail(SCANRS_ERR_ARGUMENT, "no PCA result on this handle yet");
+        if (d_u) *d_u = r.u;
+        if (ld_u) *ld_u = r.ld_u;
+        if (d_v) *d_v = r.v;
+        if (ld_v) *ld_v = r.ld_v;
+        if (k) *k = r.k;
+    });
+}
 int scanrs_omega_fill(uint64_t seed, uint64_t count, double *out) {
     return guard([&] {
         if (!out && count) fail(SCANRS_ERR_ARGUMENT, "null argument");
@@ -948,6 +967,13 @@ int scanrs_knn(const double *points, uint64_t n, uint32_t d, uint32_t k, uint32_
         if ((!points && n) || (!out && n && k)) fail(SCANRS_ERR_ARGUMENT, "null argument");
         need_device();
         knn_host(points, n, points, n, d, k, true, out);
+    });
+}
+int scanrs_knn_device(const double *d_points, uint64_t n, uint32_t ld, uint32_t d, uint32_t k, uint32_t *out) {
+    return guard([&] {
+        if ((!d_points && n) || (!out && n && k)) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        need_device();
+        knn_device(d_points, ld, n, d_points, ld, n, d, k, true, out);
     });
 }
 int scanrs_find_nn(const double *queries, uint64_t n_q, const double *points, uint64_t n_p, uint32_t d, uint32_t k, int include_self,
@@ -974,6 +1000,24 @@ int scanrs_mat_set_shard(scanrs_mat *m, uint32_t rank, uint32_t world, uint64_t 
         st.shard.outer_global = outer_global;
         st.shard.allreduce = allreduce;
         st.shard.ctx = ctx;
+        st.shard.comm = nullptr;
+    });
+}
+int scanrs_mat_set_shard_comm(scanrs_mat *m, scanrs_comm *comm, uint32_t rank, uint32_t world, uint64_t outer_begin,
+                              uint64_t outer_global) {
+    return guard([&] {
+        if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        if (world == 0 || rank >= world) fail(SCANRS_ERR_ARGUMENT, "bad rank/world");
+        if (world > 1 && !comm) fail(SCANRS_ERR_ARGUMENT, "a communicator is required when world > 1");
+        Storage &st = *m->st;
+        if (outer_begin + st.primary.n_outer > outer_global) fail(SCANRS_ERR_SHAPE, "shard exceeds the global extent");
+        st.shard.rank = rank;
+        st.shard.world = world;
+        st.shard.outer_begin = outer_begin;
+        st.shard.outer_global = outer_global;
+        st.shard.allreduce = nullptr;
+        st.shard.ctx = nullptr;
+        st.shard.comm = comm;
     });
 }
 int scanrs_plan_shards(const uint64_t *indptr, uint64_t n_outer, uint32_t world, uint64_t *bounds) {

@@ -15,6 +15,8 @@
 
 #include "scanrs_amd.h"
 
+struct scanrs_comm; // comm.cpp
+
 namespace scanrs {
 
 // ---- errors: thrown inside, turned into status codes at the C boundary ----------
@@ -163,10 +165,11 @@ struct SparseCopy {
 struct ShardInfo {
     uint32_t rank = 0, world = 1;
     uint64_t outer_begin = 0, outer_global = 0;
-    scanrs_allreduce_fn allreduce = nullptr;
+    scanrs_allreduce_fn allreduce = nullptr; // host-supplied hook (tests; a caller with its own transport)
     void *ctx = nullptr;
-    // a callback given at world == 1 is still served (single-rank RCCL runs exercise the exchange steps)
-    bool active() const { return world > 1 || allreduce != nullptr; }
+    scanrs_comm *comm = nullptr; // the library's own transport (RCCL or the single-process group); not owned
+    // a transport given at world == 1 is still served (single-rank RCCL runs exercise the exchange steps)
+    bool active() const { return world > 1 || allreduce != nullptr || comm != nullptr; }
 };
 
 // Storage shared by a handle and its views (AdaptiveMat::view / t share `&[AdaptiveVec]`).
@@ -199,6 +202,12 @@ struct Storage {
     }
     Profile prof;
     ShardInfo shard; // sharding of primary's outer dimension
+    // PcaResult of the last svd_bk / svd_rand call, as it lies in the solver's scratch (scanrs_pca_result_device)
+    struct PcaDev {
+        const double *u = nullptr, *v = nullptr;
+        uint32_t ld_u = 0, ld_v = 0, k = 0;
+        uint64_t rows_u = 0, rows_v = 0;
+    } pca_dev;
     int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 L2-blocked gather
     int panel_precision = 0;              // 0: f64 panels (default); 1: gathered panels rounded to f32, f64 sums (opt-in)
     size_t l2_tile_bytes = 3u << 20;      // panel slice per step of the L2-blocked gather (4 MB L2 per XCD)
@@ -334,9 +343,18 @@ void launch_scale_rows(Storage &st, const double *X, uint32_t ldx, uint64_t rows
 // knn.hip
 void knn_host(const double *queries, uint64_t n_q, const double *points, uint64_t n_p, uint32_t d, uint32_t k, bool skip_same_index,
               uint32_t *out);
+// the same with both point sets already in device memory (row-major, leading dimensions in elements); `out` is a host array
+void knn_device(const double *d_queries, uint32_t ld_q, uint64_t n_q, const double *d_points, uint32_t ld_p, uint64_t n_p, uint32_t d,
+                uint32_t k, bool skip_same_index, uint32_t *out);
 // decode.hip
 uint64_t decode_adaptive_vectors(const scanrs_adaptive_vec *vecs, uint64_t n_vecs, uint64_t vec_len, DevBuf<uint64_t> &indptr,
                                  DevBuf<uint32_t> &indices, DevBuf<uint32_t> &values);
+// comm.cpp
+struct LocalGroup;
+void comm_allreduce(Storage &st, scanrs_comm *c, void *d, uint64_t count, int dtype); // dtype 0 = f64, 1 = u64; on st.stream
+void comm_abort(scanrs_comm *c);
+std::shared_ptr<LocalGroup> local_group_make(uint32_t world);
+scanrs_comm *comm_make_local(const std::shared_ptr<LocalGroup> &g, uint32_t rank);
 void allreduce_f64(Storage &st, double *d, uint64_t count);
 void allreduce_u64(Storage &st, unsigned long long *d, uint64_t count);
 // is the view-row dimension the sharded one?

@@ -1537,11 +1537,8 @@ void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const doubl
             const uint32_t n_parts = (uint32_t)((cp.n_inner + 18431) / 18432);
             const uint32_t tiles_per_part = (uint32_t)(((cp.n_inner + n_parts - 1) / n_parts + (1u << BT_SHIFT) - 1) >> BT_SHIFT);
             const size_t shmem = ((size_t)tiles_per_part << BT_SHIFT) * 8;
-            static bool attr_set = false;
-            if (!attr_set) {
-                SCANRS_HIP(hipFuncSetAttribute((const void *)spmv_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                attr_set = true;
-            }
+            // per device, and handles of one process may live on different devices: set on every use (a cheap call)
+            SCANRS_HIP(hipFuncSetAttribute((const void *)spmv_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             int dev = 0, n_cu = 256;
             (void)hipGetDevice(&dev);
             (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -1780,6 +1777,34 @@ void launch_sum_f64(Storage &st, const double *x, uint64_t n, double *out) {
 
 // ---------------------------------------------------------------------------------------------
 // storage management
+// One-shot all-reduce of the single-process group (comm.cpp): rank r sums slice r of every rank's buffer in rank order
+// and writes the sum back into every buffer. Peer buffers are reached through peer-mapped pointers (xGMI) or are on the
+// same device; the caller brackets the launch with group barriers.
+struct PeerTable {
+    void *p[16];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void local_allreduce_kernel(PeerTable tab, uint32_t world, uint64_t lo, uint64_t hi) {
+    for (uint64_t e = lo + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < hi; e += (uint64_t)gridDim.x * blockDim.x) {
+        T acc = static_cast<const T *>(tab.p[0])[e];
+        for (uint32_t r = 1; r < world; r++) acc += static_cast<const T *>(tab.p[r])[e];
+        for (uint32_t r = 0; r < world; r++) static_cast<T *>(tab.p[r])[e] = acc;
+    }
+}
+void launch_local_allreduce(hipStream_t s, void *const *bufs, uint32_t world, uint32_t rank, uint64_t count, int dtype) {
+    if (world > 16) fail(SCANRS_ERR_ARGUMENT, "single-process groups hold at most 16 shards");
+    PeerTable tab;
+    for (uint32_t r = 0; r < 16; r++) tab.p[r] = r < world ? bufs[r] : nullptr;
+    const uint64_t lo = count * rank / world, hi = count * (rank + 1) / world;
+    if (hi <= lo) return;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(1024, (hi - lo + 255) / 256);
+    if (dtype == 0)
+        hipLaunchKernelGGL(local_allreduce_kernel<double>, dim3(blocks), dim3(256), 0, s, tab, world, lo, hi);
+    else
+        hipLaunchKernelGGL(local_allreduce_kernel<unsigned long long>, dim3(blocks), dim3(256), 0, s, tab, world, lo, hi);
+    SCANRS_HIP(hipGetLastError());
+}
+
 void SparseCopy::build_items(hipStream_t s) {
     std::vector<uint64_t> h(n_outer + 1);
     if (n_outer + 1) SCANRS_HIP(hipMemcpyAsync(h.data(), indptr.p, (n_outer + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));

@@ -60,61 +60,75 @@ __global__ __launch_bounds__(THREADS) void knn_kernel(const double *__restrict__
     for (uint32_t i = 0; i < k; i++) out[qi * k + i] = i < have ? best_i[i] : 0xFFFFFFFFu; // T::max_value() padding, nn.rs:66
 }
 
-__global__ void pad_points_kernel(const double *__restrict__ src, uint64_t n, uint32_t d, uint32_t dmax, double *__restrict__ dst) {
+__global__ void pad_points_kernel(const double *__restrict__ src, uint32_t ld, uint64_t n, uint32_t d, uint32_t dmax,
+                                  double *__restrict__ dst) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * dmax) return;
     const uint64_t r = e / dmax;
     const uint32_t j = (uint32_t)(e % dmax);
-    dst[e] = j < d ? src[r * d + j] : 0.0;
+    dst[e] = j < d ? src[r * ld + j] : 0.0;
 }
 
 template <int DMAX, int THREADS>
-void launch(const double *dq, uint64_t n_q, const double *dp, uint64_t n_p, uint32_t d, uint32_t k, int skip, uint32_t *dout,
-            hipStream_t s) {
-    DevBuf<double> padded;
-    padded.alloc(n_p * DMAX ? n_p * DMAX : 1);
+void launch(const double *dq, uint32_t ldq, uint64_t n_q, const double *dp, uint32_t ldp, uint64_t n_p, uint32_t d, uint32_t k, int skip,
+            uint32_t *dout, hipStream_t s) {
+    // zero-padded (n x DMAX) copies: the candidate's coordinates arrive as whole scalar-cache lines, the query's as one run per thread
+    DevBuf<double> pp, qp;
+    pp.alloc(n_p * DMAX ? n_p * DMAX : 1);
     if (n_p)
-        hipLaunchKernelGGL(pad_points_kernel, dim3((unsigned)((n_p * DMAX + 255) / 256)), dim3(256), 0, s, dp, n_p, d, (uint32_t)DMAX, padded.p);
+        hipLaunchKernelGGL(pad_points_kernel, dim3((unsigned)((n_p * DMAX + 255) / 256)), dim3(256), 0, s, dp, ldp, n_p, d, (uint32_t)DMAX, pp.p);
+    const double *q = pp.p;
+    if (dq != dp || n_q != n_p || ldq != ldp) {
+        qp.alloc(n_q * DMAX);
+        hipLaunchKernelGGL(pad_points_kernel, dim3((unsigned)((n_q * DMAX + 255) / 256)), dim3(256), 0, s, dq, ldq, n_q, d, (uint32_t)DMAX, qp.p);
+        q = qp.p;
+    }
     const dim3 grid((unsigned)((n_q + THREADS - 1) / THREADS)), block(THREADS);
-    hipLaunchKernelGGL((knn_kernel<DMAX, THREADS>), grid, block, 0, s, dq, n_q, padded.p, n_p, d, k, skip, dout);
-    SCANRS_HIP(hipStreamSynchronize(s)); // `padded` is released on return
+    hipLaunchKernelGGL((knn_kernel<DMAX, THREADS>), grid, block, 0, s, q, n_q, pp.p, n_p, (uint32_t)DMAX, k, skip, dout);
+    SCANRS_HIP(hipStreamSynchronize(s)); // the padded copies are released on return
 }
 
 } // namespace
+
+void knn_device(const double *d_queries, uint32_t ld_q, uint64_t n_q, const double *d_points, uint32_t ld_p, uint64_t n_p, uint32_t d,
+                uint32_t k, bool skip_same_index, uint32_t *out) {
+    if (k == 0 || n_q == 0) return;
+    if (k > KMAX) fail(SCANRS_ERR_ARGUMENT, "knn: k must not exceed 128");
+    if (d == 0 || d > 128) fail(SCANRS_ERR_ARGUMENT, "knn: 1 <= dimensions <= 128");
+    if (ld_q < d || ld_p < d) fail(SCANRS_ERR_ARGUMENT, "knn: leading dimension smaller than the number of coordinates");
+    if (n_p > 0xFFFFFFFEull) fail(SCANRS_ERR_SHAPE, "knn: too many points for u32 indices");
+    DevBuf<uint32_t> dout;
+    dout.alloc(n_q * k);
+    const int skip = skip_same_index ? 1 : 0;
+    if (d <= 8)
+        launch<8, 256>(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p, 0);
+    else if (d <= 16)
+        launch<16, 256>(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p, 0);
+    else if (d <= 32)
+        launch<32, 256>(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p, 0);
+    else if (d <= 52) // top-50 PCA scores, the default of scan-rs-cmd (tools/src/bin/cmd.rs:46-48)
+        launch<52, 256>(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p, 0);
+    else if (d <= 64)
+        launch<64, 256>(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p, 0);
+    else
+        launch<128, 64>(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p, 0);
+    SCANRS_HIP(hipGetLastError());
+    SCANRS_HIP(hipMemcpy(out, dout.p, n_q * k * 4, hipMemcpyDeviceToHost));
+}
 
 // queries (n_q x d) against points (n_p x d), both row-major host arrays; out n_q x k.
 void knn_host(const double *queries, uint64_t n_q, const double *points, uint64_t n_p, uint32_t d, uint32_t k, bool skip_same_index,
               uint32_t *out) {
     if (k == 0 || n_q == 0) return;
-    if (k > KMAX) fail(SCANRS_ERR_ARGUMENT, "knn: k must not exceed 128");
-    if (d == 0 || d > 128) fail(SCANRS_ERR_ARGUMENT, "knn: 1 <= dimensions <= 128");
-    if (n_p > 0xFFFFFFFEull) fail(SCANRS_ERR_SHAPE, "knn: too many points for u32 indices");
     DevBuf<double> dq, dp;
-    DevBuf<uint32_t> dout;
     const bool same = queries == points && n_q == n_p;
     dp.alloc(n_p * d ? n_p * d : 1);
     if (n_p) SCANRS_HIP(hipMemcpy(dp.p, points, n_p * d * 8, hipMemcpyHostToDevice));
     if (!same) {
-        dq.alloc(n_q * d);
+        dq.alloc(n_q * d ? n_q * d : 1);
         SCANRS_HIP(hipMemcpy(dq.p, queries, n_q * d * 8, hipMemcpyHostToDevice));
     }
-    dout.alloc(n_q * k);
-    const double *q = same ? dp.p : dq.p;
-    const int skip = skip_same_index ? 1 : 0;
-    if (d <= 8)
-        launch<8, 256>(q, n_q, dp.p, n_p, d, k, skip, dout.p, 0);
-    else if (d <= 16)
-        launch<16, 256>(q, n_q, dp.p, n_p, d, k, skip, dout.p, 0);
-    else if (d <= 32)
-        launch<32, 256>(q, n_q, dp.p, n_p, d, k, skip, dout.p, 0);
-    else if (d <= 52) // top-50 PCA scores, the default of scan-rs-cmd (tools/src/bin/cmd.rs:46-48)
-        launch<52, 256>(q, n_q, dp.p, n_p, d, k, skip, dout.p, 0);
-    else if (d <= 64)
-        launch<64, 256>(q, n_q, dp.p, n_p, d, k, skip, dout.p, 0);
-    else
-        launch<128, 64>(q, n_q, dp.p, n_p, d, k, skip, dout.p, 0);
-    SCANRS_HIP(hipGetLastError());
-    SCANRS_HIP(hipMemcpy(out, dout.p, n_q * k * 4, hipMemcpyDeviceToHost));
+    knn_device(same ? dp.p : dq.p, d, n_q, dp.p, d, n_p, d, k, skip_same_index, out);
 }
 
 } // namespace scanrs

@@ -321,6 +321,70 @@ static void orth_against(Ctx &c, const double *Q, uint32_t ldq, uint32_t nprev, 
 static bool dim_sharded_rows(const scanrs_mat *m) { return rows_sharded(m); }
 static bool dim_sharded_cols(const scanrs_mat *m) { return cols_sharded(m); }
 
+// One-sided Jacobi (Hestenes) SVD of a tall host matrix A (rows x n, row-major): A = U diag(S) V^T with U rows x n.
+// Used where the Gram-matrix route of ritz_finish would lose the small singular values (it squares the condition
+// number): requested components at or beyond the numerical rank. Columns with S = 0 get U = 0.
+static void jacobi_svd_tall(std::vector<double> A, size_t rows, int n, std::vector<double> &U, std::vector<double> &S,
+                            std::vector<double> &V) {
+    // work column-major for contiguous column sweeps
+    std::vector<double> W((size_t)n * rows);
+    for (size_t i = 0; i < rows; i++)
+        for (int j = 0; j < n; j++) W[(size_t)j * rows + i] = A[i * n + j];
+    std::vector<double> Vc((size_t)n * n, 0.0); // column-major: Vc[j * n + i] = V[i][j]
+    for (int i = 0; i < n; i++) Vc[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 80; sweep++) {
+        double off = 0.0;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double *__restrict__ wp = &W[(size_t)p * rows], *__restrict__ wq = &W[(size_t)q * rows];
+                double a = 0, b = 0, g = 0;
+                for (size_t i = 0; i < rows; i++) {
+                    a += wp[i] * wp[i];
+                    b += wq[i] * wq[i];
+                    g += wp[i] * wq[i];
+                }
+                if (g == 0.0 || !(a > 0.0) || !(b > 0.0)) continue;
+                const double rel = std::fabs(g) / std::sqrt(a * b);
+                off = std::max(off, rel);
+                if (rel <= 1e-16) continue;
+                const double zeta = (b - a) / (2.0 * g);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+                for (size_t i = 0; i < rows; i++) {
+                    const double x = wp[i], y = wq[i];
+                    wp[i] = cs * x - sn * y;
+                    wq[i] = sn * x + cs * y;
+                }
+                double *vp = &Vc[(size_t)p * n], *vq = &Vc[(size_t)q * n];
+                for (int i = 0; i < n; i++) {
+                    const double x = vp[i], y = vq[i];
+                    vp[i] = cs * x - sn * y;
+                    vq[i] = sn * x + cs * y;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    std::vector<double> sv(n);
+    std::vector<int> ord(n);
+    for (int j = 0; j < n; j++) {
+        double a = 0;
+        for (size_t i = 0; i < rows; i++) a += W[(size_t)j * rows + i] * W[(size_t)j * rows + i];
+        sv[j] = std::sqrt(a);
+        ord[j] = j;
+    }
+    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return sv[x] > sv[y]; });
+    U.assign(rows * n, 0.0);
+    V.assign((size_t)n * n, 0.0);
+    S.assign(n, 0.0);
+    for (int jj = 0; jj < n; jj++) {
+        const int j = ord[jj];
+        S[jj] = sv[j];
+        if (sv[j] > 0)
+            for (size_t i = 0; i < rows; i++) U[i * n + jj] = W[(size_t)j * rows + i] / sv[j];
+        for (int i = 0; i < n; i++) V[(size_t)i * n + jj] = Vc[(size_t)j * n + i];
+    }
+}
+
 // Rayleigh-Ritz finish shared by svd_bk and svd_rand: given an orthonormal Q on side S (dimension ds,
 // q columns), T = op(Q) on the other side (dimension dt), return the top-k triplets.
 //   side_S_vectors = Q * E, side_T_vectors = T * E * Sigma^-1, sigma = sqrt(eig(T^T T)).
@@ -339,6 +403,64 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
         if (!sym_eig_topk(G.data(), (int)q, (int)k, w.data(), Z.data()))
             fail(SCANRS_ERR_NUMERICAL, "eigensolver did not converge");
     }
+    const uint32_t ldk = even_up(k);
+    double *dS = c.dev("ritz_s", (size_t)ds * ldk);
+    double *dT = c.dev("ritz_t", (size_t)dt * ldk);
+    // sigma_i^2 are eigenvalues of T^T T: relative accuracy eps (sigma_1 / sigma_i)^2. When the k-th requested value sits
+    // at or below the numerical rank (w_k <= 1e-12 w_1: k near min(m, n), rank-deficient input) the reference's svddc on T
+    // is still accurate and orthonormal; the Gram route is not. Small problems go through a one-sided Jacobi SVD of T on
+    // the host; large ones are refused rather than answered with zero or inaccurate vectors.
+    if (!(w[k - 1] > 1e-12 * w[0]) || !(w[0] > 0.0)) {
+        if (t_sharded || (double)dt * q > 3.0e7)
+            fail(SCANRS_ERR_NUMERICAL, "requested singular values reach the numerical rank of the projection (sigma_%u / sigma_1 < 1e-6)", k);
+        Tick tk("ritz: host Jacobi SVD of T (rank-deficient)");
+        std::vector<double> hTm((size_t)dt * q), Uj, Sj, Vj;
+        download_panel(c, T, ldt, dt, q, hTm.data());
+        jacobi_svd_tall(std::move(hTm), (size_t)dt, (int)q, Uj, Sj, Vj);
+        std::vector<double> Ek((size_t)q * k), Uk((size_t)dt * k);
+        for (uint32_t j = 0; j < k; j++) {
+            hSigma[j] = Sj[j];
+            for (uint32_t i = 0; i < q; i++) Ek[(size_t)i * k + j] = Vj[(size_t)i * q + j];
+            for (uint64_t i = 0; i < dt; i++) Uk[i * k + j] = Uj[i * q + j];
+        }
+        // columns of the T side beyond the rank: any orthonormal completion (the reference's LAPACK returns one); here by
+        // Gram-Schmidt of unit vectors against the columns already present
+        for (uint32_t j = 0; j < k; j++) {
+            if (Sj[j] > 0.0) continue;
+            for (uint64_t e0 = 0; e0 < dt; e0++) {
+                std::vector<double> cand(dt, 0.0);
+                cand[e0] = 1.0;
+                for (int pass = 0; pass < 2; pass++)
+                    for (uint32_t jj = 0; jj < k; jj++) {
+                        if (jj == j || (jj > j && !(Sj[jj] > 0.0))) continue;
+                        double d = 0;
+                        for (uint64_t i = 0; i < dt; i++) d += cand[i] * Uk[i * k + jj];
+                        for (uint64_t i = 0; i < dt; i++) cand[i] -= d * Uk[i * k + jj];
+                    }
+                double nn = 0;
+                for (uint64_t i = 0; i < dt; i++) nn += cand[i] * cand[i];
+                if (nn > 0.25) {
+                    nn = std::sqrt(nn);
+                    for (uint64_t i = 0; i < dt; i++) Uk[i * k + j] = cand[i] / nn;
+                    break;
+                }
+            }
+        }
+        double *dE2 = c.dev("ritz_e", (size_t)q * k);
+        c.h2d(dE2, Ek.data(), Ek.size());
+        launch_gemm_nn(c.st, Q, ldq, q, dE2, k, k, ds, 1.0, 0.0, nullptr, 0, dS, ldk);
+        upload_panel(c, Uk.data(), dt, k, dT, ldk);
+        if (hS) download_panel(c, dS, ldk, ds, k, hS);
+        if (hT) memcpy(hT, Uk.data(), Uk.size() * 8);
+        c.sync();
+        c.st.pca_dev.k = k;
+        c.st.pca_dev.ld_u = c.st.pca_dev.ld_v = ldk;
+        c.st.pca_dev.u = dS;
+        c.st.pca_dev.rows_u = ds;
+        c.st.pca_dev.v = dT;
+        c.st.pca_dev.rows_v = dt;
+        return;
+    }
     std::vector<double> E((size_t)q * k), Es((size_t)q * k);
     for (uint32_t j = 0; j < k; j++) {
         const double sig = std::sqrt(std::max(w[j], 0.0));
@@ -349,18 +471,27 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
             Es[(size_t)i * k + j] = Z[(size_t)i * k + j] * inv;
         }
     }
-    const uint32_t ldk = even_up(k);
-    double *dS = c.dev("ritz_s", (size_t)ds * ldk);
-    double *dT = c.dev("ritz_t", (size_t)dt * ldk);
     double *dE = c.dev("ritz_e", (size_t)q * k);
     c.h2d(dE, E.data(), E.size());
     launch_gemm_nn(c.st, Q, ldq, q, dE, k, k, ds, 1.0, 0.0, nullptr, 0, dS, ldk);
     double *dEs = c.dev("ritz_es", (size_t)q * k);
     c.h2d(dEs, Es.data(), Es.size());
     launch_gemm_nn(c.st, T, ldt, q, dEs, k, k, dt, 1.0, 0.0, nullptr, 0, dT, ldk);
-    if (hS) download_panel(c, dS, ldk, ds, k, hS); // null: the caller keeps the result in HBM
+    if (hS) download_panel(c, dS, ldk, ds, k, hS); // null: the caller keeps the result in HBM (scanrs_pca_result_device)
     if (hT) download_panel(c, dT, ldk, dt, k, hT);
     c.sync();
+    // where the factors live on the device: side S first, side T second (the drivers map them to U / V)
+    c.st.pca_dev.k = k;
+    c.st.pca_dev.ld_u = c.st.pca_dev.ld_v = ldk;
+    c.st.pca_dev.u = dS;
+    c.st.pca_dev.rows_u = ds;
+    c.st.pca_dev.v = dT;
+    c.st.pca_dev.rows_v = dt;
+}
+// ritz_finish leaves (side S, side T) in pca_dev.(u, v); swap when side S holds V
+static void pca_dev_swap(Storage &st) {
+    std::swap(st.pca_dev.u, st.pca_dev.v);
+    std::swap(st.pca_dev.rows_u, st.pca_dev.rows_v);
 }
 
 int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
@@ -387,8 +518,32 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
     // op S->T: A*X when m >= n (X on the cols side), A^T*X otherwise
     const bool to_t_transpose = !rows_ge;
 
+    if ((uint64_t)b * n_iter > ds) {
+        // The Krylov matrix K (ds x b n_iter) is wider than it is tall: `K.qr()` (bk_svd.rs:98,127) then returns a square Q
+        // spanning the whole side, T = Q^T A loses nothing and the driver returns the exact truncated SVD (small feature
+        // panels: antibody / targeted-gene matrices, k close to min(m, n)). Any orthonormal basis of the whole space gives
+        // the same singular triplets, so Q = I: one sparse product with the identity panel, then the Rayleigh-Ritz finish.
+        const uint32_t qe = (uint32_t)ds, ldqe = even_up(qe);
+        double *Ke = c.dev("bk_K", (size_t)ds * ldqe);
+        double *Te = c.dev("bk_T", (size_t)dt * ldqe);
+        std::vector<double> eye((size_t)ds * qe, 0.0);
+        for (uint32_t i = 0; i < qe; i++) eye[(size_t)i * qe + i] = 1.0;
+        SCANRS_HIP(hipMemsetAsync(Ke, 0, (size_t)ds * ldqe * 8, c.s));
+        upload_panel(c, eye.data(), ds, qe, Ke, ldqe);
+        for (uint32_t i = 0; i < n_iter; i++) progress_check(snoop, (double)i / (double)n_iter * 0.8); // the reference's poll points
+        mat_apply(m, to_t_transpose, Ke, ldqe, qe, Te, ldqe);
+        c.sync();
+        progress_check(snoop, 0.93);
+        if (rows_ge) {
+            ritz_finish(c, Ke, ldqe, qe, ds, Te, ldqe, dt, t_sharded, k, v, s, u);
+            pca_dev_swap(c.st);
+        } else {
+            ritz_finish(c, Ke, ldqe, qe, ds, Te, ldqe, dt, t_sharded, k, u, s, v);
+        }
+        progress_check(snoop, 1.0);
+        return SCANRS_OK;
+    }
     const uint32_t ldb = even_up(b), q = b * n_iter, ldq = even_up(q);
-    if ((uint64_t)q > ds) fail(SCANRS_ERR_INVALID_K, "block size times iterations exceeds the matrix dimension");
     double *P = c.dev("bk_P", (size_t)ds * ldb);
     double *Ptmp = c.dev("bk_Ptmp", (size_t)ds * ldb);
     double *Y = c.dev("bk_Y", (size_t)dt * ldb);
@@ -598,10 +753,12 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
     Tick tk_fin("bk: ritz_finish");
     progress_check(snoop, 0.93);
     // m >= n: T = A Q (m x q): U = T E S^-1, V = Q E.   n > m: T^T = A^T Q (n x q): U = Q E, V = T E S^-1.
-    if (rows_ge)
+    if (rows_ge) {
         ritz_finish(c, K, ldq, q, ds, T, ldq, dt, t_sharded, k, v, s, u);
-    else
+        pca_dev_swap(c.st); // side S = cols: it holds V
+    } else {
         ritz_finish(c, K, ldq, q, ds, T, ldq, dt, t_sharded, k, u, s, v);
+    }
     progress_check(snoop, 1.0);
     return SCANRS_OK;
 }
@@ -615,8 +772,10 @@ int pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, ui
     if (Mg < 2 || Ng < 2) fail(SCANRS_ERR_SHAPE, "The input matrix must be at least 2x2.");
     if (k > std::min(Mg, Ng)) fail(SCANRS_ERR_INVALID_K, "invalid k");
     if (k == 0) fail(SCANRS_ERR_ARGUMENT, "k must be positive");
-    const uint32_t l = (uint32_t)std::max<uint64_t>(k + 4, (uint64_t)((double)k * l_multiplier)); // rand_svd.rs:46
-    if ((uint64_t)l > std::min(Mg, Ng)) fail(SCANRS_ERR_INVALID_K, "projection width exceeds the matrix dimension");
+    const uint32_t l_full = (uint32_t)std::max<uint64_t>(k + 4, (uint64_t)((double)k * l_multiplier)); // rand_svd.rs:46
+    // A projection wider than the matrix is short (rand_svd.rs accepts it: qr() of the wide panel returns a basis of the
+    // whole range and the result is the exact truncated SVD): its leading min(m, n) columns already span that range.
+    const uint32_t l = (uint32_t)std::min<uint64_t>(l_full, std::min(Mg, Ng));
     const bool rows_ge = Mg >= Ng;
     // m >= n: Omega on the cols side (n x l); Q ends on the rows side.  n > m: Omega (l x m), Q ends on the cols side.
     const uint64_t d_om = rows_ge ? N : M, d_q = rows_ge ? M : N;
@@ -635,9 +794,10 @@ int pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, ui
                 omega_fill_device(c.st, seed, d_om, l, Om, ldl, false);
             else
                 omega_fill_device(c.st, seed, l, d_om, Om, ldl, true);
-        } else if (rows_ge) {
-            upload_panel(c, omega, d_om, l, Om, ldl);
-        } else {
+        } else if (rows_ge) { // (cols x l_full) row-major: the leading l columns
+            SCANRS_HIP(hipMemcpy2DAsync(Om, (size_t)ldl * 8, omega, (size_t)l_full * 8, (size_t)l * 8, d_om, hipMemcpyHostToDevice, c.s));
+            c.sync();
+        } else { // (l_full x rows) row-major: the leading l rows
             double *tmp2 = c.dev("rs_omega_t", (size_t)l * d_om);
             c.h2d(tmp2, omega, (size_t)l * d_om);
             launch_transpose(c.st, tmp2, l, d_om, Om, ldl);
@@ -655,10 +815,12 @@ int pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, ui
     // B = Q^T A  (l x n)  resp. B = A Q: its transpose/ itself lives on the Omega side
     mat_apply(m, !om_to_q_transpose, Qp, ldl, l, Om, ldl);
     c.sync();
-    if (rows_ge)
+    if (rows_ge) {
         ritz_finish(c, Qp, ldl, l, d_q, Om, ldl, d_om, om_sharded, k, u, s, v);
-    else
+    } else {
         ritz_finish(c, Qp, ldl, l, d_q, Om, ldl, d_om, om_sharded, k, v, s, u);
+        pca_dev_swap(c.st); // side S (Q) = cols: it holds V
+    }
     return SCANRS_OK;
 }
 
@@ -754,6 +916,7 @@ int pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t maxit, const doub
     if (M < 2 || N < 2) fail(SCANRS_ERR_SHAPE, "The input matrix must be at least 2x2.");
     if (nu > std::min(M, N) || nu == 0) fail(SCANRS_ERR_INVALID_K, "invalid k");
     if (m->off_rank) fail(SCANRS_ERR_ARGUMENT, "irlba: LowRankOffset has no Ix1 Dot impl in the reference (low_rank_offset.rs:68-96)");
+    if (maxit == 0) fail(SCANRS_ERR_ARGUMENT, "irlba: max_iter must be positive"); // the epilogue reads the last iteration's factors
     const uint32_t m_b = (uint32_t)std::min<uint64_t>(nu + 20, std::min<uint64_t>(3ull * nu, N)); // irlba.rs:87
     if (m_b < 4 || m_b <= nu) fail(SCANRS_ERR_INVALID_K, "invalid k");
     const uint32_t ldm = even_up(m_b);

@@ -47,6 +47,57 @@ def synth_counts(n_cells: int, n_genes: int, density: float, seed: int = 0, n_cl
     return m
 
 
+def synth_counts_fast(n_cells: int, n_genes: int, density: float, seed: int = 0, n_clusters: int = 20, chunk: int = 8192):
+    """The same model in its Poisson-process form, ~20x faster on the host (used for the BASELINE-size fixtures, which
+    both the fixture script and the GPU test have to regenerate): gene g is present in cell c when a Poisson process
+    of intensity depth_c * rate[cluster_c, g] * density / mean(rate) has at least one event, i.e. with probability
+    1 - exp(-depth * rate * scale) (= depth * rate * scale to first order, the Bernoulli probability of `synth_counts`).
+    Per cell: N ~ Poisson(depth * sum of the cluster's scaled rates) events, each assigned to a gene by inverting the
+    cluster's cumulative rate table (the positions of a cell drawn already sorted, as normalised partial sums of
+    exponential spacings), duplicates merged. Counts 1 + Geometric(0.6) as before. A different random stream
+    from `synth_counts`, deterministic for a given numpy Generator implementation."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(seed)
+    rates = _profiles(rng, n_clusters, n_genes)
+    scale = density / rates.mean()
+    cum = np.cumsum(rates * scale, axis=1)  # n_clusters x n_genes
+    total = cum[:, -1].copy()
+    big = float(np.ceil(total.max())) + 1.0
+    cum_flat = (cum + big * np.arange(n_clusters)[:, None]).ravel()  # one increasing table for all clusters
+    cluster = rng.integers(0, n_clusters, size=n_cells)
+    depth = np.exp(rng.normal(0.0, 0.3, size=n_cells))
+    indptr = np.zeros(n_cells + 1, dtype=np.int64)
+    idx_parts, val_parts = [], []
+    for c0 in range(0, n_cells, chunk):
+        c1 = min(n_cells, c0 + chunk)
+        cl = cluster[c0:c1]
+        n_ev = rng.poisson(depth[c0:c1] * total[cl])
+        # the N event positions of a cell in ascending order = normalised partial sums of N + 1 exponential spacings
+        starts = np.concatenate(([0], np.cumsum(n_ev + 1)))
+        e = rng.standard_exponential(int(starts[-1]))
+        cs = np.cumsum(e)
+        seg_base = np.concatenate(([0.0], cs[starts[1:-1] - 1]))  # partial sum before each cell's first spacing
+        seg_total = cs[starts[1:] - 1] - seg_base
+        keep = np.ones(e.shape[0], dtype=bool)
+        keep[starts[1:] - 1] = False  # the (N+1)-th spacing only closes the interval
+        cell = np.repeat(np.arange(c1 - c0), n_ev)
+        u = (cs[keep] - seg_base[cell]) / seg_total[cell] * total[cl][cell]
+        gene = np.searchsorted(cum_flat, u + big * cl[cell], side="right") - cl[cell] * n_genes
+        np.clip(gene, 0, n_genes - 1, out=gene)
+        first = np.ones(gene.shape[0], dtype=bool)  # ascending per cell: a duplicate equals its predecessor in the same cell
+        first[1:] = (gene[1:] != gene[:-1]) | (cell[1:] != cell[:-1])
+        indptr[c0 + 1:c1 + 1] = np.bincount(cell[first], minlength=c1 - c0)
+        idx_parts.append(gene[first].astype(np.uint32))
+        val_parts.append(rng.geometric(0.6, size=int(first.sum())).astype(np.uint32))
+    indptr = np.cumsum(indptr)
+    indices = np.concatenate(idx_parts) if idx_parts else np.zeros(0, dtype=np.uint32)
+    values = np.concatenate(val_parts) if val_parts else np.zeros(0, dtype=np.uint32)
+    m = sp.csr_matrix((values, indices.astype(np.int64), indptr), shape=(n_cells, n_genes))
+    m.has_sorted_indices = True
+    return m
+
+
 def synth_counts_torch(n_cells: int, n_genes: int, density: float, seed: int, device, cell_begin: int = 0,
                        cell_end: int | None = None, n_clusters: int = 20, chunk: int = 4096):
     """Device-side generator: returns (indptr int64[n_local+1], indices int32[nnz], values int32[nnz])

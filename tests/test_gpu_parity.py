@@ -716,17 +716,74 @@ def test_bksvd_parameter_grid_matches_oracle(sa, k, mult, n_iter):
 
 
 def test_bksvd_block_clipped_to_matrix_size(sa):
-    # b = min(m, n, b) (bk_svd.rs:81): a 12 x 40 matrix with k = 5 -> b = 10, then 5 blocks of 10 > 12 rows is refused
+    # b = min(m, n, b) (bk_svd.rs:81): a 12 x 40 matrix with k = 5 -> b = 10, 5 blocks of 10 > 12 rows: K is wider than tall, qr()
+    # returns a square Q and the driver returns the exact truncated SVD (the reference accepts the shape; round-1 refused it)
     rng = np.random.default_rng(3)
     dense = random_counts(rng, 12, 40, 0.7, 9) + 1
     g, o = pair(sa, dense, so.CSR)
-    with pytest.raises(sa.ScanrsError):
-        sa.BkSvd().run_pca(g, 5)
+    u, s, v = sa.BkSvd().run_pca(g, 5)
+    uo, s_o, vo = so.BkSvd().run_pca(o, 5)
+    full = np.linalg.svd(dense.astype(np.float64), compute_uv=False)
+    assert np.max(np.abs(s - full[:5]) / full[:5]) < 1e-10 and np.max(np.abs(s - s_o) / s_o) < 1e-10
+    assert np.max(np.abs(_sign_fix(u, uo) - uo)) < 1e-8 and np.max(np.abs(_sign_fix(v, vo) - vo)) < 1e-8
     # 2 x 2 is the smallest accepted input (bk_svd.rs:73-75)
     g2, o2 = pair(sa, np.array([[3, 1], [1, 2]], dtype=np.uint32), so.CSR)
     u, s, v = sa.BkSvd(1.0, 2).run_pca(g2, 1)
     full = np.linalg.svd(np.array([[3.0, 1.0], [1.0, 2.0]]), compute_uv=False)
     assert abs(s[0] - full[0]) < 1e-9 * full[0]
+
+
+@pytest.mark.parametrize("storage", [so.CSR, so.CSC])
+def test_small_feature_panel_wide_krylov_and_wide_projection(sa, storage):
+    """min(m, n) < b * n_iter (svd_bk) and l > min(m, n) (svd_rand): 50 features, k = 10 -> b = 20, q = 100; l = 100. Antibody /
+    targeted panels. The reference's qr() of the wide matrix spans everything: exact truncated SVD."""
+    rng = np.random.default_rng(11)
+    dense = random_counts(rng, 50, 700, 0.3, 30)
+    g, o = pair(sa, dense, storage)
+    g, o = sa.normalize(g, sa.Normalization.CellRanger), so.normalize(o, "cellranger")
+    exact = np.linalg.svd(o.to_dense(), compute_uv=False)
+    for drv, odrv in ((sa.BkSvd(), so.BkSvd()), (sa.RandSvd(), so.RandSvd())):
+        u, s, v = drv.run_pca(g, 10)
+        uo, s_o, vo = odrv.run_pca(o, 10)
+        assert np.max(np.abs(s - exact[:10]) / exact[:10]) < 1e-10
+        assert np.max(np.abs(s - s_o) / s_o) < 1e-10
+        assert np.max(np.abs(_sign_fix(u, uo) - uo)) < 1e-7 and np.max(np.abs(_sign_fix(v, vo) - vo)) < 1e-7
+        assert np.max(np.abs(u.T @ u - np.eye(10))) < 1e-12 and np.max(np.abs(v.T @ v - np.eye(10))) < 1e-12
+    # the transposed view takes the other branch
+    u, s, v = sa.BkSvd().run_pca(g.t(), 10)
+    assert np.max(np.abs(s - exact[:10]) / exact[:10]) < 1e-10
+
+
+def test_components_beyond_the_numerical_rank(sa):
+    """k = min(m, n) on a rank-deficient matrix: the Gram-matrix route would square the condition number and return zero
+    vectors for sigma = 0; the library switches to a one-sided Jacobi SVD of the projection (small problems) — accurate small
+    singular values, orthonormal vectors, as the reference's svddc gives."""
+    rng = np.random.default_rng(12)
+    base = random_counts(rng, 6, 300, 0.5, 20)
+    dense = np.vstack([base, base[:3] * 2, base[:1]])  # 10 x 300 of rank 6
+    g, o = pair(sa, dense, so.CSR)
+    exact = np.linalg.svd(dense.astype(np.float64), compute_uv=False)
+    u, s, v = sa.BkSvd().run_pca(g, 10)
+    assert np.max(np.abs(s[:6] - exact[:6]) / exact[:6]) < 1e-10
+    assert np.max(np.abs(s[6:])) < 1e-8 * exact[0]
+    assert np.max(np.abs(u.T @ u - np.eye(10))) < 1e-10  # a complete orthonormal set, zero singular values included
+    assert np.max(np.abs(v[:, :6].T @ v[:, :6] - np.eye(6))) < 1e-10
+    assert np.max(np.abs(g.dot(v[:, :6]) - u[:, :6] * s[:6])) < 1e-8 * exact[0]
+    # tiny but nonzero singular values keep their relative accuracy
+    d2 = dense.astype(np.float64)
+    tiny = np.zeros((10, 300), dtype=np.uint32)
+    tiny[9, 7] = 1  # perturbation that lifts one zero singular value to ~1
+    g2, _ = pair(sa, dense + tiny, so.CSR)
+    ex2 = np.linalg.svd(d2 + tiny, compute_uv=False)
+    _, s2, _ = sa.BkSvd().run_pca(g2, 10)
+    assert abs(s2[6] - ex2[6]) < 1e-8 * ex2[6]
+
+
+def test_irlba_rejects_zero_iterations(sa):
+    g, _ = pair(sa, random_counts(np.random.default_rng(0), 30, 40, 0.5, 9), so.CSR)
+    with pytest.raises(sa.ScanrsError) as e:
+        sa.Irlba(1e-4, 0).run_pca(g, 3)
+    assert e.value.code == 6
 
 
 def test_empty_vectors_and_reset_map(sa):
