@@ -285,6 +285,10 @@ int scanrs_multi_pca_bk(scanrs_multi *mm, uint32_t k, double k_multiplier, uint3
                         const scanrs_snoop *snoop, double *u, double *s, double *v);
 int scanrs_multi_pca_rand(scanrs_multi *mm, uint32_t k, double l_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
                           double *u, double *s, double *v);
+int scanrs_multi_log_normalize(scanrs_multi *mm, double umi_count_sum, int log_fn, const uint32_t *size_factors);
+/* v0 (optional) spans ALL columns of the matrix. */
+int scanrs_multi_pca_irlba(scanrs_multi *mm, uint32_t nu, double tol, uint32_t max_iter, const double *v0, const scanrs_snoop *snoop,
+                           double *u, double *s, double *v, uint32_t *mprod);
 /* nnz-balanced contiguous partition of the outer dimension: bounds has world+1 entries. */
 int scanrs_plan_shards(const uint64_t *indptr, uint64_t n_outer, uint32_t world, uint64_t *bounds);
 

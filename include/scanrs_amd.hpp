@@ -253,4 +253,47 @@ struct Irlba { // dim_red/irlba.rs:36-57
     PcaResult run_pca(const AdaptiveMat &m, size_t k) const { return run_pca_cancellable(m, k, nullptr); }
 };
 
+// PcaResult left in device memory by the last BkSvd / RandSvd call on `m` (scanrs_pca_result_device): for device consumers
+struct PcaResultDevice {
+    const double *d_u = nullptr, *d_v = nullptr; // rows x k, cols x k, row-major with leading dimensions ld_u / ld_v (elements)
+    uint32_t ld_u = 0, ld_v = 0, k = 0;
+};
+inline PcaResultDevice pca_result_device(const AdaptiveMat &m) {
+    PcaResultDevice r;
+    check(scanrs_pca_result_device(m.raw(), &r.d_u, &r.ld_u, &r.d_v, &r.ld_v, &r.k));
+    return r;
+}
+// nn::knn on scores that are already in device memory
+inline std::vector<uint32_t> knn_device(const double *d_points, size_t n, uint32_t ld, uint32_t d, size_t k) {
+    std::vector<uint32_t> out(n * k);
+    check(scanrs_knn_device(d_points, n, ld, d, (uint32_t)k, out.data()));
+    return out;
+}
+
+// The single-process multi-GPU form (scanrs_multi_*): one object for the whole matrix, sharded by the library over
+// `n_shards` devices; normalize + run_pca as on a single handle, results for the whole matrix.
+class MultiMat {
+    scanrs_multi *h_ = nullptr;
+    size_t rows_ = 0, cols_ = 0;
+
+  public:
+    MultiMat(size_t rows, size_t cols, int storage, const uint64_t *indptr, const uint32_t *indices, const uint32_t *values,
+             uint32_t n_shards, const int *devices = nullptr)
+        : rows_(rows), cols_(cols) {
+        check(scanrs_multi_create(rows, cols, storage, indptr, indices, values, n_shards, devices, &h_));
+    }
+    MultiMat(const MultiMat &) = delete;
+    MultiMat &operator=(const MultiMat &) = delete;
+    ~MultiMat() { scanrs_multi_free(h_); }
+    size_t rows() const { return rows_; }
+    size_t cols() const { return cols_; }
+    void normalize(Normalization norm) { check(scanrs_multi_normalize(h_, (int)norm, nullptr)); }
+    PcaResult run_pca(const BkSvd &cfg, size_t k) {
+        PcaResult r{Array2(rows_, k), std::vector<double>(k), Array2(cols_, k)};
+        check(scanrs_multi_pca_bk(h_, (uint32_t)k, cfg.k_multiplier, (uint32_t)cfg.n_iter, 0, nullptr, nullptr, r.u.data.data(),
+                                  r.s.data(), r.v.data.data()));
+        return r;
+    }
+};
+
 } // namespace scanrs

@@ -73,12 +73,22 @@ def _clib():
     return _lib
 
 
+_THREADS = 1
+_OTHER_COPY = {}  # all-core mode only: (indptr address, indices address) -> the other orientation of the same triplet
+
+
 def set_threads(t: int) -> int:
     """Threads of the sparse loops (bench.py's all-core CPU baseline). 1 = the serial reference order (default, the
-    mode every parity pin is taken in); returns the thread count in force."""
+    mode every parity pin is taken in); returns the thread count in force. With more than one thread the scatter form
+    of the product (CSC storage, sqz/src/prod.rs:190-214) is served by the gather loop on a transposed copy of the
+    matrix built once per matrix (what a rayon port would do: output rows dealt to threads, no write conflicts)."""
+    global _THREADS
     lib = _clib()
     lib.oracle_set_threads(ctypes.c_int(int(t)))
-    return int(lib.oracle_get_threads())
+    _THREADS = int(lib.oracle_get_threads())
+    if _THREADS == 1:
+        _OTHER_COPY.clear()
+    return _THREADS
 
 
 def max_threads() -> int:
@@ -248,10 +258,30 @@ class AdaptiveMat:
             rhs_c = np.ascontiguousarray(rhs, dtype=np.float64)
             out = np.zeros((self.rows, l), dtype=np.float64)
             arr, n, _keep = self._call_args()
-            _clib().oracle_spmm_f64(
-                ctypes.c_int(self.storage), ctypes.c_size_t(self.n_outer), _ptr(self.indptr), _ptr(self.indices),
-                _ptr(self.values), arr, ctypes.c_int(n), _ptr(rhs_c), ctypes.c_size_t(l), _ptr(out))
+            if _THREADS > 1 and self.storage == CSC:  # all-core baseline: gather on the transposed copy, rows dealt to threads
+                ip2, ix2, vv2 = self.other_copy()
+                _clib().oracle_spmm_f64(
+                    ctypes.c_int(CSR), ctypes.c_size_t(self.rows), _ptr(ip2), _ptr(ix2), _ptr(vv2), arr, ctypes.c_int(n),
+                    _ptr(rhs_c), ctypes.c_size_t(l), _ptr(out))
+            else:
+                _clib().oracle_spmm_f64(
+                    ctypes.c_int(self.storage), ctypes.c_size_t(self.n_outer), _ptr(self.indptr), _ptr(self.indices),
+                    _ptr(self.values), arr, ctypes.c_int(n), _ptr(rhs_c), ctypes.c_size_t(l), _ptr(out))
         return out[:, 0] if one_d else out
+
+    def other_copy(self):
+        """(indptr, indices, values) of the same matrix in the other orientation (all-core baseline only; cached per triplet)."""
+        import scipy.sparse as sp
+
+        key = (self.indptr.ctypes.data, self.indices.ctypes.data)
+        if key not in _OTHER_COPY:
+            cls = sp.csr_matrix if self.storage == CSR else sp.csc_matrix
+            m = cls((self.values, self.indices.astype(np.int64), self.indptr.astype(np.int64)), shape=(self.rows, self.cols))
+            o = m.tocsc() if self.storage == CSR else m.tocsr()
+            o.sort_indices()
+            _OTHER_COPY[key] = (np.ascontiguousarray(o.indptr, dtype=np.uint64), np.ascontiguousarray(o.indices, dtype=np.uint32),
+                                np.ascontiguousarray(o.data, dtype=np.uint32), self.indptr, self.indices)  # keep the key's arrays alive
+        return _OTHER_COPY[key][:3]
 
     def rdot(self, lhs: np.ndarray) -> np.ndarray:
         """`lhs.dot(&self)` (sqz/src/mat.rs:1124-1132): transpose both, run the other
@@ -506,6 +536,23 @@ class SmallRng:
         return (v12 - 1.0) * 2.0 + (-1.0)
 
 
+    def normal(self, count: int) -> np.ndarray:
+        """Standard normals by Box-Muller on the same stream, one value per pair of draws (u1 from the top 53 bits + 1/2 ulp,
+        cos branch only) — the rule the product's default IRLBA start vector uses (solver.cpp SmallRng::normal). The
+        reference draws `Normal` through rand_distr 0.6's ziggurat (irlba.rs:107-112), whose tables are not under
+        /root/reference: parity unpinned for the DEFAULT start vector; tests pass v0 explicitly or compare results that
+        do not depend on it."""
+        out = np.empty(count)
+        for i in range(count):
+            while True:
+                u1 = ((self.next_u64() >> 11) + 0.5) * (1.0 / 9007199254740992.0)
+                if u1 > 0.0:
+                    break
+            u2 = ((self.next_u64() >> 11) + 0.5) * (1.0 / 9007199254740992.0)
+            out[i] = np.sqrt(-2.0 * np.log(u1)) * np.cos(6.283185307179586 * u2)
+        return out
+
+
 def omega_panel(shape, seed: int = 0) -> np.ndarray:
     """`Array2::from_shape_simple_fn(shape, || unif.sample(&mut rng))`: row-major fill order."""
     return SmallRng(seed).uniform_m1_1(int(shape[0]) * int(shape[1])).reshape(shape)
@@ -657,7 +704,7 @@ def irlba(A, nu: int, tol: float, maxit: int, v0: Optional[np.ndarray] = None, s
     F = np.zeros(n)
     B = np.zeros((m_b, m_b))
     if v0 is None:
-        v0 = np.random.default_rng(0).standard_normal(n)
+        v0 = SmallRng(0).normal(n)  # seed 0 as irlba.rs:107; same restatement as the product (see SmallRng.normal)
     v0 = np.asarray(v0, dtype=np.float64)
     V[:, 0] = v0 * (1.0 / _norm(v0))
     u = sigma = vt = None

@@ -674,6 +674,21 @@ class MultiMat:
                                           ctypes.c_uint64(seed), _p(om), _p(u), _p(s), _p(v)))
         return u, s, v
 
+    def log_normalize(self, umi_count_sum=None, log_fn: int = 3, size_factors=None):
+        sf = None if size_factors is None else np.ascontiguousarray(size_factors, dtype=np.uint32)
+        _check(_lib.scanrs_multi_log_normalize(self._h, ctypes.c_double(-1.0 if umi_count_sum is None else umi_count_sum),
+                                               ctypes.c_int(log_fn), _p(sf)))
+        return self
+
+    def run_pca_irlba(self, k: int, tol: float = 1e-4, max_iter: int = 50, v0=None):
+        u, s, v = np.zeros((self.rows, k)), np.zeros(k), np.zeros((self.cols, k))
+        v0c = None if v0 is None else _f64(v0)
+        mp = ctypes.c_uint32()
+        _check(_lib.scanrs_multi_pca_irlba(self._h, ctypes.c_uint32(k), ctypes.c_double(tol), ctypes.c_uint32(max_iter), _p(v0c), None,
+                                           _p(u), _p(s), _p(v), ctypes.byref(mp)))
+        self.mprod = int(mp.value)
+        return u, s, v
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             _lib.scanrs_multi_free(self._h)
@@ -803,7 +818,7 @@ EXPORTED_SYMBOLS = [
     "scanrs_mat_dot", "scanrs_mat_rdot", "scanrs_mat_dot_u32", "scanrs_mat_rdot_u32", "scanrs_mat_dot_device",
     "scanrs_normalize", "scanrs_log_normalize", "scanrs_log1p_normalize_fixed_point", "scanrs_mat_target_umi",
     "scanrs_pca_bk", "scanrs_pca_rand", "scanrs_pca_irlba", "scanrs_pca_result_device", "scanrs_knn_device", "scanrs_omega_fill", "scanrs_mat_set_shard", "scanrs_mat_set_shard_comm", "scanrs_comm_get_unique_id", "scanrs_comm_create", "scanrs_comm_free",
-    "scanrs_multi_create", "scanrs_multi_free", "scanrs_multi_n_shards", "scanrs_multi_shard", "scanrs_multi_normalize", "scanrs_multi_pca_bk", "scanrs_multi_pca_rand",
+    "scanrs_multi_create", "scanrs_multi_free", "scanrs_multi_n_shards", "scanrs_multi_shard", "scanrs_multi_normalize", "scanrs_multi_pca_bk", "scanrs_multi_pca_rand", "scanrs_multi_pca_irlba", "scanrs_multi_log_normalize",
     "scanrs_plan_shards", "scanrs_profile_enable", "scanrs_profile_reset", "scanrs_profile_get", "scanrs_mat_sync", "scanrs_mat_set_spmm_path", "scanrs_mat_set_panel_precision",
     "scanrs_host_chol_upper", "scanrs_host_inv_upper", "scanrs_host_sym_eig", "scanrs_host_sym_eig_topk",
 ]

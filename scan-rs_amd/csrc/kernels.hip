@@ -903,28 +903,86 @@ __global__ void row_reduce_finish_kernel(const MultiRow *__restrict__ multi, uin
 
 // ---------------------------------------------------------------------------------------------
 // w[q,:] = sum_i B[i,q] * X[i,:]   (the `v.dot(rhs)` / `lhs.dot(u)` of low_rank_offset.rs:76-95)
+// Streaming form: a wave walks rows r0 + wave, r0 + wave + 4, ... of its block's slice, lanes own column pairs (one 16-byte load
+// per lane per row, a panel row = one coalesced read), 8 rows in flight per wave; the four waves' partial sums meet in LDS in
+// wave order (deterministic). HBM-bound: n x l x 8 bytes once.
 __global__ __launch_bounds__(256) void weighted_colsum_partial_kernel(const double *__restrict__ B, uint32_t rank,
                                                                       const double *__restrict__ X, uint32_t ldx,
                                                                       uint64_t n, uint32_t l, uint64_t rows_per_block,
                                                                       double *__restrict__ partial) {
+    __shared__ d2 part[3][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_block;
     const uint64_t r1 = min(n, r0 + rows_per_block);
     for (uint32_t q = 0; q < rank; q++) {
-        for (uint32_t c = threadIdx.x; c < l; c += blockDim.x) {
-            double s = 0.0;
-            for (uint64_t i = r0; i < r1; i++) s = fma(B[i * rank + q], X[i * ldx + c], s);
-            partial[((size_t)blockIdx.x * rank + q) * l + c] = s;
+        for (uint32_t c0 = 0; c0 < l; c0 += 128u) {
+            const uint32_t col = c0 + lane * 2u;
+            const bool act = col < l; // ldx is even and >= l rounded up to even: the pair load stays inside the row
+            d2 acc = {0.0, 0.0};
+            if (act) {
+                uint64_t i = r0 + wave;
+                for (; i + 28u < r1; i += 32u) {
+                    d2 x[8];
+                    double b[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        x[u] = *reinterpret_cast<const d2 *>(X + (i + 4u * u) * ldx + col);
+                        b[u] = B[(i + 4u * u) * rank + q];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        acc.x = fma(b[u], x[u].x, acc.x);
+                        acc.y = fma(b[u], x[u].y, acc.y);
+                    }
+                }
+                for (; i < r1; i += 4u) {
+                    const d2 x = *reinterpret_cast<const d2 *>(X + i * ldx + col);
+                    const double b = B[i * rank + q];
+                    acc.x = fma(b, x.x, acc.x);
+                    acc.y = fma(b, x.y, acc.y);
+                }
+            }
+            __syncthreads(); // `part` free again
+            if (wave > 0) part[wave - 1][lane] = acc;
+            __syncthreads();
+            if (wave == 0 && act) {
+                for (int w = 0; w < 3; w++) {
+                    acc.x += part[w][lane].x;
+                    acc.y += part[w][lane].y;
+                }
+                double *dst = partial + ((size_t)blockIdx.x * rank + q) * l + col;
+                dst[0] = acc.x;
+                if (col + 1 < l) dst[1] = acc.y;
+            }
         }
     }
 }
-__global__ void weighted_colsum_finish_kernel(const double *__restrict__ partial, uint32_t nblocks, uint32_t rank,
-                                              uint32_t l, double *__restrict__ w, uint32_t ldw) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= rank * l) return;
-    const uint32_t q = e / l, c = e % l;
+// ordered sum of the per-block partials: 64 output entries per workgroup, the blocks dealt to 4 groups of 64 threads
+// (8 independent loads in flight each), the four group sums added in group order (deterministic)
+__global__ __launch_bounds__(256) void weighted_colsum_finish_kernel(const double *__restrict__ partial, uint32_t nblocks, uint32_t rank,
+                                                                     uint32_t l, double *__restrict__ w, uint32_t ldw) {
+    __shared__ double part[4][64];
+    const uint32_t e = blockIdx.x * 64u + (threadIdx.x & 63u), g = threadIdx.x >> 6;
+    const bool act = e < rank * l;
     double s = 0.0;
-    for (uint32_t b = 0; b < nblocks; b++) s += partial[((size_t)b * rank + q) * l + c];
-    w[(size_t)q * ldw + c] = s;
+    if (act) {
+        const size_t stride = (size_t)rank * l;
+        uint32_t b = g;
+        for (; b + 28u < nblocks; b += 32u) {
+            double t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = partial[(size_t)(b + 4u * u) * stride + e];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += t[u];
+        }
+        for (; b < nblocks; b += 4u) s += partial[(size_t)b * stride + e];
+    }
+    part[g][threadIdx.x & 63u] = s;
+    __syncthreads();
+    if (g == 0 && act) {
+        const uint32_t q = e / l, c = e % l, t = threadIdx.x;
+        w[(size_t)q * ldw + c] = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1648,7 +1706,7 @@ void launch_weighted_colsum(Storage &st, const double *B, uint32_t rank, const d
     ProfScope ps(st, "weighted_colsum", (double)n * l * 8.0 + (double)n * rank * 8.0);
     hipLaunchKernelGGL(weighted_colsum_partial_kernel, dim3(nblocks), dim3(256), 0, st.stream, B, rank, X, ldx, n, l, rpb,
                        partial);
-    hipLaunchKernelGGL(weighted_colsum_finish_kernel, grid1((uint64_t)rank * l, 256), dim3(256), 0, st.stream, partial,
+    hipLaunchKernelGGL(weighted_colsum_finish_kernel, grid1((uint64_t)rank * l, 64), dim3(256), 0, st.stream, partial,
                        nblocks, rank, l, w, ldw);
     SCANRS_HIP(hipGetLastError());
 }

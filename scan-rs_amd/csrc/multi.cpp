@@ -202,4 +202,46 @@ int scanrs_multi_pca_rand(scanrs_multi *mm, uint32_t k, double l_multiplier, uin
     });
 }
 
+// Irlba on the un-centred handle (irlba.rs:59-215; LowRankOffset has no Ix1 Dot impl). v0: optional start vector over ALL columns.
+int scanrs_multi_pca_irlba(scanrs_multi *mm, uint32_t nu, double tol, uint32_t max_iter, const double *v0, const scanrs_snoop *snoop,
+                           double *u, double *s, double *v, uint32_t *mprod) {
+    if (!u || !v) return SCANRS_ERR_ARGUMENT;
+    std::vector<uint32_t> mp(mm ? mm->shards.size() : 0, 0);
+    const int rc = multi_pca(mm, nu, u, s, v, [&](size_t i, double *ui, double *si, double *vi) {
+        scanrs_snoop sn;
+        const scanrs_snoop *psn = nullptr;
+        if (snoop) {
+            sn = *snoop;
+            if (i != 0) sn.progress = nullptr;
+            psn = &sn;
+        }
+        const bool cols_sharded = mm->storage == SCANRS_CSC;
+        const uint64_t n_loc = mm->bounds[i + 1] - mm->bounds[i];
+        // scanrs_pca_irlba wants both factors: the replicated one of shards > 0 goes to a scratch array
+        std::vector<double> spare;
+        if (!ui) {
+            spare.resize((size_t)(cols_sharded ? mm->rows : n_loc) * nu);
+            ui = spare.data();
+        }
+        if (!vi) {
+            spare.resize((size_t)(cols_sharded ? n_loc : mm->cols) * nu);
+            vi = spare.data();
+        }
+        const double *v0i = v0 ? (cols_sharded ? v0 + mm->bounds[i] : v0) : nullptr;
+        return scanrs_pca_irlba(mm->shards[i], nu, tol, max_iter, v0i, psn, ui, si, vi, &mp[i]);
+    });
+    if (mprod && !mp.empty()) *mprod = mp[0];
+    return rc;
+}
+
+// Raw-count log normalisation without the centre / scale step (the only input irlba.rs takes).
+int scanrs_multi_log_normalize(scanrs_multi *mm, double umi_count_sum, int log_fn, const uint32_t *size_factors) {
+    if (!mm) return SCANRS_ERR_ARGUMENT;
+    return fan_out(mm, [&](size_t i) {
+        const uint32_t *sf = size_factors;
+        if (sf && mm->storage == SCANRS_CSC) sf += mm->bounds[i];
+        return scanrs_log_normalize(mm->shards[i], umi_count_sum, log_fn, sf);
+    });
+}
+
 } // extern "C"

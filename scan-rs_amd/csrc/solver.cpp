@@ -912,12 +912,16 @@ int pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t maxit, const doub
               double *s, double *v, uint32_t *mprod_out) {
     Ctx c(m);
     const uint64_t M = m->rows(), N = m->cols();
-    if (c.st.shard.active()) fail(SCANRS_ERR_ARGUMENT, "irlba: sharded matrices are not supported");
-    if (M < 2 || N < 2) fail(SCANRS_ERR_SHAPE, "The input matrix must be at least 2x2.");
-    if (nu > std::min(M, N) || nu == 0) fail(SCANRS_ERR_INVALID_K, "invalid k");
+    // sharded handles: vectors on the sharded side are held by slices, their dot products and norms are all-reduced
+    // (gram_host), the products that contract over that side are all-reduced inside mat_apply; everything on the other side and
+    // the small bidiagonal problem are replicated and deterministic.
+    const bool sh_m = dim_sharded_rows(m), sh_n = dim_sharded_cols(m);
+    const uint64_t Mg = sh_m ? c.st.shard.outer_global : M, Ng = sh_n ? c.st.shard.outer_global : N;
+    if (Mg < 2 || Ng < 2) fail(SCANRS_ERR_SHAPE, "The input matrix must be at least 2x2.");
+    if (nu > std::min(Mg, Ng) || nu == 0) fail(SCANRS_ERR_INVALID_K, "invalid k");
     if (m->off_rank) fail(SCANRS_ERR_ARGUMENT, "irlba: LowRankOffset has no Ix1 Dot impl in the reference (low_rank_offset.rs:68-96)");
     if (maxit == 0) fail(SCANRS_ERR_ARGUMENT, "irlba: max_iter must be positive"); // the epilogue reads the last iteration's factors
-    const uint32_t m_b = (uint32_t)std::min<uint64_t>(nu + 20, std::min<uint64_t>(3ull * nu, N)); // irlba.rs:87
+    const uint32_t m_b = (uint32_t)std::min<uint64_t>(nu + 20, std::min<uint64_t>(3ull * nu, Ng)); // irlba.rs:87
     if (m_b < 4 || m_b <= nu) fail(SCANRS_ERR_INVALID_K, "invalid k");
     const uint32_t ldm = even_up(m_b);
     uint32_t mprod = 0, it = 0, j = 0, k = nu;
@@ -934,17 +938,17 @@ int pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t maxit, const doub
     {
         std::vector<double> h(N);
         if (v0)
-            memcpy(h.data(), v0, N * 8);
+            memcpy(h.data(), v0, N * 8); // the local slice when the columns are sharded
         else {
+            // seed 0 (irlba.rs:107); a sharded handle takes its slice of the one sequential stream
             SmallRng rng(0);
+            const uint64_t skip = sh_n ? c.st.shard.outer_begin : 0;
+            for (uint64_t i = 0; i < skip; i++) (void)rng.normal();
             for (auto &x : h) x = rng.normal();
         }
-        double nn = 0;
-        for (double x : h) nn += x * x;
-        nn = 1.0 / std::sqrt(nn);
-        for (auto &x : h) x *= nn;
         upload_panel(c, h.data(), N, 1, vv, 2);
-        set_col(c, V, ldm, 0, vv, N, 1.0);
+        const double nn = norm_dev(c, vv, N, sh_n); // global norm
+        set_col(c, V, ldm, 0, vv, N, 1.0 / nn);
     }
     double fnorm = 0.0;
     std::vector<double> resid(m_b);
@@ -953,8 +957,8 @@ int pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t maxit, const doub
         get_col(c, V, ldm, j, vv, N);
         mat_apply(m, false, vv, 2, 1, wv, 2); // W[:, j] = A V[:, j]
         mprod++;
-        if (it > 0) orthog_dev(c, wv, W, ldm, j, M, false); // irlba.rs:131-134 (assigned to column k == j)
-        double sn = norm_dev(c, wv, M, false);
+        if (it > 0) orthog_dev(c, wv, W, ldm, j, M, sh_m); // irlba.rs:131-134 (assigned to column k == j)
+        double sn = norm_dev(c, wv, M, sh_m);
         double sinv = invcheck(sn);
         set_col(c, W, ldm, j, wv, M, sinv);
         while (j < m_b) {
@@ -966,8 +970,8 @@ int pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t maxit, const doub
                 get_col(c, V, ldm, j, vv, N);
                 gemm_hostw(c, vv, 2, 1, a, 1, N, 1.0, 1.0, F, 2, "irlba_w");
             }
-            orthog_dev(c, F, V, ldm, j + 1, N, false);
-            fnorm = norm_dev(c, F, N, false);
+            orthog_dev(c, F, V, ldm, j + 1, N, sh_n);
+            fnorm = norm_dev(c, F, N, sh_n);
             const double finv = invcheck(fnorm);
             set_col(c, F, 2, 0, F, N, finv); // F *= finv (in place through the scale path)
             if (j == m_b - 1) {
@@ -984,8 +988,8 @@ int pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t maxit, const doub
                     get_col(c, W, ldm, j, wj, M);
                     gemm_hostw(c, wj, 2, 1, a, 1, M, 1.0, 1.0, wv, 2, "irlba_w");
                 }
-                orthog_dev(c, wv, W, ldm, j + 1, M, false);
-                sn = norm_dev(c, wv, M, false);
+                orthog_dev(c, wv, W, ldm, j + 1, M, sh_m);
+                sn = norm_dev(c, wv, M, sh_m);
                 sinv = invcheck(sn);
                 set_col(c, W, ldm, j + 1, wv, M, sinv);
             }

@@ -397,6 +397,33 @@ def test_irlba_matches_oracle(sa):
         sa.Irlba().run_pca(sa.normalize(pair(sa, random_counts(np.random.default_rng(0), 20, 30, 0.5, 5) + 1, so.CSR)[0], 0), 3)
 
 
+def test_irlba_sharded_and_default_start_vector(sa):
+    """IRLBA over cells range-partitioned on 2 shards (single-process form, both on GPU 0): the same singular values as the
+    unsharded handle at the tolerance of the solver's own stopping test; the default start vector (seed 0, Box-Muller on the
+    xoshiro stream) is the same restatement in the library and in the oracle (round-1 verdict: three different defaults)."""
+    m = _synth(3000, 500, 0.06, 4)  # cells x genes
+    k = 6
+    g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)  # genes x cells, cells sharded below
+    o = so.AdaptiveMat(m.shape[1], m.shape[0], so.CSC, m.indptr, m.indices, m.data)
+    gl = sa.log_normalize_with_size_factor(g, None, sa.FN_LOG2_1P)
+    ol = so.log_normalize_with_size_factor(o, None, so.LOG_TWO)
+    u1, s1, v1 = sa.Irlba(tol=1e-10, max_iter=300).run_pca(gl, k)  # default start vector
+    uo, s_o, vo, _ = so.irlba(ol, k, 1e-10, 300)
+    assert np.max(np.abs(s1 - s_o) / s_o) < 1e-8
+    assert np.max(np.abs(_sign_fix(u1, uo) - uo)) < 1e-4 and np.max(np.abs(_sign_fix(v1, vo) - vo)) < 1e-4
+    mm = sa.MultiMat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data, 2, devices=[0, 0])
+    mm.log_normalize(None, sa.FN_LOG2_1P)
+    u2, s2, v2 = mm.run_pca_irlba(k, tol=1e-10, max_iter=300)
+    assert u2.shape == u1.shape and v2.shape == v1.shape
+    assert np.max(np.abs(s2 - s1) / s1) < 1e-8
+    assert np.max(np.abs(_sign_fix(u2, u1) - u1)) < 1e-4 and np.max(np.abs(_sign_fix(v2, v1) - v1)) < 1e-4
+    v0 = np.random.default_rng(3).standard_normal(m.shape[0])
+    u3, s3, v3 = mm.run_pca_irlba(k, tol=1e-10, max_iter=300, v0=v0)  # explicit start vector over ALL cells, sliced per shard
+    u4, s4, v4 = sa.Irlba(tol=1e-10, max_iter=300).run_pca(gl, k, v0=v0)
+    assert np.max(np.abs(s3 - s4) / s4) < 1e-8
+    mm.close()
+
+
 def test_pca_errors_and_cancellation(sa):
     rng = np.random.default_rng(0)
     dense = random_counts(rng, 40, 60, 0.5, 9) + 1
