@@ -1,15 +1,21 @@
 // knn.hip — exact k-nearest-neighbours of the PCA scores (scan-rs/src/nn.rs:38-83), SURVEY.md §8 f4.
 //
 // The reference builds a ball tree (ball_tree crate) over the rows of a cells x d matrix and asks it for the k+1
-// nearest points of every row, dropping the row itself. Same result here by exhaustive search: one thread per
-// query (its d coordinates in registers), the candidate point wave-uniform in SGPRs (scalar loads), the squared distance as the
-// reference forms it (sum of squared differences, nn.rs:14-21 — not the |p|^2 + |q|^2 - 2 p.q expansion, whose
-// cancellation would reorder near neighbours), a sorted k-list per thread in private memory. f64 vector FMA bound:
-// n_q x n x d multiply-adds. Ties keep ascending index order (the rule of the reference's own test oracle,
-// `exhaustive_knn`, nn.rs:112-137; the ball tree's order among exactly equidistant points is a property of that crate).
+// nearest points of every row, dropping the row itself. Same result here by search over all pairs, in two forms:
+//  * knn_kernel (small point sets, d > 58, k > 64): one thread per query (its d coordinates in registers), the candidate point
+//    wave-uniform in SGPRs (scalar loads), the squared distance as the reference forms it (sum of squared differences,
+//    nn.rs:14-21 — not the |p|^2 + |q|^2 - 2 p.q expansion, whose cancellation would reorder near neighbours), a sorted k-list
+//    per thread in private memory. f64 vector FMA bound: n_q x n x d multiply-adds (8 s at 10^6 x 50).
+//  * the filtered form (>= 32768 points): the distance matrix is GEMM-shaped, so its bulk runs on the matrix cores
+//    (v_mfma_f32_32x32x16_bf16) as a FILTER with a rigorous error margin, and only the few pairs that pass are ranked, by the
+//    exact f64 distance above (kf_* kernels below: 0.49 s at 10^6 x 50, k = 15, identical output).
+// Ties keep ascending index order (the rule of the reference's own test oracle, `exhaustive_knn`, nn.rs:112-137; the ball
+// tree's order among exactly equidistant points is a property of that crate).
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <cmath>
+#include <vector>
 
 #include "common.hpp"
 
@@ -21,7 +27,7 @@ constexpr uint32_t KMAX = 128;
 
 template <int DMAX, int THREADS>
 __global__ __launch_bounds__(THREADS) void knn_kernel(const double *__restrict__ queries, uint64_t n_q, const double *__restrict__ points,
-                                                     uint64_t n_p, uint32_t d, uint32_t k, int skip_same_index,
+                                                     uint64_t n_p, uint32_t d, uint32_t k, int skip_same_index, uint64_t skip_stride,
                                                      uint32_t *__restrict__ out) {
     const uint64_t qi = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
     const bool live = qi < n_q;
@@ -42,7 +48,7 @@ __global__ __launch_bounds__(THREADS) void knn_kernel(const double *__restrict__
             const double t = pt[j] - q[j];
             s = fma(t, t, s);
         }
-        if (!live || (skip_same_index && pi == qi)) continue;
+        if (!live || (skip_same_index && pi * skip_stride == qi)) continue; // candidate pi is row pi * skip_stride of the full set
         if (have == k && !(s < worst)) continue;
         // sorted insertion; equal distances stay in index order because candidates arrive in index order
         uint32_t pos = have < k ? have : k - 1u;
@@ -60,32 +66,466 @@ __global__ __launch_bounds__(THREADS) void knn_kernel(const double *__restrict__
     for (uint32_t i = 0; i < k; i++) out[qi * k + i] = i < have ? best_i[i] : 0xFFFFFFFFu; // T::max_value() padding, nn.rs:66
 }
 
+// dst row r = src row r * row_stride, zero-padded to dmax columns
 __global__ void pad_points_kernel(const double *__restrict__ src, uint32_t ld, uint64_t n, uint32_t d, uint32_t dmax,
-                                  double *__restrict__ dst) {
+                                  double *__restrict__ dst, uint64_t row_stride) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n * dmax) return;
     const uint64_t r = e / dmax;
     const uint32_t j = (uint32_t)(e % dmax);
-    dst[e] = j < d ? src[r * ld + j] : 0.0;
+    dst[e] = j < d ? src[r * row_stride * ld + j] : 0.0;
 }
 
 template <int DMAX, int THREADS>
 void launch(const double *dq, uint32_t ldq, uint64_t n_q, const double *dp, uint32_t ldp, uint64_t n_p, uint32_t d, uint32_t k, int skip,
-            uint32_t *dout, hipStream_t s) {
+            uint32_t *dout, hipStream_t s, uint64_t p_stride = 1) {
+    // p_stride > 1: the candidates are rows 0, p_stride, 2 p_stride, ... of dp (n_p of them); indices written are subset-local
     // zero-padded (n x DMAX) copies: the candidate's coordinates arrive as whole scalar-cache lines, the query's as one run per thread
     DevBuf<double> pp, qp;
     pp.alloc(n_p * DMAX ? n_p * DMAX : 1);
     if (n_p)
-        hipLaunchKernelGGL(pad_points_kernel, dim3((unsigned)((n_p * DMAX + 255) / 256)), dim3(256), 0, s, dp, ldp, n_p, d, (uint32_t)DMAX, pp.p);
+        hipLaunchKernelGGL(pad_points_kernel, dim3((unsigned)((n_p * DMAX + 255) / 256)), dim3(256), 0, s, dp, ldp, n_p, d, (uint32_t)DMAX, pp.p, p_stride);
     const double *q = pp.p;
-    if (dq != dp || n_q != n_p || ldq != ldp) {
+    if (dq != dp || n_q != n_p || ldq != ldp || p_stride != 1) {
         qp.alloc(n_q * DMAX);
-        hipLaunchKernelGGL(pad_points_kernel, dim3((unsigned)((n_q * DMAX + 255) / 256)), dim3(256), 0, s, dq, ldq, n_q, d, (uint32_t)DMAX, qp.p);
+        hipLaunchKernelGGL(pad_points_kernel, dim3((unsigned)((n_q * DMAX + 255) / 256)), dim3(256), 0, s, dq, ldq, n_q, d, (uint32_t)DMAX, qp.p, (uint64_t)1);
         q = qp.p;
     }
     const dim3 grid((unsigned)((n_q + THREADS - 1) / THREADS)), block(THREADS);
-    hipLaunchKernelGGL((knn_kernel<DMAX, THREADS>), grid, block, 0, s, q, n_q, pp.p, n_p, (uint32_t)DMAX, k, skip, dout);
+    hipLaunchKernelGGL((knn_kernel<DMAX, THREADS>), grid, block, 0, s, q, n_q, pp.p, n_p, (uint32_t)DMAX, k, skip, p_stride, dout);
     SCANRS_HIP(hipStreamSynchronize(s)); // the padded copies are released on return
+}
+
+// exhaustive search of every query against rows 0, p_stride, 2 p_stride, ... of the point set (n_sub of them); subset-local indices
+void exhaustive(const double *dq, uint32_t ldq, uint64_t n_q, const double *dp, uint32_t ldp, uint64_t n_sub, uint32_t d, uint32_t k,
+                int skip, uint32_t *dout, uint64_t p_stride = 1) {
+    if (d <= 8)
+        launch<8, 256>(dq, ldq, n_q, dp, ldp, n_sub, d, k, skip, dout, 0, p_stride);
+    else if (d <= 16)
+        launch<16, 256>(dq, ldq, n_q, dp, ldp, n_sub, d, k, skip, dout, 0, p_stride);
+    else if (d <= 32)
+        launch<32, 256>(dq, ldq, n_q, dp, ldp, n_sub, d, k, skip, dout, 0, p_stride);
+    else if (d <= 52) // top-50 PCA scores, the default of scan-rs-cmd (tools/src/bin/cmd.rs:46-48)
+        launch<52, 256>(dq, ldq, n_q, dp, ldp, n_sub, d, k, skip, dout, 0, p_stride);
+    else if (d <= 64)
+        launch<64, 256>(dq, ldq, n_q, dp, ldp, n_sub, d, k, skip, dout, 0, p_stride);
+    else
+        launch<128, 64>(dq, ldq, n_q, dp, ldp, n_sub, d, k, skip, dout, 0, p_stride);
+    SCANRS_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Large point sets: filter on the matrix cores, decide in f64.
+//
+// The distance matrix is GEMM-shaped work, so its bulk goes to bf16 MFMA (v_mfma_f32_32x32x16_bf16) — but only as a
+// FILTER whose error is bounded rigorously; every neighbour that is returned was ranked by the exact f64 distance
+// (sum of squared differences in coordinate order, nn.rs:14-21), ties by index, exactly as the exhaustive kernel does.
+//   d^2(q, p) = |q|^2 + |p|^2 - 2 G,  G = q.p.  With coordinates rounded to bf16 (relative error 2^-9 each) and f32
+//   accumulation, |G~ - G| <= 2^-8 * 1.02 * |q| |p| <= gamma (|q|^2 + |p|^2), gamma = 2^-9 * 1.02 + slack = 0.0021.
+//   If tau_q is an upper bound of q's true k-th distance, every true neighbour satisfies
+//       G~ + A_q - N_p >= 0,   A_q = tau_q / 2 - |q|^2 (1/2 - gamma),   N_p = |p|^2 (1/2 - gamma).
+// A_q and N_p ride in spare k-slots of the operands (three bf16 pieces each, against 1.0 on the other side), so the
+// accumulator tile IS the test value and the epilogue is one max-tree per tile plus a rare append to the query's
+// candidate list. tau_q comes from exact searches on nested strided subsets (every 256th point exhaustively, then every
+// 16th and finally all points through the filter): a round passes about k * 16 * (volume inflation of the margin)
+// candidates per query, which the rerank kernel evaluates exactly. A query whose list overflows is redone exhaustively.
+constexpr uint32_t KF_DP = 64;     // operand row: 58 coordinates + 6 augmentation slots
+constexpr uint32_t KF_DMAX = 58;
+constexpr uint32_t KF_CAP = 1024;  // candidates per query and round
+constexpr double KF_GAMMA = 0.0021;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint16_t to_bf16(float f) { // round to nearest even
+    uint32_t u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float from_bf16(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+// v = h + m + l up to 2^-24 |v|
+__device__ __forceinline__ void split3(float v, uint16_t &h, uint16_t &m, uint16_t &l) {
+    h = to_bf16(v);
+    const float r1 = v - from_bf16(h);
+    m = to_bf16(r1);
+    l = to_bf16(r1 - from_bf16(m));
+}
+
+// operand rows of the point side: [p_0 .. p_{d-1}, 0.., 1, 1, 1, -N_h, -N_m, -N_l]; rows >= n are sentinels that fail every test
+__global__ void kf_prep_points_kernel(const double *__restrict__ P, uint32_t ld, uint64_t n, uint64_t n_rows, uint32_t d,
+                                      uint16_t *__restrict__ Pb) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    uint16_t *row = Pb + r * KF_DP;
+    double nn = 0.0;
+    for (uint32_t j = 0; j < KF_DP - 6; j++) {
+        const double x = (r < n && j < d) ? P[r * ld + j] : 0.0;
+        nn = fma(x, x, nn);
+        row[j] = to_bf16((float)x);
+    }
+    // N rounded DOWN (it is subtracted): shave a few ulps before the split
+    float nf = r < n ? (float)(nn * (0.5 - KF_GAMMA) * (1.0 - 4e-7)) : 1e30f;
+    uint16_t h, m, l;
+    split3(-nf, h, m, l);
+    row[KF_DP - 6] = row[KF_DP - 5] = row[KF_DP - 4] = 0x3F80; // 1.0
+    row[KF_DP - 3] = h;
+    row[KF_DP - 2] = m;
+    row[KF_DP - 1] = l;
+}
+// query side: [q_0 .. q_{d-1}, 0.., A_h, A_m, A_l, 1, 1, 1]; the A slots are rewritten every round
+__global__ void kf_prep_queries_kernel(const double *__restrict__ Q, uint32_t ld, uint64_t n, uint64_t n_rows, uint32_t d,
+                                       uint16_t *__restrict__ Qb, double *__restrict__ qn) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    uint16_t *row = Qb + r * KF_DP;
+    double nn = 0.0;
+    for (uint32_t j = 0; j < KF_DP - 6; j++) {
+        const double x = (r < n && j < d) ? Q[r * ld + j] : 0.0;
+        nn = fma(x, x, nn);
+        row[j] = to_bf16((float)x);
+    }
+    if (r < n) qn[r] = nn;
+    uint16_t h, m, l;
+    split3(-1e30f, h, m, l); // until a threshold is set nothing passes (and never for sentinel rows)
+    row[KF_DP - 6] = h;
+    row[KF_DP - 5] = m;
+    row[KF_DP - 4] = l;
+    row[KF_DP - 3] = row[KF_DP - 2] = row[KF_DP - 1] = 0x3F80;
+}
+__global__ void kf_set_threshold_kernel(const double *__restrict__ tau, const double *__restrict__ qn, uint64_t n,
+                                        uint16_t *__restrict__ Qb, uint32_t *__restrict__ cnt) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    cnt[r] = 0;
+    double a = 0.5 * tau[r] - qn[r] * (0.5 - KF_GAMMA);
+    a += fabs(a) * 4e-7 + 1e-300; // rounded UP
+    float af = a > 1e30 ? 1e30f : (float)a; // tau = +inf (fewer than k neighbours so far): everything passes
+    if (!(af == af)) af = 1e30f;
+    uint16_t h, m, l;
+    split3(af, h, m, l);
+    uint16_t *row = Qb + r * KF_DP;
+    row[KF_DP - 6] = h;
+    row[KF_DP - 5] = m;
+    row[KF_DP - 4] = l;
+}
+
+// One wave: 128 queries (4 row blocks of 32) x 32 points per step; the 4 waves of a workgroup share the query tile and take
+// every fourth 32-point block. Points are rows t * stride of Pb, t < n_sub; t >= n_sub reads the sentinel row. A passing
+// (query, point) pair is parked in a per-wave LDS buffer (LDS atomic for the position, ~100 clk) and the buffer is flushed to the
+// queries' global candidate lists in batches: with about one passing pair per tile a returning GLOBAL atomic per pair would
+// stall the wave for a memory round trip every tile (and drain the prefetched point blocks with it).
+constexpr uint32_t KF_BUF = 512; // parked pairs per wave
+__device__ __forceinline__ void kf_flush(uint32_t lane, uint32_t n, const uint2 *buf, uint32_t *__restrict__ cand, uint32_t *__restrict__ cnt) {
+    for (uint32_t e = lane; e < n; e += 64u) {
+        const uint2 qp = buf[e];
+        const uint32_t slot = atomicAdd(&cnt[qp.x], 1u);
+        if (slot < KF_CAP) cand[(uint64_t)qp.x * KF_CAP + slot] = qp.y;
+    }
+}
+__global__ __launch_bounds__(256, 2) void kf_filter_kernel(const uint16_t *__restrict__ Qb, uint64_t n_q, const uint16_t *__restrict__ Pb,
+                                                           uint64_t n_sub, uint64_t stride, uint64_t sentinel_row,
+                                                           uint32_t *__restrict__ cand, uint32_t *__restrict__ cnt) {
+    __shared__ uint2 park[4][KF_BUF];
+    __shared__ uint32_t park_n[4];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t r = lane & 31u, h = lane >> 5;
+    const uint64_t q0 = (uint64_t)blockIdx.x * 128u;
+    if (lane == 0) park_n[wave] = 0u;
+    bf16x8 a[4][4];
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+            a[rb][ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(Qb + (q0 + 32u * rb + r) * KF_DP + 16u * ks + 8u * h));
+    const uint64_t n_blocks = (n_sub + 31u) / 32u;
+    auto load_b = [&](uint64_t blk, bf16x8 (&b)[4], uint32_t &prow) {
+        const uint64_t t = blk * 32u + r;
+        const uint64_t pr = t < n_sub ? t * stride : sentinel_row;
+        prow = (uint32_t)pr;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+            b[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(Pb + pr * KF_DP + 16u * ks + 8u * h));
+    };
+    // Register ring of KF_STAGES point blocks: the loads of block i + KF_STAGES are issued right after block i has been consumed, so
+    // ~3 tiles of MFMA work (plus the SIMD's other wave) cover the L2 / HBM latency of every load. Blocks past the end read the
+    // sentinel row: no branch around any load, so the loads in flight can be counted (counted s_waitcnt vmcnt).
+    constexpr int KF_STAGES = 3;
+    bf16x8 b[KF_STAGES][4];
+    uint32_t prow[KF_STAGES];
+#pragma unroll
+    for (int st = 0; st < KF_STAGES; st++) load_b(wave + 4u * st, b[st], prow[st]);
+    for (uint64_t base = wave; base < n_blocks; base += 4u * KF_STAGES) {
+#pragma unroll
+        for (int st = 0; st < KF_STAGES; st++) {
+            const uint64_t blk = base + 4u * st;
+            const uint32_t pr = prow[st];
+#pragma unroll
+            for (int half = 0; half < 2; half++) { // two row blocks at a time: 32 accumulator registers live instead of 64
+                f32x16 acc[2];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    acc[e] = (f32x16){0};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++)
+                        acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 * half + e][ks], b[st][ks], acc[e], 0, 0, 0);
+                }
+                if (half == 1) {
+                    load_b(blk + 4u * KF_STAGES, b[st], prow[st]);
+                    asm volatile("" ::: "memory"); // the refill is ISSUED here: left alone, the compiler sinks it next to its use, tiles later
+                }
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int rb = 2 * half + e;
+                    float mx = acc[e][0];
+#pragma unroll
+                    for (int i = 1; i < 16; i++) mx = fmaxf(mx, acc[e][i]);
+                    if (__builtin_amdgcn_ballot_w64(mx >= 0.0f) == 0) continue; // no pair of this 32 x 32 block passes
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        if (acc[e][i] >= 0.0f) { // sentinel rows (queries past n_q, points past the subset) never get here: their A / N slots are -/+1e30
+                            const uint32_t q = (uint32_t)q0 + 32u * rb + (uint32_t)((i & 3) + 8 * (i >> 2)) + 4u * h;
+                            const uint32_t pos = atomicAdd(&park_n[wave], 1u);
+                            if (pos < KF_BUF)
+                                park[wave][pos] = make_uint2(q, pr);
+                            else
+                                atomicMax(&cnt[q], KF_CAP + 1u); // more than KF_BUF pairs in one tile (heavy ties): that query goes to the exhaustive kernel
+                        }
+                    }
+                }
+            }
+            const uint32_t parked = min(park_n[wave], KF_BUF);
+            if (parked > KF_BUF - 128u) { // wave-uniform
+                kf_flush(lane, parked, park[wave], cand, cnt);
+                if (lane == 0) park_n[wave] = 0u;
+            }
+        }
+    }
+    kf_flush(lane, min(park_n[wave], KF_BUF), park[wave], cand, cnt);
+}
+
+// exact f64 ranking of a query's candidates: one wave per query, a candidate per lane (the same fma chain over the coordinates as
+// knn_kernel), then k rounds of a wave-wide lexicographic (distance, index) minimum. Writes the k neighbours (UINT32_MAX padded)
+// and tau = the k-th distance (+inf when fewer than k exist). Overflowed lists are flagged and left to the exhaustive kernel.
+constexpr uint32_t KF_PER_LANE = KF_CAP / 64u;
+__global__ __launch_bounds__(256) void kf_rerank_kernel(const double *__restrict__ Q, uint32_t ldq, uint64_t n_q, const double *__restrict__ P,
+                                                        uint32_t ldp, uint32_t d, uint32_t k, int skip_same_index,
+                                                        const uint32_t *__restrict__ cand, const uint32_t *__restrict__ cnt,
+                                                        uint32_t *__restrict__ out, double *__restrict__ tau,
+                                                        uint32_t *__restrict__ overflow) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t q = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (q >= n_q) return;
+    const uint32_t c = cnt[q];
+    if (c > KF_CAP) {
+        if (lane == 0) overflow[q] = 1u;
+        return;
+    }
+    if (lane == 0) overflow[q] = 0u;
+    double dist[KF_PER_LANE];
+    uint32_t idx[KF_PER_LANE];
+    const double *__restrict__ qr = Q + q * ldq;
+#pragma unroll
+    for (uint32_t u = 0; u < KF_PER_LANE; u++) {
+        const uint32_t j = u * 64u + lane;
+        dist[u] = DBL_MAX;
+        idx[u] = 0xFFFFFFFFu;
+        if (j < c) {
+            const uint32_t p = cand[q * KF_CAP + j];
+            if (!(skip_same_index && (uint64_t)p == q)) {
+                const double *__restrict__ pr = P + (uint64_t)p * ldp;
+                double s = 0.0;
+                for (uint32_t t = 0; t < d; t++) {
+                    const double df = pr[t] - qr[t];
+                    s = fma(df, df, s);
+                }
+                dist[u] = s;
+                idx[u] = p;
+            }
+        }
+    }
+    double kth = DBL_MAX;
+    for (uint32_t it = 0; it < k; it++) {
+        // lane-local minimum, then the wave's
+        double bd = DBL_MAX;
+        uint32_t bi = 0xFFFFFFFFu;
+#pragma unroll
+        for (uint32_t u = 0; u < KF_PER_LANE; u++)
+            if (dist[u] < bd || (dist[u] == bd && idx[u] < bi)) {
+                bd = dist[u];
+                bi = idx[u];
+            }
+        double wd = bd;
+        uint32_t wi = bi;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double od = __shfl_xor(wd, off, 64);
+            const uint32_t oi = (uint32_t)__shfl_xor((int)wi, off, 64);
+            if (od < wd || (od == wd && oi < wi)) {
+                wd = od;
+                wi = oi;
+            }
+        }
+        if (lane == 0) out[q * k + it] = wi;
+        if (wi == 0xFFFFFFFFu) { // fewer than k candidates: the rest is padding
+            for (uint32_t r2 = it + 1; r2 < k; r2++)
+                if (lane == 0) out[q * k + r2] = 0xFFFFFFFFu;
+            kth = DBL_MAX;
+            break;
+        }
+        kth = wd;
+        // the owner retires that entry (indices are unique within a list: a point is appended once per round)
+#pragma unroll
+        for (uint32_t u = 0; u < KF_PER_LANE; u++)
+            if (idx[u] == wi) {
+                dist[u] = DBL_MAX;
+                idx[u] = 0xFFFFFFFFu;
+            }
+    }
+    if (lane == 0) tau[q] = kth == DBL_MAX ? INFINITY : kth;
+}
+
+// tau of round 0 from the exhaustive search on the coarsest subset: exact distance to the k-th neighbour found there
+__global__ void kf_tau0_kernel(const double *__restrict__ Q, uint32_t ldq, uint64_t n_q, const double *__restrict__ P, uint32_t ldp,
+                               uint32_t d, uint32_t k, uint64_t stride, const uint32_t *__restrict__ nbr, double *__restrict__ tau) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_q) return;
+    const uint32_t t = nbr[q * k + (k - 1u)];
+    if (t == 0xFFFFFFFFu) {
+        tau[q] = INFINITY;
+        return;
+    }
+    const double *pr = P + (uint64_t)t * stride * ldp, *qr = Q + q * ldq;
+    double s = 0.0;
+    for (uint32_t j = 0; j < d; j++) {
+        const double df = pr[j] - qr[j];
+        s = fma(df, df, s);
+    }
+    tau[q] = s;
+}
+
+// round 0: every query's candidate list = the whole coarsest subset (rows 0, stride, 2 stride, ...), ranked exactly by kf_rerank_kernel
+__global__ void kf_fill_all_kernel(uint64_t n_q, uint32_t n_sub, uint64_t stride, uint32_t *__restrict__ cand, uint32_t *__restrict__ cnt) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_q * n_sub) return;
+    const uint64_t q = e / n_sub;
+    const uint32_t j = (uint32_t)(e % n_sub);
+    cand[q * KF_CAP + j] = (uint32_t)(j * stride);
+    if (j == 0) cnt[q] = n_sub;
+}
+
+__global__ void kf_gather_rows_kernel(const double *__restrict__ src, uint32_t ld, uint32_t d, const uint32_t *__restrict__ rows, uint64_t n,
+                                      double *__restrict__ dst) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * d) return;
+    dst[e] = src[(uint64_t)rows[e / d] * ld + (e % d)];
+}
+__global__ void kf_scatter_result_kernel(const uint32_t *__restrict__ res, const uint32_t *__restrict__ rows, uint64_t n, uint32_t k,
+                                         uint32_t *__restrict__ out) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * k) return;
+    out[(uint64_t)rows[e / k] * k + (e % k)] = res[e];
+}
+
+bool knn_filtered(const double *dq, uint32_t ldq, uint64_t n_q, const double *dp, uint32_t ldp, uint64_t n_p, uint32_t d, uint32_t k,
+                  int skip, uint32_t *dout) {
+    const bool off = getenv("SCANRS_KNN_EXHAUSTIVE") && atoi(getenv("SCANRS_KNN_EXHAUSTIVE")) != 0; // read per call (tests flip it)
+    uint64_t min_points = 32768;
+    if (const char *e = getenv("SCANRS_KNN_FILTER_MIN_POINTS")) min_points = (uint64_t)atoll(e);
+    if (off || d > KF_DMAX || n_p < min_points || k > 64 || n_q < 256) return false;
+    hipStream_t s = 0;
+    // nested strided subsets S_0 < S_1 < ... < all points: S_0 (at most KF_CAP points) is ranked exactly for every query, which gives
+    // an upper bound tau of the k-th distance; every further subset is `ratio` times denser and goes through the filter with the
+    // previous tau, which lets about k * ratio * (volume inflation of the margin) pairs per query through.
+    uint64_t ratio = 4; // 1M x 50, k = 15: 487 ms at 4, 553 at 8, 606 at 16 (fewer passes, but longer candidate lists and the first overflows)
+    if (const char *e = getenv("SCANRS_KNN_RATIO")) ratio = std::max<uint64_t>(2, (uint64_t)atoll(e));
+    const bool stats = getenv("SCANRS_KNN_STATS") != nullptr;
+    std::vector<uint64_t> strides;
+    uint64_t st0 = 1;
+    while ((n_p + st0 - 1) / st0 > KF_CAP) st0 *= 2;
+    for (uint64_t st = st0; st > 1;) {
+        st = st / ratio > 0 ? st / ratio : 1;
+        strides.push_back(st);
+    }
+    if (strides.empty()) return false;
+    const uint64_t nq_rows = (n_q + 127) / 128 * 128, np_rows = n_p + 1; // one sentinel row behind the points
+    DevBuf<uint16_t> Qb(nq_rows * KF_DP), Pb(np_rows * KF_DP);
+    DevBuf<double> qn(n_q), tau(n_q);
+    DevBuf<uint32_t> cnt(n_q), cand(n_q * KF_CAP), ovf(n_q);
+    hipLaunchKernelGGL(kf_prep_points_kernel, dim3((unsigned)((np_rows + 255) / 256)), dim3(256), 0, s, dp, ldp, n_p, np_rows, d, Pb.p);
+    hipLaunchKernelGGL(kf_prep_queries_kernel, dim3((unsigned)((nq_rows + 255) / 256)), dim3(256), 0, s, dq, ldq, n_q, nq_rows, d, Qb.p, qn.p);
+    { // round 0: exact ranking of the coarsest subset
+        const uint32_t n0 = (uint32_t)((n_p + st0 - 1) / st0);
+        hipLaunchKernelGGL(kf_fill_all_kernel, dim3((unsigned)((n_q * n0 + 255) / 256)), dim3(256), 0, s, n_q, n0, st0, cand.p, cnt.p);
+        hipLaunchKernelGGL(kf_rerank_kernel, dim3((unsigned)((n_q + 3) / 4)), dim3(256), 0, s, dq, ldq, n_q, dp, ldp, d, k, skip, cand.p, cnt.p,
+                           dout, tau.p, ovf.p);
+    }
+    for (uint64_t st : strides) {
+        const uint64_t n_sub = (n_p + st - 1) / st;
+        hipLaunchKernelGGL(kf_set_threshold_kernel, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, s, tau.p, qn.p, n_q, Qb.p, cnt.p);
+        hipLaunchKernelGGL(kf_filter_kernel, dim3((unsigned)(nq_rows / 128)), dim3(256), 0, s, Qb.p, n_q, Pb.p, n_sub, st, n_p, cand.p, cnt.p);
+        hipLaunchKernelGGL(kf_rerank_kernel, dim3((unsigned)((n_q + 3) / 4)), dim3(256), 0, s, dq, ldq, n_q, dp, ldp, d, k, skip, cand.p, cnt.p,
+                           dout, tau.p, ovf.p);
+        SCANRS_HIP(hipGetLastError());
+        if (stats) {
+            std::vector<uint32_t> hc(n_q);
+            SCANRS_HIP(hipMemcpy(hc.data(), cnt.p, n_q * 4, hipMemcpyDeviceToHost));
+            double sum = 0;
+            uint32_t mx = 0, over = 0;
+            for (uint32_t c : hc) {
+                sum += c;
+                mx = std::max(mx, c);
+                over += c > KF_CAP;
+            }
+            fprintf(stderr, "[scanrs knn] stride %llu: %llu points, candidates per query mean %.1f max %u, %u lists overflowed\n",
+                    (unsigned long long)st, (unsigned long long)n_sub, sum / (double)n_q, mx, over);
+        }
+        // overflowed lists (rare: heavy ties, adversarial clusters): those queries are redone exhaustively on this subset
+        std::vector<uint32_t> h_ovf(n_q);
+        SCANRS_HIP(hipMemcpy(h_ovf.data(), ovf.p, n_q * 4, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> rows;
+        for (uint64_t q = 0; q < n_q; q++)
+            if (h_ovf[q]) rows.push_back((uint32_t)q);
+        if (!rows.empty()) {
+            const uint64_t m = rows.size();
+            DevBuf<uint32_t> d_rows(m), res(m * k);
+            DevBuf<double> qsel(m * d), tsel(m);
+            SCANRS_HIP(hipMemcpy(d_rows.p, rows.data(), m * 4, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(kf_gather_rows_kernel, dim3((unsigned)((m * d + 255) / 256)), dim3(256), 0, s, dq, ldq, d, d_rows.p, m, qsel.p);
+            // the self-exclusion rule compares row numbers, which the gathered copy has lost: search for k + 1 and drop the query's own row on the host
+            const uint32_t kk = std::min<uint32_t>(k + (skip ? 1u : 0u), KMAX);
+            DevBuf<uint32_t> res2(m * kk);
+            exhaustive(qsel.p, d, m, dp, ldp, n_sub, d, kk, 0, res2.p, st);
+            std::vector<uint32_t> h_res(m * kk), h_out(m * k);
+            SCANRS_HIP(hipMemcpy(h_res.data(), res2.p, m * kk * 4, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < m; i++) {
+                uint32_t w = 0;
+                for (uint32_t j = 0; j < kk && w < k; j++) {
+                    const uint32_t t = h_res[i * kk + j];
+                    const uint64_t prow = t == 0xFFFFFFFFu ? 0xFFFFFFFFull : (uint64_t)t * st;
+                    if (skip && prow == rows[i]) continue;
+                    h_out[i * k + w++] = t == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)prow;
+                }
+                for (; w < k; w++) h_out[i * k + w] = 0xFFFFFFFFu;
+            }
+            SCANRS_HIP(hipMemcpy(res.p, h_out.data(), m * k * 4, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(kf_scatter_result_kernel, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, s, res.p, d_rows.p, m, k, dout);
+            // their thresholds for the next round: exact distance to the k-th neighbour just found (row indices now)
+            if (st != 1) {
+                DevBuf<uint32_t> nb(n_q * k);
+                SCANRS_HIP(hipMemcpy(nb.p, dout, n_q * k * 4, hipMemcpyDeviceToDevice));
+                DevBuf<double> tau2(n_q);
+                hipLaunchKernelGGL(kf_tau0_kernel, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, s, dq, ldq, n_q, dp, ldp, d, k, (uint64_t)1, nb.p,
+                                   tau2.p);
+                std::vector<double> h_t(n_q), h_t2(n_q);
+                SCANRS_HIP(hipMemcpy(h_t.data(), tau.p, n_q * 8, hipMemcpyDeviceToHost));
+                SCANRS_HIP(hipMemcpy(h_t2.data(), tau2.p, n_q * 8, hipMemcpyDeviceToHost));
+                for (uint32_t rq : rows) h_t[rq] = h_t2[rq];
+                SCANRS_HIP(hipMemcpy(tau.p, h_t.data(), n_q * 8, hipMemcpyHostToDevice));
+            }
+        }
+    }
+    SCANRS_HIP(hipStreamSynchronize(s));
+    return true;
 }
 
 } // namespace
@@ -100,18 +540,8 @@ void knn_device(const double *d_queries, uint32_t ld_q, uint64_t n_q, const doub
     DevBuf<uint32_t> dout;
     dout.alloc(n_q * k);
     const int skip = skip_same_index ? 1 : 0;
-    if (d <= 8)
-        launch<8, 256>(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p, 0);
-    else if (d <= 16)
-        launch<16, 256>(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p, 0);
-    else if (d <= 32)
-        launch<32, 256>(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p, 0);
-    else if (d <= 52) // top-50 PCA scores, the default of scan-rs-cmd (tools/src/bin/cmd.rs:46-48)
-        launch<52, 256>(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p, 0);
-    else if (d <= 64)
-        launch<64, 256>(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p, 0);
-    else
-        launch<128, 64>(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p, 0);
+    if (!knn_filtered(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p))
+        exhaustive(d_queries, ld_q, n_q, d_points, ld_p, n_p, d, k, skip, dout.p);
     SCANRS_HIP(hipGetLastError());
     SCANRS_HIP(hipMemcpy(out, dout.p, n_q * k * 4, hipMemcpyDeviceToHost));
 }

@@ -87,3 +87,69 @@ def test_knn_larger_set_all_dimension_kernels_and_duplicates():
         sa.knn(rng.standard_normal((10, 129)), 2)
     with pytest.raises(sa.ScanrsError):
         sa.knn(rng.standard_normal((300, 4)), 129)
+
+
+def _knn_both_ways(sa, fn, monkeypatch):
+    """run `fn` with the matrix-core filter allowed and with the exhaustive kernel forced; the env switch is read per call"""
+    monkeypatch.delenv("SCANRS_KNN_EXHAUSTIVE", raising=False)
+    a = fn()
+    monkeypatch.setenv("SCANRS_KNN_EXHAUSTIVE", "1")
+    b = fn()
+    monkeypatch.delenv("SCANRS_KNN_EXHAUSTIVE", raising=False)
+    return a, b
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,k", [(40_000, 50, 15), (36_000, 7, 30), (150_000, 50, 15)])
+def test_filtered_knn_equals_exhaustive(monkeypatch, n, d, k):
+    """Large point sets go through the bf16-MFMA filter + exact f64 rerank (knn.hip): the result must be IDENTICAL to the
+    exhaustive f64 kernel's — same neighbours, same order, ties by index — on PCA-score-like data (decaying column scales,
+    clusters), with exact duplicates, for one (n <= 131k) and two (n > 131k) filter rounds."""
+    import scanrs_amd as sa
+
+    rng = np.random.default_rng(n + d)
+    centres = rng.standard_normal((12, d)) * 3.0
+    v = centres[rng.integers(0, 12, size=n)] + rng.standard_normal((n, d))
+    v *= np.linspace(1.0, 0.3, d)  # decaying spectrum, as PCA scores have
+    v[17] = v[5]
+    v[n - 1] = v[5]  # three exactly coincident points
+    got, want = _knn_both_ways(sa, lambda: sa.knn(v, k), monkeypatch)
+    assert np.array_equal(got, want)
+    assert set(got[5, :2].tolist()) == {17, n - 1} and got[5, 0] == 17  # distance-0 ties in ascending index order
+
+
+@pytest.mark.gpu
+def test_filtered_find_nn_and_overflow_fallback(monkeypatch):
+    import scanrs_amd as sa
+
+    rng = np.random.default_rng(5)
+    pts = rng.standard_normal((50_000, 20))
+    qs = rng.standard_normal((3_000, 20))
+    for include_self in (True, False):
+        got, want = _knn_both_ways(sa, lambda: sa.find_nn(qs, 10, pts, include_self), monkeypatch)
+        assert np.array_equal(got, want)
+    # 3000 coincident points: every one of them has > 1024 candidates at distance 0 -> the lists overflow and those queries
+    # are redone exhaustively; the answer is still exact (ties by index)
+    pts2 = pts.copy()
+    pts2[:3000] = pts2[0]
+    got, want = _knn_both_ways(sa, lambda: sa.knn(pts2, 8), monkeypatch)
+    assert np.array_equal(got, want)
+    assert got[0].tolist() == [1, 2, 3, 4, 5, 6, 7, 8] and got[2999].tolist() == [0, 1, 2, 3, 4, 5, 6, 7]
+
+
+@pytest.mark.gpu
+def test_knn_device_on_pca_scores(monkeypatch):
+    """scanrs_knn_device on the scores scanrs_pca_result_device hands out (leading dimension != d) = knn of the host copy"""
+    import scanrs_amd as sa
+    from scanrs_amd.synth import synth_counts
+
+    m = synth_counts(40_000, 600, 0.05, 2)
+    g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+    sa.normalize(g, sa.Normalization.CellRanger)
+    u, s, v = sa.BkSvd().run_pca(g, 9)
+    s2, res = sa.BkSvd().run_pca_device(g, 9)
+    assert res.ld_v == 10 and res.k == 9
+    a = sa.knn_device(res.d_v, m.shape[0], res.ld_v, res.k, 15)
+    monkeypatch.setenv("SCANRS_KNN_EXHAUSTIVE", "1")
+    b = sa.knn(v, 15)
+    assert np.array_equal(a, b)
