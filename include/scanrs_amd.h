@@ -307,8 +307,9 @@ int scanrs_profile_reset(scanrs_mat *m);
 /* Fills up to `cap` entries, writes the total count to *n. */
 int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uint32_t *n);
 /* Which f64 product kernel serves this handle (and its views): 0 = auto (L2-blocked gather for large matrices and
- * panels of 16+ columns, plain gather otherwise), 1 = plain gather, 2 = L2-blocked gather. Both are HIP kernels;
- * results agree to rounding. */
+ * panels of 16+ columns, plain gather otherwise), 1 = plain gather, 2 = L2-blocked gather, 3 = LDS-staged panel tiles over
+ * a tile-bucketed second layout of the matrix (panels of 16..104 columns; built on first use; other widths take path 2).
+ * All are HIP kernels; results agree to rounding. */
 int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
 /* Arithmetic of the large sparse products: 0 (default) = f64 throughout, the reference's arithmetic; 1 = opt-in fast
  * mode: the dense panel is rounded to f32 before it is gathered (half the on-chip bytes per nonzero), products and

@@ -1074,7 +1074,8 @@ int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uin
 int scanrs_mat_set_spmm_path(scanrs_mat *m, int path) {
     return guard([&] {
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
-        if (path < 0 || path > 2) fail(SCANRS_ERR_ARGUMENT, "path must be 0 (auto), 1 (plain gather) or 2 (L2-blocked gather)");
+        if (path < 0 || path > 3)
+            fail(SCANRS_ERR_ARGUMENT, "path must be 0 (auto), 1 (plain gather), 2 (L2-blocked gather) or 3 (LDS-staged tiles)");
         m->st->spmm_path = path;
     });
 }

@@ -146,6 +146,10 @@ struct MultiRow {
     uint32_t _pad;
 };
 
+// quad.hip: the tile-bucketed second layout of an orientation that the LDS-staged product walks
+struct QuadLayout;
+void quad_layout_free(QuadLayout *q);
+
 // A compressed orientation: n_outer vectors over n_inner positions.
 struct SparseCopy {
     uint64_t n_outer = 0, n_inner = 0, nnz = 0;
@@ -159,6 +163,7 @@ struct SparseCopy {
     // on the host (how many vectors are "hot" for a given step count is a binary search)
     DevBuf<uint32_t> order;
     std::vector<uint32_t> sorted_len;
+    std::shared_ptr<QuadLayout> quad; // built on first use of the LDS-staged product (spmm path 3)
     void build_items(hipStream_t s);
 };
 
@@ -208,7 +213,7 @@ struct Storage {
         uint32_t ld_u = 0, ld_v = 0, k = 0;
         uint64_t rows_u = 0, rows_v = 0;
     } pca_dev;
-    int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 L2-blocked gather
+    int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 L2-blocked gather, 3 LDS-staged tiles (quad layout)
     int panel_precision = 0;              // 0: f64 panels (default); 1: gathered panels rounded to f32, f64 sums (opt-in)
     size_t l2_tile_bytes = 3u << 20;      // panel slice per step of the L2-blocked gather (4 MB L2 per XCD)
     int spmm_order = 1;                   // L2-blocked gather: launch outer vectors longest first: 0 never, 1 auto, 2 always (SCANRS_SPMM_ORDER)
@@ -274,6 +279,11 @@ void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const doubl
                      double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw);
 void launch_spmm_u32(Storage &st, const SparseCopy &cp, const uint32_t *X, uint32_t ldx, uint32_t l, uint32_t *out,
                      uint32_t ldo);
+// quad.hip
+QuadLayout *quad_layout_build(Storage &st, const SparseCopy &cp);
+bool spmm_quad_ok(const SparseCopy &cp, const DevMap &map, uint32_t ldx, uint32_t l);
+void launch_spmm_quad(Storage &st, SparseCopy &cp, QuadLayout &q, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
+                      double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw);
 // per-outer-vector reductions. mode 0: sum of raw u32 counts; 1: sum of mapped values; 2: sum and sum of squares.
 void launch_row_reduce(Storage &st, SparseCopy &cp, const DevMap &map, int mode, uint32_t *out_u32, double *out_sum,
                        double *out_sumsq);

@@ -492,6 +492,56 @@ def test_blocked_kernel_matches_gather_and_oracle(sa, storage):
             assert_close(a1, a2, rtol=1e-11, atol=1e-10)
 
 
+@pytest.mark.parametrize("storage", [so.CSR, so.CSC])
+def test_lds_staged_product_matches_gather_and_oracle(sa, storage):
+    """spmm path 3 (quad.hip: panel tiles staged in LDS, tile-bucketed second layout, static register accumulators) against the
+    gather kernels and the oracle: shapes around the slot (40) / workgroup (320) / tile (96) edges, empty vectors, dense spots that
+    fill the overflow lists (more than 4 nonzeros per vector and tile, more than 64 per visit), with and without the rank-r offset,
+    panel widths 16 .. 104 (other widths fall through to path 2)."""
+    rng = np.random.default_rng(31 + storage)
+    for rows, cols, fill in ((1, 1, 1.0), (39, 95, 0.5), (40, 96, 0.3), (41, 97, 0.9), (321, 200, 0.05), (700, 1000, 0.03),
+                             (97, 5000, 0.02), (2000, 193, 0.2)):
+        dense = random_counts(rng, rows, cols, fill, 40)
+        dense[rng.random(rows) < 0.2, :] = 0  # some empty rows
+        dense[0, 0] = 7
+        g1, o = pair(sa, dense, storage)
+        g3, _ = pair(sa, dense, storage)
+        g1.set_spmm_path(1)
+        g3.set_spmm_path(3)
+        f = rng.random(cols) + 0.5
+        fr = rng.random(rows) + 0.5
+        for gm in (g1, g3):
+            gm.compose_scale_axis(1, f).apply(sa.FN_LOG2_1P).compose_scale_axis(0, fr)
+        o = o.compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=1, a=f)).apply(so.OP_LOG2_1P).compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=0, a=fr))
+        for with_offset in (False, True):
+            ref_m = o
+            if with_offset:
+                u, v = rng.standard_normal((rows, 2)), rng.standard_normal((2, cols))
+                g1.set_offset(u, v)
+                g3.set_offset(u, v)
+                ref_m = so.LowRankOffset(o, u, v)
+            for l in (16, 17, 50, 100, 104, 105, 8):
+                q = rng.standard_normal((cols, l))
+                a1, a3, ref = g1.dot(q), g3.dot(q), ref_m.dot(q)
+                assert_close(a3, ref, rtol=1e-10, atol=1e-9)
+                assert_close(a1, a3, rtol=1e-11, atol=1e-10)
+                ql = rng.standard_normal((l, rows))
+                a1, a3, ref = g1.rdot(ql), g3.rdot(ql), ref_m.rdot(ql)
+                assert_close(a3, ref, rtol=1e-10, atol=1e-9)
+                assert_close(a1, a3, rtol=1e-11, atol=1e-10)
+    # bitwise repeatable, and the whole PCA through it agrees with the default path
+    m = _synth(4000, 900, 0.06, 5)
+    ga = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+    gb = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+    gb.set_spmm_path(3)
+    ua, s_a, va = sa.BkSvd().run_pca(sa.normalize(ga, sa.Normalization.CellRanger), 10)
+    ub, s_b, vb = sa.BkSvd().run_pca(sa.normalize(gb, sa.Normalization.CellRanger), 10)
+    assert np.max(np.abs(s_a - s_b) / s_a) < 1e-10
+    assert np.max(np.abs(_sign_fix(ub, ua) - ua)) < 1e-7 and np.max(np.abs(_sign_fix(vb, va) - va)) < 1e-7
+    ub2, s_b2, vb2 = sa.BkSvd().run_pca(gb, 10)
+    assert np.array_equal(s_b, s_b2) and np.array_equal(ub, ub2) and np.array_equal(vb, vb2)
+
+
 def test_blocked_kernel_many_steps_and_determinism(sa):
     # a panel of several L2 steps: the running sums are carried through the output panel between launches
     rng = np.random.default_rng(4)

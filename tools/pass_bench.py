@@ -13,10 +13,13 @@ from scanrs_amd.synth import synth_counts_torch
 
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 genes, l = 33_000, int(sys.argv[2]) if len(sys.argv) > 2 else 100
+path = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 dev = torch.device("cuda", 0)
 ip, ix, vv = synth_counts_torch(cells, genes, 0.03, 0, dev)
 m = sa.AdaptiveMat.from_device(genes, cells, sa.CSC, ip.data_ptr(), ix.data_ptr(), vv.data_ptr())
 nnz = int(ip[-1].item())
+if path:
+    m.set_spmm_path(path)
 del ip, ix, vv
 xg = torch.randn(genes, l, device=dev, dtype=torch.float64)
 xc = torch.randn(cells, l, device=dev, dtype=torch.float64)
