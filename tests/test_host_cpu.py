@@ -56,6 +56,17 @@ def test_no_cpu_fallback_without_device(sa):
     assert e.value.code == 4 and "no CPU fallback" in str(e.value)
 
 
+def test_single_process_multi_gpu_form_needs_a_device_too(sa):
+    if sa.device_available():
+        pytest.skip("checks the behaviour of a host without a GPU")
+    ip = np.array([0, 1, 2], dtype=np.uint64)
+    with pytest.raises(sa.ScanrsError) as e:
+        sa.MultiMat(2, 2, sa.CSR, ip, np.array([0, 1], dtype=np.uint32), np.array([1, 1], dtype=np.uint32), 2, devices=[0, 0])
+    assert e.value.code == 4
+    with pytest.raises(sa.ScanrsError):  # and bad arguments are refused before anything else
+        sa.MultiMat(2, 2, sa.CSR, ip, np.array([0, 1], dtype=np.uint32), np.array([1, 1], dtype=np.uint32), 17)
+
+
 def test_product_path_never_imports_the_oracle():
     names = ("scanrs_oracle", "liboracle", "import adaptive_vec", "knn_oracle", "oracle/")  # everything under oracle/
     for top in ("scan-rs_amd", "tools", "include"):
