@@ -219,7 +219,11 @@ static void download_panel_staged(Ctx &c, const double *d, uint32_t ld, uint64_t
     const uint64_t slot_rows = std::max<uint64_t>(1, SLOT / row_bytes);
     const size_t n_chunks = (size_t)((rows + slot_rows - 1) / slot_rows);
     char *stage = (char *)c.st.pinned((size_t)NS * slot_rows * row_bytes);
-    const unsigned T = std::max(1u, std::min(4u, std::thread::hardware_concurrency()));
+    static const unsigned T_env = [] {
+        const char *e = getenv("SCANRS_D2H_THREADS");
+        return e ? (unsigned)std::max(1, atoi(e)) : 4u;
+    }();
+    const unsigned T = std::max(1u, std::min(T_env, std::thread::hardware_concurrency()));
     hipEvent_t ev[NS];
     for (auto &e : ev) SCANRS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     std::atomic<size_t> ready{0};
