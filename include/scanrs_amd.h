@@ -43,7 +43,8 @@ enum {
     SCANRS_ERR_CANCELLED = 3, /* snoop::CancellationError (snoop/src/lib.rs:5-18) */
     SCANRS_ERR_DEVICE = 4,    /* no gfx950 device / HIP failure / out of memory */
     SCANRS_ERR_NUMERICAL = 5, /* LAPACK-style failure (`?` on qr()/svddc_into()) */
-    SCANRS_ERR_ARGUMENT = 6   /* null pointer, bad enum, unsupported combination */
+    SCANRS_ERR_ARGUMENT = 6,  /* null pointer, bad enum, unsupported combination */
+    SCANRS_ERR_IO = 7         /* file missing / not HDF5 / truncated / a format feature this reader does not parse */
 };
 
 /* storage flag, sqz/src/mat.rs:45-65 */
@@ -328,6 +329,52 @@ int scanrs_host_inv_upper(double *r, int n);
 int scanrs_host_sym_eig(const double *a, int n, double *w, double *z);
 /* the k leading eigenpairs only: w[0..k) descending, z row-major n x k */
 int scanrs_host_sym_eig_topk(const double *a, int n, int k, double *w, double *z);
+
+/* ---- 10x HDF5 ingestion (hdf5-io/src/matrix.rs, analysis.rs). Host-side; no device needed.
+ * The files are parsed by the library's own reader (csrc/h5lite.cpp) — no libhdf5 dependency. Failures are
+ * SCANRS_ERR_IO with the reason in scanrs_last_error(). ------------------------------------------------------------ */
+typedef struct scanrs_h5_matrix scanrs_h5_matrix; /* GenericFeatureBarcodeMatrix / MatrixMetadata (scan-types/src/matrix.rs:8-15) */
+
+/* `read_csc_matrix` (hdf5-io/src/matrix.rs:56-97): group "matrix" -> features x barcodes CSC, u64 indptr, u32 indices,
+ * u32 values (stored values converted through f64 as the reference does, :247-257). Columns whose indices are not
+ * ascending (some Cell Ranger 3 files) are sorted, the reference's `new_from_unsorted_csc` fallback (:71-79). */
+int scanrs_h5_read_csc_matrix(const char *path, scanrs_h5_matrix **out);
+/* `read_adaptive_csr_matrix` (:129-199): the same matrix feature-major (CSR) with features dropped when their
+ * feature_type does not contain `retain_feature_like` (NULL: keep all) or their total count is below `shrink_row`
+ * (< 0: None). The arrays are exactly what scanrs_mat_create(rows, cols, SCANRS_CSR, ...) takes. */
+int scanrs_h5_read_adaptive_csr_matrix(const char *path, const char *retain_feature_like, int64_t shrink_row,
+                                       scanrs_h5_matrix **out);
+/* `read_matrix_metadata` (:17-54): barcodes, (filtered) feature ids / names / types and nnz; no matrix arrays. */
+int scanrs_h5_read_matrix_metadata(const char *path, const char *retain_feature_like, scanrs_h5_matrix **out);
+void scanrs_h5_matrix_free(scanrs_h5_matrix *m);
+
+int scanrs_h5_matrix_shape(const scanrs_h5_matrix *m, uint64_t *rows, uint64_t *cols, uint64_t *nnz, int *storage);
+/* borrowed pointers, valid until scanrs_h5_matrix_free; NULL for a metadata-only handle */
+int scanrs_h5_matrix_arrays(const scanrs_h5_matrix *m, const uint64_t **indptr, const uint32_t **indices, const uint32_t **values);
+/* what = 0 barcodes, 1 feature ids, 2 feature names, 3 feature types (per kept feature; the LabelClass of the reference
+ * flattened, scan-types/src/label_class.rs:129-145), 4 name of the file */
+int scanrs_h5_matrix_n_strings(const scanrs_h5_matrix *m, int what, uint64_t *n);
+const char *scanrs_h5_matrix_string(const scanrs_h5_matrix *m, int what, uint64_t i);
+/* indices (in the file's feature order) of the features that were filtered out — the BTreeSet the reference returns */
+int scanrs_h5_matrix_removed(const scanrs_h5_matrix *m, const uint64_t **removed, uint64_t *n);
+
+/* `read_umi_counts_from_matrix` (:270-299): per-barcode sums of the stored values, read in blocks of 2000 columns */
+int scanrs_h5_read_umi_counts(const char *path, uint32_t *out, uint64_t cap, uint64_t *n);
+
+/* `get_clustering_keys` (analysis.rs:38-41): names under /clustering, NUL-separated into buf */
+int scanrs_h5_get_clustering_keys(const char *path, char *buf, uint64_t cap, uint64_t *n_keys, uint64_t *bytes);
+/* `get_clustering` (analysis.rs:5-20): i64 -> i16 / u16 by truncation, as the reference's `as` casts do */
+int scanrs_h5_get_clustering(const char *path, const char *clustering_key, uint16_t *num_clusters, int16_t *clusters,
+                             uint64_t cap, uint64_t *n);
+/* `get_differential_expression` (analysis.rs:23-36): the rows x cols f64 table, row-major */
+int scanrs_h5_get_differential_expression(const char *path, const char *clustering_key, double *out, uint64_t cap,
+                                          uint64_t *rows, uint64_t *cols);
+
+/* generic access used by the tests to check the parser against files written by libhdf5: numbers of any stored type
+ * converted to f64 (dims gets up to 8 entries), fixed-length strings NUL-separated, link names NUL-separated */
+int scanrs_h5_read_f64(const char *path, const char *dataset, double *out, uint64_t cap, uint64_t *dims, uint32_t *rank);
+int scanrs_h5_read_strings(const char *path, const char *dataset, char *buf, uint64_t cap, uint64_t *n, uint64_t *bytes);
+int scanrs_h5_member_names(const char *path, const char *group, char *buf, uint64_t cap, uint64_t *n, uint64_t *bytes);
 
 #ifdef __cplusplus
 }

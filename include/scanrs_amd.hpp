@@ -296,4 +296,114 @@ class MultiMat {
     }
 };
 
+// ---- hdf5-io crate (hdf5-io/src/matrix.rs, analysis.rs): 10x files -> host arrays, parsed by the library itself ----
+namespace hdf5_io {
+static const char *const FEATURE_TYPE_GENE_EXPRESSION = "Gene Expression"; // matrix.rs:14
+
+// GenericFeatureBarcodeMatrix / MatrixMetadata (scan-types/src/matrix.rs:8-15) with the matrix as host arrays
+struct FeatureBarcodeMatrix {
+    std::string name;
+    std::vector<std::string> barcodes, feature_ids, feature_names, feature_types;
+    Storage storage = Storage::CSC;
+    uint64_t rows = 0, cols = 0, nnz = 0;
+    std::vector<uint64_t> indptr; // empty for read_matrix_metadata
+    std::vector<uint32_t> indices, values;
+    std::vector<uint64_t> removed_features; // ascending (the BTreeSet of the reference)
+    AdaptiveMat to_device() const { return AdaptiveMat::from_csmat(rows, cols, storage, indptr.data(), indices.data(), values.data()); }
+};
+
+namespace detail {
+inline FeatureBarcodeMatrix take(scanrs_h5_matrix *h) {
+    struct Free {
+        scanrs_h5_matrix *h;
+        ~Free() { scanrs_h5_matrix_free(h); }
+    } guard{h};
+    FeatureBarcodeMatrix m;
+    int storage = 0;
+    check(scanrs_h5_matrix_shape(h, &m.rows, &m.cols, &m.nnz, &storage));
+    m.storage = (Storage)storage;
+    auto strings = [&](int what) {
+        uint64_t n = 0;
+        check(scanrs_h5_matrix_n_strings(h, what, &n));
+        std::vector<std::string> v(n);
+        for (uint64_t i = 0; i < n; i++) v[i] = scanrs_h5_matrix_string(h, what, i);
+        return v;
+    };
+    m.barcodes = strings(0);
+    m.feature_ids = strings(1);
+    m.feature_names = strings(2);
+    m.feature_types = strings(3);
+    m.name = strings(4)[0];
+    const uint64_t *ip = nullptr, *rem = nullptr;
+    const uint32_t *ix = nullptr, *vv = nullptr;
+    check(scanrs_h5_matrix_arrays(h, &ip, &ix, &vv));
+    if (ip) {
+        const uint64_t n_outer = m.storage == Storage::CSR ? m.rows : m.cols;
+        m.indptr.assign(ip, ip + n_outer + 1);
+        m.indices.assign(ix, ix + m.nnz);
+        m.values.assign(vv, vv + m.nnz);
+    }
+    uint64_t n_rem = 0;
+    check(scanrs_h5_matrix_removed(h, &rem, &n_rem));
+    m.removed_features.assign(rem, rem + n_rem);
+    return m;
+}
+inline std::vector<std::string> unpack(const std::vector<char> &buf, uint64_t n) {
+    std::vector<std::string> out;
+    const char *p = buf.data();
+    for (uint64_t i = 0; i < n; i++) {
+        out.emplace_back(p);
+        p += out.back().size() + 1;
+    }
+    return out;
+}
+} // namespace detail
+
+inline FeatureBarcodeMatrix read_csc_matrix(const std::string &path) { // matrix.rs:56-97
+    scanrs_h5_matrix *h = nullptr;
+    check(scanrs_h5_read_csc_matrix(path.c_str(), &h));
+    return detail::take(h);
+}
+// matrix.rs:129-199; retain_feature_like == nullptr: None; shrink_row < 0: None
+inline FeatureBarcodeMatrix read_adaptive_csr_matrix(const std::string &path, const char *retain_feature_like = nullptr, int64_t shrink_row = -1) {
+    scanrs_h5_matrix *h = nullptr;
+    check(scanrs_h5_read_adaptive_csr_matrix(path.c_str(), retain_feature_like, shrink_row, &h));
+    return detail::take(h);
+}
+inline FeatureBarcodeMatrix read_matrix_metadata(const std::string &path, const char *retain_feature_like = nullptr) { // matrix.rs:17-54
+    scanrs_h5_matrix *h = nullptr;
+    check(scanrs_h5_read_matrix_metadata(path.c_str(), retain_feature_like, &h));
+    return detail::take(h);
+}
+inline std::vector<uint32_t> read_umi_counts_from_matrix(const std::string &path) { // matrix.rs:270-299
+    uint64_t n = 0;
+    check(scanrs_h5_read_umi_counts(path.c_str(), nullptr, 0, &n));
+    std::vector<uint32_t> out(n);
+    check(scanrs_h5_read_umi_counts(path.c_str(), out.data(), n, &n));
+    return out;
+}
+inline std::vector<std::string> get_clustering_keys(const std::string &analysis_h5) { // analysis.rs:38-41
+    uint64_t n = 0, bytes = 0;
+    check(scanrs_h5_get_clustering_keys(analysis_h5.c_str(), nullptr, 0, &n, &bytes));
+    std::vector<char> buf(bytes + 1);
+    check(scanrs_h5_get_clustering_keys(analysis_h5.c_str(), buf.data(), bytes, &n, &bytes));
+    return detail::unpack(buf, n);
+}
+inline std::pair<uint16_t, std::vector<int16_t>> get_clustering(const std::string &analysis_h5, const std::string &key) { // analysis.rs:5-20
+    uint16_t nc = 0;
+    uint64_t n = 0;
+    check(scanrs_h5_get_clustering(analysis_h5.c_str(), key.c_str(), &nc, nullptr, 0, &n));
+    std::vector<int16_t> c(n);
+    check(scanrs_h5_get_clustering(analysis_h5.c_str(), key.c_str(), &nc, c.data(), n, &n));
+    return {nc, std::move(c)};
+}
+inline Array2 get_differential_expression(const std::string &analysis_h5, const std::string &key) { // analysis.rs:23-36
+    uint64_t r = 0, c = 0;
+    check(scanrs_h5_get_differential_expression(analysis_h5.c_str(), key.c_str(), nullptr, 0, &r, &c));
+    Array2 out(r, c);
+    check(scanrs_h5_get_differential_expression(analysis_h5.c_str(), key.c_str(), out.data.data(), r * c, &r, &c));
+    return out;
+}
+} // namespace hdf5_io
+
 } // namespace scanrs

@@ -821,4 +821,8 @@ EXPORTED_SYMBOLS = [
     "scanrs_multi_create", "scanrs_multi_free", "scanrs_multi_n_shards", "scanrs_multi_shard", "scanrs_multi_normalize", "scanrs_multi_pca_bk", "scanrs_multi_pca_rand", "scanrs_multi_pca_irlba", "scanrs_multi_log_normalize",
     "scanrs_plan_shards", "scanrs_profile_enable", "scanrs_profile_reset", "scanrs_profile_get", "scanrs_mat_sync", "scanrs_mat_set_spmm_path", "scanrs_mat_set_panel_precision",
     "scanrs_host_chol_upper", "scanrs_host_inv_upper", "scanrs_host_sym_eig", "scanrs_host_sym_eig_topk",
+    "scanrs_h5_read_csc_matrix", "scanrs_h5_read_adaptive_csr_matrix", "scanrs_h5_read_matrix_metadata", "scanrs_h5_matrix_free",
+    "scanrs_h5_matrix_shape", "scanrs_h5_matrix_arrays", "scanrs_h5_matrix_n_strings", "scanrs_h5_matrix_string", "scanrs_h5_matrix_removed",
+    "scanrs_h5_read_umi_counts", "scanrs_h5_get_clustering_keys", "scanrs_h5_get_clustering", "scanrs_h5_get_differential_expression",
+    "scanrs_h5_read_f64", "scanrs_h5_read_strings", "scanrs_h5_member_names",
 ]

@@ -14,17 +14,11 @@
 #include <hip/hip_runtime.h>
 
 #include "scanrs_amd.h"
+#include "common_err.hpp"
 
 struct scanrs_comm; // comm.cpp
 
 namespace scanrs {
-
-// ---- errors: thrown inside, turned into status codes at the C boundary ----------
-struct Failure {
-    int code;
-};
-void set_error(const char *fmt, ...);
-[[noreturn]] void fail(int code, const char *fmt, ...);
 
 #define SCANRS_HIP(expr)                                                                              \
     do {                                                                                              \

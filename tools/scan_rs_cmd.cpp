@@ -1,6 +1,7 @@
 // scan-rs-cmd on MI355X: the reference's command line tool (tools/src/bin/cmd.rs:16-104) over the
 // C++ mirror of its API (include/scanrs_amd.hpp):
 //   scan-rs-cmd INPUT.mtx[.gz] -o OUT_DIR -n {cellranger|cellranger8|seuratlog|binomialdeviance|binomialpearson} -d NUM_PCS
+// (INPUT may also be a 10x feature-barcode matrix .h5 — read through the hdf5-io mirror; the reference CLI takes mtx only)
 // writes svd_u.csv.gz, svd_d.csv.gz, svd_v.csv.gz exactly as cmd.rs:83-86 does.
 #include <algorithm>
 #include <charconv>
@@ -132,7 +133,10 @@ int main(int argc, char **argv) {
     }
     try {
         const Normalization normalization = normalization_from_str(norm);
-        AdaptiveMat matrix = load_mtx(input);
+        // extension over cmd.rs: a 10x feature-barcode .h5 is read the way diff-exp/src/utils.rs:42 reads it
+        // (hdf5_io::matrix::read_adaptive_csr_matrix, all feature types, no count filter)
+        const bool is_h5 = input.size() > 3 && input.compare(input.size() - 3, 3, ".h5") == 0;
+        AdaptiveMat matrix = is_h5 ? hdf5_io::read_adaptive_csr_matrix(input).to_device() : load_mtx(input);
         mkdir(out_dir.c_str(), 0777);
         AdaptiveMat norm_mat = normalize(matrix.view(), normalization); // cmd.rs:67-80
         const PcaResult r = BkSvd().run_pca(norm_mat, num_pcs);
