@@ -216,12 +216,39 @@ def main():
         mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev, stage_through_host=True))
         transport = "host hook over gloo (test mode: ranks share one GPU)"
     elif world > 1 or args.force_collective:
-        uid = [sa.Comm.unique_id() if rank == 0 else None]
+        comm_err = ""
+        try:
+            uid = [sa.Comm.unique_id() if rank == 0 else None]
+        except sa.ScanrsError as e:  # rank 0 could not even load RCCL: tell everybody
+            uid, comm_err = [None], str(e)
         if dist is not None:
             dist.broadcast_object_list(uid, src=0)
-        comm = sa.Comm(uid[0], rank, world)
-        mat.set_shard_comm(comm, lo, args.cells)
-        transport = "RCCL all-reduce enqueued by the library on its own stream (scanrs_comm_*)"
+        if uid[0] is not None:
+            try:
+                comm = sa.Comm(uid[0], rank, world)
+            except sa.ScanrsError as e:
+                comm_err = str(e)
+        ok = comm is not None
+        if dist is not None:  # every rank must take the same branch or the first exchange step hangs
+            flags = [None] * world
+            dist.all_gather_object(flags, ok)
+            ok = all(flags)
+        if ok:
+            mat.set_shard_comm(comm, lo, args.cells)
+            transport = "RCCL all-reduce enqueued by the library on its own stream (scanrs_comm_*)"
+        elif dist is None:
+            raise SystemExit(f"bench.py: library RCCL communicator failed: {comm_err}")
+        else:
+            # the library's own communicator could not be built on some rank: same schedule, exchange steps served by the
+            # host program's RCCL group through the all-reduce hook (round 1's transport) — still device buffers over xGMI
+            from scanrs_amd.dist import make_allreduce
+
+            if comm is not None:
+                comm.close()
+                comm = None
+            nccl_group = dist.new_group(backend="nccl")
+            mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev, group=nccl_group))
+            transport = f"torch.distributed RCCL group through the library's all-reduce hook (library communicator failed: {comm_err or 'on another rank'})"
 
     if args.f32_panels:
         mat.set_panel_precision(1)

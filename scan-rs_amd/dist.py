@@ -14,7 +14,7 @@ class _DevArr:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def make_allreduce(dist, device=None, stage_through_host: bool = False):
+def make_allreduce(dist, device=None, stage_through_host: bool = False, group=None):
     """Returns callback(ptr, count, dtype) -> 0. dtype 0 = f64, 1 = u64 (summed as i64).
 
     device=None: `ptr` is host memory (CPU tests). Otherwise `ptr` is device memory on `device`;
@@ -25,17 +25,17 @@ def make_allreduce(dist, device=None, stage_through_host: bool = False):
         ct = ctypes.c_double if dtype == 0 else ctypes.c_int64
         arr = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ct)), shape=(count,))
         t = torch.from_numpy(arr)
-        dist.all_reduce(t)
+        dist.all_reduce(t, group=group)
         return 0
 
     def dev_cb(ptr, count, dtype):
         t = torch.as_tensor(_DevArr(ptr, count, "<f8" if dtype == 0 else "<i8"), device=device)
         if stage_through_host:
             h = t.cpu()
-            dist.all_reduce(h)
+            dist.all_reduce(h, group=group)
             t.copy_(h)
         else:
-            dist.all_reduce(t)
+            dist.all_reduce(t, group=group)
         torch.cuda.synchronize(device)
         return 0
 
