@@ -269,6 +269,9 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
         if (kb >= 64) st->l2_tile_bytes = (size_t)kb << 10;
     }
     if (const char *e = getenv("SCANRS_SPMM_ORDER")) st->spmm_order = atoi(e);
+    if (const char *e = getenv("SCANRS_SPMM_PERSIST")) st->persist = atoi(e);
+    if (const char *e = getenv("SCANRS_PERSIST_SLACK")) st->persist_slack = (uint32_t)std::max(0, atoi(e));
+    if (const char *e = getenv("SCANRS_PERSIST_TILE_KB")) st->persist_tile_bytes = (size_t)std::max(64, atoi(e)) << 10;
     if (const char *e = getenv("SCANRS_HOT_SEGMENT")) st->hot_segment = (uint32_t)std::max(0, atoi(e));
     SparseCopy &cp = st->primary;
     cp.n_outer = storage == SCANRS_CSR ? rows : cols;

@@ -213,6 +213,11 @@ struct Storage {
     int spmm_order = 1;                   // L2-blocked gather: launch outer vectors longest first: 0 never, 1 auto, 2 always (SCANRS_SPMM_ORDER)
     uint32_t hot_segment = 512;           // ... and give a workgroup to vectors with >= this many nonzeros per step (0 = never)
     uint64_t blocked_min_nnz = 1ull << 22; // auto: matrices below this stay on the plain gather kernel
+    // persistent form of the L2-blocked gather on copies with <= 16 outer vectors per wave of the chip (65536 on MI355X) (kernels.hip, spmm_gather2d_persist_kernel)
+    int persist = 0;                      // 0 off, 1 on (SCANRS_SPMM_PERSIST)
+    uint32_t persist_slack = 1;           // steps a wave may run ahead of the slowest workgroup (0: never wait)
+    size_t persist_tile_bytes = 3u << 19; // panel slice per step: (slack + 1) slices share a 4 MB L2
+    bool persist_broken = false;          // a product saw the grid fall out of step (wait timed out): multi-launch form from then on
     ~Storage();
     // the copy whose outer dimension is the base matrix's rows (true) or cols (false)
     SparseCopy &copy_with_outer_rows(bool outer_rows);

@@ -935,3 +935,48 @@ def test_default_seed_panel_is_the_sequential_stream(sa):
         e = sa.RandSvd().run_pca(g, k, omega=explicit)
         for x, y in zip(a, e):
             assert np.array_equal(x, y)
+
+
+
+@pytest.mark.parametrize("knobs", [{"SCANRS_PERSIST_SLACK": "1", "SCANRS_PERSIST_TILE_KB": "64"},
+                                   {"SCANRS_PERSIST_SLACK": "0", "SCANRS_PERSIST_TILE_KB": "64"},
+                                   {"SCANRS_PERSIST_SLACK": "3", "SCANRS_PERSIST_TILE_KB": "200"},
+                                   {"SCANRS_PERSIST_SLACK": "1", "SCANRS_PERSIST_TILE_KB": "1536"}])
+def test_persistent_gather_matches_the_multi_launch_form(sa, monkeypatch, knobs):
+    """SCANRS_SPMM_PERSIST=1: one launch per product on the copy with few, long outer vectors — every wave owns a fixed
+    set of vectors and keeps their sums in registers across the L2 steps; the steps in flight are held together by
+    counters that carry no data. Nonzeros of a vector are added in the same order as by the per-step launches, so the
+    two forms agree bit for bit; both agree with the oracle (map with an inner-indexed scale, rank-1 offset)."""
+    rng = np.random.default_rng(78)
+    dense = random_counts(rng, 70, 9000, 0.03, 30)
+    dense[3, :] = rng.integers(1, 9, size=9000)
+    dense[40, :] = 0
+    f = rng.random(9000) + 0.5
+    u, v = rng.standard_normal((70, 1)), rng.standard_normal((1, 9000))
+
+    def build(persist, storage):
+        monkeypatch.setenv("SCANRS_SPMM_PERSIST", "1" if persist else "0")
+        monkeypatch.setenv("SCANRS_HOT_SEGMENT", "0")  # the multi-launch form then adds a vector's nonzeros in one wave too
+        for k_, v_ in knobs.items():
+            monkeypatch.setenv(k_, v_)  # read when a handle is created
+        g, o = pair(sa, dense + 0, storage)
+        g.set_spmm_path(2)
+        g.compose_scale_axis(1, f).apply(sa.FN_LOG2_1P)
+        o = o.compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=1, a=f)).apply(so.OP_LOG2_1P)
+        g.set_offset(u, v)
+        return g, so.LowRankOffset(o, u, v)
+
+    for storage in (so.CSR, so.CSC):
+        gp, lo = build(True, storage)
+        gm, _ = build(False, storage)
+        gp.profile_enable(True)
+        for l in (6, 100, 128, 200):
+            q = rng.standard_normal((9000, l))     # out rows = 70: the copy with 70 outer vectors of 9000 -> persistent form
+            a = gp.dot(q)
+            assert np.array_equal(a, gm.dot(q))
+            assert np.array_equal(a, gp.dot(q))
+            assert_close(a, lo.dot(q), rtol=1e-10, atol=1e-8)
+            ql = rng.standard_normal((l, 70))      # the other orientation stays on the multi-launch form
+            assert np.array_equal(gp.rdot(ql), gm.rdot(ql))
+        names = set(gp.profile_get())
+        assert any("persist" in n for n in names), names
