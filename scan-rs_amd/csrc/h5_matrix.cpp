@@ -99,6 +99,8 @@ void read_csc(const char *path, scanrs_h5_matrix &m) {
     m.feature_names = read_features(f, matrix, "name");
     m.feature_types = read_features(f, matrix, "feature_type");
     require_features(m.feature_types);
+    if (m.feature_ids.size() != m.feature_types.size() || m.feature_names.size() != m.feature_types.size())
+        fail(SCANRS_ERR_IO, "%s: feature id / name / type lengths differ", path);
     m.rows = m.feature_ids.size();
     m.cols = m.barcodes.size();
     m.nnz = m.indices.size();

@@ -327,9 +327,17 @@ DatasetInfo File::info(Object dataset) const {
             if (d[3] == 2) di.null_space = true;
         } else
             H5FAIL("%s: unsupported dataspace version %u", path_.c_str(), ver);
-        (void)flags;
         if (sp->size < off + (uint64_t)rank * L_) H5FAIL("%s: short dataspace message", path_.c_str());
         for (unsigned i = 0; i < rank; i++) di.dims.push_back(rdL(d + off + (uint64_t)i * L_));
+        if (flags & 1) { // maximum extents follow (all ones: unlimited)
+            if (sp->size < off + 2ull * rank * L_) H5FAIL("%s: short dataspace message", path_.c_str());
+            for (unsigned i = 0; i < rank; i++) {
+                const uint64_t v = rdL(d + off + (uint64_t)(rank + i) * L_);
+                di.max_dims.push_back((L_ == 4 && v == 0xFFFFFFFFull) ? UINT64_MAX : v);
+            }
+        } else {
+            di.max_dims = di.dims;
+        }
     }
     {
         const uint8_t *d = ty->data;
@@ -539,9 +547,148 @@ void File::parse_layout(const std::vector<Msg> &m, const DatasetInfo &di, Layout
                     }
                 }
             }
+        } else if (index_type == 4) { // extensible array: exactly one unlimited dimension
+            if (q + 5 + O_ > e) H5FAIL("%s: short layout message", path_.c_str());
+            const unsigned max_bits = q[0], idx_elmts = q[1], min_ptrs = q[2], min_elmts = q[3], page_bits = q[4];
+            const uint64_t hdr = rdO(q + 5);
+            if (!undefined(hdr)) {
+                auto ilog2 = [&](uint64_t v) {
+                    unsigned r = 0;
+                    while (v > 1) {
+                        v >>= 1;
+                        r++;
+                    }
+                    return r;
+                };
+                if (min_elmts == 0 || (min_elmts & (min_elmts - 1)) || min_ptrs < 2 || (min_ptrs & (min_ptrs - 1)) || max_bits == 0 || max_bits > 64 ||
+                    max_bits < ilog2(min_elmts) || page_bits > 31)
+                    H5FAIL("%s: bad extensible array parameters", path_.c_str());
+                const uint8_t *h = at(base_addr_ + hdr, 12 + 6 * L_ + O_ + 4);
+                if (memcmp(h, "EAHD", 4) != 0) H5FAIL("%s: bad extensible array header", path_.c_str());
+                const unsigned client = h[5], esz = h[6];
+                if (h[7] != max_bits || h[8] != idx_elmts || h[9] != min_elmts || h[10] != min_ptrs || h[11] != page_bits)
+                    H5FAIL("%s: extensible array header disagrees with the layout message", path_.c_str());
+                if ((client == 0 && esz != O_) || (client == 1 && (esz < O_ + 5 || esz > O_ + 12))) H5FAIL("%s: bad extensible array entry size", path_.c_str());
+                const uint64_t iblk = rdO(h + 12 + 6 * L_);
+                const unsigned off_sz = (max_bits + 7) / 8;
+                const unsigned nsblks = 1 + (max_bits - ilog2(min_elmts));
+                const unsigned ib_nsblks = 2 * ilog2(min_ptrs);
+                const uint64_t ib_ndblk = 2ull * (min_ptrs - 1);
+                const unsigned ib_nsblk_addrs = nsblks > ib_nsblks ? nsblks - ib_nsblks : 0;
+                const uint64_t page_n = 1ull << page_bits;
+                // which dimension is unlimited, and the linear index of a chunk: the unlimited dimension counts slowest
+                // (H5VM_swizzle_coords), the others by the chunk counts of their MAXIMUM extents
+                int unlim = -1;
+                for (unsigned i = 0; i < rank; i++)
+                    if (i < di.max_dims.size() && di.max_dims[i] == UINT64_MAX) {
+                        if (unlim >= 0) H5FAIL("%s: extensible array with two unlimited dimensions", path_.c_str());
+                        unlim = (int)i;
+                    }
+                if (unlim < 0) H5FAIL("%s: extensible array chunk index without an unlimited dimension", path_.c_str());
+                std::vector<unsigned> order;
+                order.push_back((unsigned)unlim);
+                for (unsigned i = 0; i < rank; i++)
+                    if ((int)i != unlim) order.push_back(i);
+                std::vector<uint64_t> max_chunks(rank);
+                for (unsigned i = 0; i < rank; i++) {
+                    const uint64_t md = (int)i == unlim ? di.dims[i] : di.max_dims[i];
+                    max_chunks[i] = (md + lay.chunk_dims[i] - 1) / lay.chunk_dims[i];
+                }
+                auto element = [&](const uint8_t *el, uint64_t linear, const std::vector<uint64_t> &off) {
+                    (void)linear;
+                    Chunk c;
+                    c.addr = rdO(el);
+                    if (undefined(c.addr)) return;
+                    c.size = (uint32_t)chunk_bytes;
+                    c.filter_mask = 0;
+                    if (client == 1) {
+                        const unsigned csz = esz - O_ - 4;
+                        c.size = (uint32_t)rd(el + O_, csz);
+                        c.filter_mask = (uint32_t)rd(el + O_ + csz, 4);
+                    }
+                    c.offset = off;
+                    lay.chunks.push_back(std::move(c));
+                };
+                if (!undefined(iblk) && n_chunks > 0) {
+                    const uint8_t *ib = at(base_addr_ + iblk, 6 + O_);
+                    if (memcmp(ib, "EAIB", 4) != 0) H5FAIL("%s: bad extensible array index block", path_.c_str());
+                    const uint64_t ib_elems = base_addr_ + iblk + 6 + O_;
+                    const uint64_t ib_dblks = ib_elems + (uint64_t)idx_elmts * esz;
+                    const uint64_t ib_sblks = ib_dblks + ib_ndblk * O_;
+                    at(ib_elems, (uint64_t)idx_elmts * esz + ib_ndblk * O_ + (uint64_t)ib_nsblk_addrs * O_ + 4);
+                    // super block geometry
+                    std::vector<uint64_t> sb_ndblks(nsblks), sb_dnel(nsblks), sb_start_idx(nsblks), sb_start_dblk(nsblks);
+                    {
+                        uint64_t si = 0, sd = 0;
+                        for (unsigned u = 0; u < nsblks; u++) {
+                            sb_ndblks[u] = 1ull << (u / 2);
+                            sb_dnel[u] = (uint64_t)min_elmts << ((u + 1) / 2);
+                            sb_start_idx[u] = si;
+                            sb_start_dblk[u] = sd;
+                            if (u < 62) {
+                                si += sb_ndblks[u] * sb_dnel[u];
+                                sd += sb_ndblks[u];
+                            }
+                        }
+                    }
+                    // walk the chunk grid; the per-chunk lookup is the library's H5EA__lookup_elmt
+                    std::vector<uint64_t> scaled(rank);
+                    for (uint64_t g = 0; g < n_chunks; g++) {
+                        const std::vector<uint64_t> off = offset_of(g);
+                        for (unsigned i = 0; i < rank; i++) scaled[i] = off[i] / lay.chunk_dims[i];
+                        uint64_t idx = 0;
+                        for (unsigned i = 0; i < rank; i++) idx = (i == 0 ? 0 : idx * max_chunks[order[i]]) + scaled[order[i]];
+                        if (idx < idx_elmts) {
+                            element(at(ib_elems + idx * esz, esz), idx, off);
+                            continue;
+                        }
+                        uint64_t ei = idx - idx_elmts;
+                        const unsigned sb = ilog2(ei / min_elmts + 1);
+                        if (sb >= nsblks) H5FAIL("%s: chunk index past the extensible array's range", path_.c_str());
+                        ei -= sb_start_idx[sb];
+                        const uint64_t dnel = sb_dnel[sb];
+                        uint64_t dblk_addr;
+                        const uint64_t dblk_in_sb = ei / dnel;
+                        const uint64_t in_dblk = ei % dnel;
+                        const bool paged = dnel > page_n;
+                        if (sb < ib_nsblks) {
+                            const uint64_t di_ = sb_start_dblk[sb] + dblk_in_sb;
+                            if (di_ >= ib_ndblk) H5FAIL("%s: bad extensible array geometry", path_.c_str());
+                            dblk_addr = rdO(at(ib_dblks + di_ * O_, O_));
+                        } else {
+                            const uint64_t sa = rdO(at(ib_sblks + (uint64_t)(sb - ib_nsblks) * O_, O_));
+                            if (undefined(sa)) continue;
+                            const uint8_t *sp = at(base_addr_ + sa, 6 + O_ + off_sz);
+                            if (memcmp(sp, "EASB", 4) != 0) H5FAIL("%s: bad extensible array super block", path_.c_str());
+                            uint64_t pos = base_addr_ + sa + 6 + O_ + off_sz;
+                            if (paged) {
+                                const uint64_t npages = dnel / page_n, bm = (npages + 7) / 8;
+                                // one bit per page, indexed dblk * npages + page across the whole region (H5EA__lookup_elmt),
+                                // although the region is sized ndblks * ceil(npages / 8) bytes
+                                const uint8_t *bits = at(pos, sb_ndblks[sb] * bm);
+                                const uint64_t pg = dblk_in_sb * npages + in_dblk / page_n;
+                                if (!(bits[pg / 8] & (0x80u >> (pg % 8)))) continue; // page never written
+                                pos += sb_ndblks[sb] * bm;
+                            }
+                            dblk_addr = rdO(at(pos + dblk_in_sb * O_, O_));
+                        }
+                        if (undefined(dblk_addr)) continue;
+                        const uint8_t *dp = at(base_addr_ + dblk_addr, 6 + O_ + off_sz);
+                        if (memcmp(dp, "EADB", 4) != 0) H5FAIL("%s: bad extensible array data block", path_.c_str());
+                        uint64_t epos = base_addr_ + dblk_addr + 6 + O_ + off_sz;
+                        if (paged) {
+                            epos += 4; // the data block's own checksum precedes its pages
+                            epos += (in_dblk / page_n) * (page_n * esz + 4) + (in_dblk % page_n) * esz;
+                        } else {
+                            epos += in_dblk * esz;
+                        }
+                        element(at(epos, esz), idx, off);
+                    }
+                }
+            }
         } else {
             H5FAIL("%s: chunk index type %u (%s) is not supported by this reader", path_.c_str(), index_type,
-                   index_type == 4 ? "extensible array" : index_type == 5 ? "version-2 B-tree" : "unknown");
+                   index_type == 5 ? "version-2 B-tree" : "unknown");
         }
     } else {
         H5FAIL("%s: data layout class %d is not supported", path_.c_str(), lay.cls);

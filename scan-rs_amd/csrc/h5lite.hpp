@@ -6,9 +6,10 @@
 //   superblock v0-v3; object headers v1 and v2 (with continuation blocks); old-style groups (symbol table message ->
 //   v1 B-tree of SNOD nodes + local heap) and new-style compact groups (link messages); dataspace v1/v2 (scalar, simple,
 //   null); datatypes: fixed-point 1-8 bytes either endianness, IEEE f32/f64, fixed-length strings; data layout v3
-//   (compact, contiguous, chunked through a v1 B-tree) and v4 (single-chunk, implicit and fixed-array chunk indexes);
+//   (compact, contiguous, chunked through a v1 B-tree) and v4 (single-chunk, implicit, fixed-array and extensible-array
+//   chunk indexes);
 //   filter pipeline v1/v2 with deflate, shuffle and fletcher32.
-// Anything else (dense link storage in fractal heaps, extensible-array / v2-B-tree chunk indexes, variable-length
+// Anything else (dense link storage in fractal heaps, v2-B-tree chunk indexes, variable-length
 // data, compound types, szip/lzf, external or virtual storage) is refused with a message naming the feature.
 // Checked against files written by the real library: tests/golden/make_h5_fixtures.py, tests/test_h5_reader.py.
 #pragma once
@@ -31,6 +32,7 @@ struct TypeInfo {
 
 struct DatasetInfo {
     std::vector<uint64_t> dims; // empty: scalar (one element) or null (no elements)
+    std::vector<uint64_t> max_dims; // UINT64_MAX: unlimited
     bool null_space = false;
     TypeInfo type;
     uint64_t n_elements() const {

@@ -176,6 +176,24 @@ def main():
         did = h5py.h5d.create(f.id, b"implicit", h5py.h5t.NATIVE_UINT8, h5py.h5s.create_simple(a.shape), dcpl=dcpl)
         did.write(h5py.h5s.ALL, h5py.h5s.ALL, a)
         fl["implicit"] = a.tolist()
+        # (own group: more than 8 links in one new-style group would switch it to dense storage, which the reader refuses)
+        # extensible array (one unlimited dimension): index block only; data blocks reached from the index block, filtered;
+        # real super blocks (> 244 chunks); two-dimensional with the unlimited dimension first / last (swizzled linear index)
+        a = rng.integers(0, 1000, size=5).astype(np.int32)
+        f.create_dataset("ea/ea_small", data=a, chunks=(2,), maxshape=(None,))
+        fl["ea/ea_small"] = a.tolist()
+        a = rng.normal(size=400)
+        f.create_dataset("ea/ea_filtered", data=a, chunks=(2,), maxshape=(None,), compression="gzip", shuffle=True)
+        fl["ea/ea_filtered"] = a.tolist()
+        a = rng.integers(0, 60000, size=3001).astype(np.uint16)
+        f.create_dataset("ea/ea_super", data=a, chunks=(2,), maxshape=(None,))
+        fl["ea/ea_super"] = a.tolist()
+        a = rng.integers(0, 255, size=(37, 7)).astype(np.uint8)
+        f.create_dataset("ea/ea_2d_unlim0", data=a, chunks=(2, 3), maxshape=(None, 7))
+        fl["ea/ea_2d_unlim0"] = a.tolist()
+        a = rng.integers(0, 255, size=(9, 41)).astype(np.uint8)
+        f.create_dataset("ea/ea_2d_unlim1", data=a, chunks=(4, 2), maxshape=(12, None))
+        fl["ea/ea_2d_unlim1"] = a.tolist()
         g = f.create_group("grp")
         for i in range(6):
             g.create_dataset(f"d{i}", data=np.array([i * 1.5]))

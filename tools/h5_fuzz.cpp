@@ -3,8 +3,9 @@
 //       scan-rs_amd/csrc/h5lite.cpp scan-rs_amd/csrc/h5_matrix.cpp -lz -o /tmp/h5_fuzz
 //   /tmp/h5_fuzz 1500 tests/golden/*.h5
 // Every iteration overwrites 1-3 random bytes of a fixture (and truncates one file in ten), then runs every reader entry
-// point on it: each call must return a status, never touch memory it does not own. Round 2: 10 500 mutants, clean
-// (it found one real bug on the way: an indptr entry past nnz was dereferenced before it was validated).
+// point on it: each call must return a status, never touch memory it does not own. Round 2: 21 000 mutants over the seven
+// fixtures, clean (it found two real bugs on the way: an indptr entry past nnz dereferenced before it was validated, and
+// feature id / type tables of different lengths indexed by the same counter).
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -40,7 +41,7 @@ int main(int argc, char **argv) {
             if (rc == 0) scanrs_h5_matrix_free(m);
             uint64_t n = 0, nb = 0, dims[8]; uint32_t rank;
             std::vector<double> out(100000);
-            for (const char *ds : {"f64_2d_edge", "u64_be_chunked", "u32_many_chunks", "i32_compact", "fixed_array_paged", "fixed_array_filtered_2d", "implicit", "clustering/_graphclust/clusters", "all_differential_expression/_graphclust/data"})
+            for (const char *ds : {"f64_2d_edge", "u64_be_chunked", "u32_many_chunks", "i32_compact", "fixed_array_paged", "fixed_array_filtered_2d", "implicit", "ea/ea_small", "ea/ea_filtered", "ea/ea_super", "ea/ea_2d_unlim0", "ea/ea_2d_unlim1", "clustering/_graphclust/clusters", "all_differential_expression/_graphclust/data"})
                 scanrs_h5_read_f64("/tmp/scanrs_h5_fuzz_cur.h5", ds, out.data(), out.size(), dims, &rank);
             std::vector<char> buf(100000);
             scanrs_h5_member_names("/tmp/scanrs_h5_fuzz_cur.h5", "many", buf.data(), buf.size(), &n, &nb);
