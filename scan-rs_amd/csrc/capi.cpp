@@ -1,6 +1,7 @@
 // extern "C" boundary + operator-level host logic (the sqz::AdaptiveMat / LowRankOffset /
 // scan-rs::normalization surface). See include/scanrs_amd.h for the reference citations per entry point.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
@@ -24,6 +25,11 @@ void fail(int code, const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     throw Failure{code};
+}
+
+uint32_t next_map_op_id() {
+    static std::atomic<uint32_t> next{1};
+    return next.fetch_add(1, std::memory_order_relaxed);
 }
 
 bool trace_on() {
@@ -178,6 +184,7 @@ DevMap scanrs_mat::dev_map(bool outer_is_view_row) const {
         if (n >= MAX_OPS) fail(SCANRS_ERR_ARGUMENT, "map chain longer than %d links", MAX_OPS);
         DevOp &d = dm.ops[n++];
         d.kind = op.kind;
+        d.id = op.id;
         d.a = op.a ? op.a->p : nullptr;
         d.b = op.b ? op.b->p : nullptr;
         if (op.kind == OP_SCALE_AXIS) {
@@ -269,6 +276,7 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
         if (kb >= 64) st->l2_tile_bytes = (size_t)kb << 10;
     }
     if (const char *e = getenv("SCANRS_SPMM_ORDER")) st->spmm_order = atoi(e);
+    if (const char *e = getenv("SCANRS_MATERIALIZE")) st->materialize = atoi(e);
     if (const char *e = getenv("SCANRS_SPMM_PERSIST")) st->persist = atoi(e);
     if (const char *e = getenv("SCANRS_PERSIST_SLACK")) st->persist_slack = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("SCANRS_PERSIST_TILE_KB")) st->persist_tile_bytes = (size_t)std::max(64, atoi(e)) << 10;

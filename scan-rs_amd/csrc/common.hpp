@@ -158,6 +158,13 @@ struct SparseCopy {
     DevBuf<uint32_t> order;
     std::vector<uint32_t> sorted_len;
     std::shared_ptr<QuadLayout> quad; // built on first use of the LDS-staged product (spmm path 3)
+    // Materialized map values (kernels.hip, "materialized prefix"): f64 per nonzero, in this copy's order, of the first
+    // `fsig_n` links of a map chain — kept for the copy with few, long outer vectors, where evaluating the chain costs a
+    // scattered 8-byte gather per nonzero per product (the per-barcode scale while walking a gene's vector).
+    DevBuf<double> fvals;
+    int fsig_n = 0;
+    uint32_t fsig_id[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // MapOp ids of the materialized links (never reused)
+    int fsig_outer[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ... and how each indexes its arrays in this copy
     void build_items(hipStream_t s);
 };
 
@@ -214,6 +221,7 @@ struct Storage {
     uint32_t hot_segment = 512;           // ... and give a workgroup to vectors with >= this many nonzeros per step (0 = never)
     uint64_t blocked_min_nnz = 1ull << 22; // auto: matrices below this stay on the plain gather kernel
     // persistent form of the L2-blocked gather on copies with <= 16 outer vectors per wave of the chip (65536 on MI355X) (kernels.hip, spmm_gather2d_persist_kernel)
+    int materialize = 1;                  // keep the map prefix's values per nonzero on the short-outer copy (SCANRS_MATERIALIZE=0: off)
     int persist = 0;                      // 0 off, 1 on (SCANRS_SPMM_PERSIST)
     uint32_t persist_slack = 1;           // steps a wave may run ahead of the slowest workgroup (0: never wait)
     size_t persist_tile_bytes = 3u << 19; // panel slice per step: (slack + 1) slices share a 4 MB L2
@@ -225,13 +233,15 @@ struct Storage {
 
 // ---- lazy map (sqz::MatrixMap chain) ------------------------------------------------------
 enum { OP_INTO = 0, OP_SCALE_AXIS = 1, OP_LN_1P = 2, OP_LOG2_1P = 3, OP_LOG10_1P = 4, OP_SQUARE = 5, OP_BINOM_DEV = 6, OP_BINOM_PEARSON = 7 };
-constexpr int MAX_OPS = 8;
+constexpr int MAX_OPS = 8; // SparseCopy::fsig_* are sized to this
 
+uint32_t next_map_op_id(); // capi.cpp: never reused (1 ..), identifies a link and the arrays it holds
 struct MapOp {
     int kind = OP_INTO;
     int axis = 0;
     bool swap = false; // under an odd number of TransposeMap wrappers
     std::shared_ptr<DevBuf<double>> a, b;
+    uint32_t id = next_map_op_id(); // copies of a link (views) keep the id: same arrays, same values
 };
 
 // what the kernels see (by value)
@@ -239,7 +249,7 @@ struct DevOp {
     int kind;
     int a_outer; // index `a` by the outer (1) or inner (0) position of the copy being walked
     int b_outer;
-    int _pad;
+    uint32_t id; // MapOp::id
     const double *a;
     const double *b;
 };

@@ -185,12 +185,16 @@ __global__ void build_bounds_kernel(const uint64_t *__restrict__ indptr, const u
 // nonzeros per step: popular genes on the gene-major copy) get a whole workgroup: its 4 waves take a quarter of the
 // segment each, partial sums meet in LDS and wave 0 adds them in wave order (deterministic) — otherwise one such
 // wave is the critical path of the whole step.
-template <int NACC>
+// MAT: the first `fstart` links of the map were evaluated once per nonzero into `fvals` (materialized prefix, see
+// ensure_fvals); the kernel reads that f64 instead of the u32 count and applies only the remaining links, which index
+// their arrays by the outer position (wave-uniform) — no scattered gather of a scale per nonzero.
+template <int NACC, bool MAT>
 __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
     const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices, const uint32_t *__restrict__ values,
     const uint32_t *__restrict__ bounds, uint32_t nb, uint32_t b0, uint32_t b1, int first, int last, uint64_t n_outer,
     const uint32_t *__restrict__ order, uint32_t n_hot, DevMap map, const double *__restrict__ X, uint32_t ldx, uint32_t l,
-    double *out, uint32_t ldo, const double *__restrict__ off_a, uint32_t rank, const double *__restrict__ off_w, uint32_t ldw) {
+    double *out, uint32_t ldo, const double *__restrict__ off_a, uint32_t rank, const double *__restrict__ off_w, uint32_t ldw,
+    const double *__restrict__ fvals, int fstart) {
     __shared__ d2 part[3][NACC][64];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -215,7 +219,12 @@ __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
     const uint64_t base = indptr[row64] + o0;
     const uint32_t *__restrict__ ind = indices + base;
     const uint32_t *__restrict__ val = values + base;
+    const double *__restrict__ fv = MAT ? fvals + base : nullptr;
     const RowMap rm = row_map(map, row);
+    // MAT with a single trailing link (the usual 1/sigma): its factor is one number per outer vector, read once here
+    // instead of once per chunk of 64 nonzeros (same product f * a, same rounding)
+    const bool one_post = MAT && fstart + 1 == map.n;
+    const double post = one_post ? map.ops[fstart & (MAX_OPS - 1)].a[row] : 1.0;
 
     uint32_t col[NACC], lcol[NACC];
     bool act[NACC];
@@ -234,7 +243,10 @@ __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
         double f = 0.0;
         if (p < len) {
             idx = ind[p];
-            f = eval_map(map, rm, val[p], row, idx);
+            if constexpr (MAT)
+                f = one_post ? post * fv[p] : eval_map_from(map, fstart, fv[p], row, idx);
+            else
+                f = eval_map(map, rm, val[p], row, idx);
         }
         const uint32_t n = min(64u, len - c);
         // Lanes that own no column sit out the whole gather loop (one exec mask around it, v_readlane still sees
@@ -859,13 +871,14 @@ __global__ __launch_bounds__(256) void row_reduce2d_kernel(const uint64_t *__res
                                                            const uint32_t *__restrict__ values,
                                                            const uint32_t *__restrict__ bounds, uint32_t nb, uint32_t b0,
                                                            uint32_t b1, int first, uint64_t n_outer, DevMap map,
-                                                           double *__restrict__ out_sum, double *__restrict__ out_sumsq) {
+                                                           double *__restrict__ out_sum, double *__restrict__ out_sumsq,
+                                                           double *__restrict__ fout) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t row = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     if (row >= n_outer) return;
     const uint32_t *__restrict__ bd = bounds + row * (nb + 1);
     const uint32_t o0 = bd[b0], len = bd[b1] - o0;
-    if (len == 0 && !first) return;
+    if (len == 0 && (!first || MODE == 3)) return;
     const uint64_t base = indptr[row] + o0;
     const RowMap rm = row_map(map, (uint32_t)row);
     double s = 0.0, s2 = 0.0;
@@ -885,8 +898,10 @@ __global__ __launch_bounds__(256) void row_reduce2d_kernel(const uint64_t *__res
             const double x = eval_map(map, rm, vv[u], (uint32_t)row, g[u]);
             s = ok[u] ? s + x : s;
             if constexpr (MODE == 2) s2 = ok[u] ? fma(x, x, s2) : s2;
+            if (fout && ok[u]) fout[base + p0 + 64u * u] = x; // the mapped value itself, kept for the products (ensure_fvals)
         }
     }
+    if constexpr (MODE == 3) return; // values only
     s = wave_sum(s);
     if constexpr (MODE == 2) s2 = wave_sum(s2);
     if (lane == 0) {
@@ -1473,6 +1488,66 @@ static uint32_t count_at_least(const SparseCopy &cp, uint64_t min_len) {
     return (uint32_t)lo;
 }
 
+// ---- materialized prefix of the map chain ---------------------------------------------------------------------------
+// On the copy with few, long outer vectors (genes as outer vectors) the chain of normalize() starts with the per-barcode
+// scale: an 8-byte read at the INNER index of every nonzero, i.e. one scattered line request per lane per 64 nonzeros,
+// in every product (measured: +3.4 ms on a 39.3 ms pass, 1 M x 33 k). The first `n` links — everything up to the trailing
+// run of outer-indexed ScaleAxis links — give one f64 per nonzero that does not change between products: it is kept
+// (8 B per nonzero beside the 8 B of index + count) and the products apply only the trailing links, which are uniform
+// over an outer vector. Identity is by MapOp id (never reused), so a re-normalized handle or another view never sees
+// stale values. Same arithmetic in the same order as the lazy evaluation: results are bit-identical.
+static int fvals_prefix_len(const DevMap &map) {
+    int n = map.n;
+    while (n > 0 && map.ops[n - 1].kind == OP_SCALE_AXIS && map.ops[n - 1].a_outer) n--;
+    return n;
+}
+static bool fvals_wanted(Storage &st, const SparseCopy &cp, const DevMap &map, int n) {
+    if (!st.materialize || n <= 0 || n > MAX_OPS || cp.n_outer >= cp.n_inner || cp.nnz < st.blocked_min_nnz) return false;
+    bool inner_indexed = false;
+    for (int i = 0; i < n; i++)
+        inner_indexed = inner_indexed || (map.ops[i].a && !map.ops[i].a_outer) || (map.ops[i].b && !map.ops[i].b_outer);
+    if (!inner_indexed) return false;
+    if (cp.fvals.n == cp.nnz) return true; // already allocated
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    return free_b > cp.nnz * 8 + (size_t(8) << 30); // leave room for the solver's panels
+}
+static bool fvals_match(const SparseCopy &cp, const DevMap &map, int n) {
+    if (cp.fsig_n != n || cp.fvals.n != cp.nnz) return false;
+    for (int i = 0; i < n; i++)
+        if (cp.fsig_id[i] != map.ops[i].id || cp.fsig_outer[i] != map.ops[i].a_outer) return false;
+    return true;
+}
+// the buffer, about to be (re)written with the values of the first n links of `map`
+static double *fvals_claim(Storage &st, SparseCopy &cp, const DevMap &map, int n) {
+    if (cp.fvals.n != cp.nnz) cp.fvals.alloc(cp.nnz);
+    cp.fsig_n = n;
+    for (int i = 0; i < n; i++) {
+        cp.fsig_id[i] = map.ops[i].id;
+        cp.fsig_outer[i] = map.ops[i].a_outer;
+    }
+    return cp.fvals.p;
+}
+// values of the first n links for every nonzero of the copy; computed here when the moments pass did not leave them
+static const double *ensure_fvals(Storage &st, SparseCopy &cp, const DevMap &map, int n) {
+    if (fvals_match(cp, map, n)) return cp.fvals.p;
+    double *fout = fvals_claim(st, cp, map, n);
+    DevMap prefix = map;
+    prefix.n = n;
+    const uint32_t nb = ensure_bounds(st, cp);
+    const uint32_t m = 256;
+    const uint32_t steps = (nb + m - 1) / m;
+    const dim3 grid((unsigned)((cp.n_outer + 3) / 4)), block(256);
+    for (uint32_t sidx = 0; sidx < steps; sidx++) {
+        const uint32_t b0 = sidx * m, b1 = std::min(nb, b0 + m);
+        ProfScope ps(st, "materialize_map_values", (double)cp.nnz * 16.0 / steps);
+        hipLaunchKernelGGL((row_reduce2d_kernel<3>), grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p, cp.bounds.p, nb, b0,
+                           b1, sidx == 0 ? 1 : 0, cp.n_outer, prefix, (double *)nullptr, (double *)nullptr, fout);
+    }
+    SCANRS_HIP(hipGetLastError());
+    return cp.fvals.p;
+}
+
 // L2-blocked gather: see spmm_gather2d_kernel.
 static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
                            double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w,
@@ -1487,6 +1562,8 @@ static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const
     // -8 % per step); with ~10^6 vectors there is no tail to hide and the permuted rows only scatter the streaming reads (+3 %).
     const bool ordered = st.spmm_order == 2 || (st.spmm_order == 1 && cp.n_outer <= 65536u);
     if (ordered) ensure_order(st, cp);
+    const int fstart = fvals_prefix_len(map);
+    const double *fvals = fvals_wanted(st, cp, map, fstart) ? ensure_fvals(st, cp, map, fstart) : nullptr;
     const dim3 block(256);
     for (uint32_t c0 = 0; c0 < l; c0 += lc) {
         const uint32_t lw = std::min(lc, l - c0);
@@ -1504,9 +1581,16 @@ static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const
             ProfScope ps(st, cp.n_outer >= cp.n_inner ? (lw > 110 ? "spmm_gather2d_kernel<1>/long-outer/wide" : "spmm_gather2d_kernel<1>/long-outer")
                                                       : "spmm_gather2d_kernel<1>/short-outer", bytes,
                         (double)cp.nnz * 8.0 * lw / steps);
-            hipLaunchKernelGGL((spmm_gather2d_kernel<1>), grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p,
-                               cp.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, sidx + 1 == steps ? 1 : 0, cp.n_outer,
-                               ordered ? cp.order.p : nullptr, n_hot, map, X + c0, ldx, lw, out + c0, ldo, off_a, rank, offw, ldw);
+            if (fvals)
+                hipLaunchKernelGGL((spmm_gather2d_kernel<1, true>), grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p,
+                                   cp.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, sidx + 1 == steps ? 1 : 0, cp.n_outer,
+                                   ordered ? cp.order.p : nullptr, n_hot, map, X + c0, ldx, lw, out + c0, ldo, off_a, rank, offw, ldw,
+                                   fvals, fstart);
+            else
+                hipLaunchKernelGGL((spmm_gather2d_kernel<1, false>), grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p,
+                                   cp.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, sidx + 1 == steps ? 1 : 0, cp.n_outer,
+                                   ordered ? cp.order.p : nullptr, n_hot, map, X + c0, ldx, lw, out + c0, ldo, off_a, rank, offw, ldw,
+                                   (const double *)nullptr, 0);
         }
     }
     SCANRS_HIP(hipGetLastError());
@@ -1719,16 +1803,19 @@ void launch_row_reduce(Storage &st, SparseCopy &cp, const DevMap &map, int mode,
             const uint32_t m = 256; // 256 * 1024 inner positions * 8 B = 2 MB slice of the scale array
             const uint32_t steps = (nb + m - 1) / m;
             const dim3 grid((unsigned)((cp.n_outer + 3) / 4)), block(256);
-            const double bytes = ((double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_outer * (mode == 1 ? 8.0 : 16.0)) / steps;
+            // the moments walk evaluates exactly the chain the later products start with (normalize: scale, log — then
+            // the 1/sigma link is appended): keep the values, the products then skip the per-nonzero scale gather
+            double *fout = mode == 2 && fvals_wanted(st, cp, map, map.n) ? fvals_claim(st, cp, map, map.n) : nullptr;
+            const double bytes = ((double)cp.nnz * (fout ? 16.0 : 8.0) + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_outer * (mode == 1 ? 8.0 : 16.0)) / steps;
             for (uint32_t sidx = 0; sidx < steps; sidx++) {
                 const uint32_t b0 = sidx * m, b1 = std::min(nb, b0 + m);
                 ProfScope ps(st, mode == 1 ? "row_reduce2d_sum" : "row_reduce2d_moments", bytes);
                 if (mode == 1)
                     hipLaunchKernelGGL((row_reduce2d_kernel<1>), grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p,
-                                       cp.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, cp.n_outer, map, out_sum, out_sumsq);
+                                       cp.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, cp.n_outer, map, out_sum, out_sumsq, (double *)nullptr);
                 else
                     hipLaunchKernelGGL((row_reduce2d_kernel<2>), grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p,
-                                       cp.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, cp.n_outer, map, out_sum, out_sumsq);
+                                       cp.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, cp.n_outer, map, out_sum, out_sumsq, fout);
             }
             SCANRS_HIP(hipGetLastError());
             return;

@@ -980,3 +980,52 @@ def test_persistent_gather_matches_the_multi_launch_form(sa, monkeypatch, knobs)
             assert np.array_equal(gp.rdot(ql), gm.rdot(ql))
         names = set(gp.profile_get())
         assert any("persist" in n for n in names), names
+
+
+def test_materialized_map_values_are_bit_identical_and_never_stale(sa, monkeypatch):
+    """On the copy with few, long outer vectors the first links of the normalisation chain (per-barcode scale, log) are
+    evaluated once per nonzero and kept (SCANRS_MATERIALIZE, default on): the moments pass of normalize() leaves them,
+    the products read them. Same arithmetic in the same order, so products and PCA agree bit for bit with the lazy
+    evaluation; values are keyed by link identity, so re-normalizing, another view or a different size factor never
+    sees the previous values."""
+    import scipy.sparse as sp
+
+    genes, cells = 220, 560_000
+    rng = np.random.default_rng(11)
+    a = sp.random(genes, cells, density=0.04, random_state=3, format="csc", dtype=np.float64)
+    a.data = np.floor(a.data * 6 + 1)
+    a = a.astype(np.uint32)
+    assert a.nnz > (1 << 22) and cells >= (1 << 19)  # blocked kernels + the 2-D moments walk
+    x = rng.standard_normal((cells, 40))
+    y = rng.standard_normal((genes, 40))
+    sf = rng.integers(500, 5000, size=cells).astype(np.uint32)
+
+    def run(materialize):
+        monkeypatch.setenv("SCANRS_MATERIALIZE", "1" if materialize else "0")
+        m = sa.AdaptiveMat.from_scipy(a)
+        m.profile_enable(True)
+        out = {}
+        sa.normalize(m, sa.Normalization.CellRanger)
+        out["dot"] = m.dot(x)          # genes x 40: walks the gene-major copy (few long vectors)
+        out["tdot"] = m.t().dot(y)     # cells x 40: the other copy, never materialized
+        out["s"] = sa.BkSvd().run_pca(m, 5)[1]
+        v = m.view()                   # a view with another chain on the same storage
+        v.reset_map()
+        sa.log_normalize_with_size_factor(v, None, sa.FN_LN_1P, sf)
+        out["view_dot"] = v.dot(x)
+        out["dot_again"] = m.dot(x)    # back to the first chain
+        m.reset_map()
+        sa.normalize(m, sa.Normalization.SeuratLog)   # new links -> new values
+        out["renorm_dot"] = m.dot(x)
+        names = set(m.profile_get())
+        return out, names
+
+    lazy, names_lazy = run(False)
+    mat, names_mat = run(True)
+    assert "materialize_map_values" not in names_lazy
+    for k_ in lazy:
+        assert np.array_equal(lazy[k_], mat[k_]), k_
+    assert np.array_equal(mat["dot"], mat["dot_again"])
+    assert not np.array_equal(mat["dot"], mat["renorm_dot"])
+    # the view's chain was not left by a moments pass: its values were computed by the dedicated walk
+    assert "materialize_map_values" in names_mat, names_mat
