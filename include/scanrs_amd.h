@@ -358,6 +358,11 @@ const char *scanrs_h5_matrix_string(const scanrs_h5_matrix *m, int what, uint64_
 /* indices (in the file's feature order) of the features that were filtered out — the BTreeSet the reference returns */
 int scanrs_h5_matrix_removed(const scanrs_h5_matrix *m, const uint64_t **removed, uint64_t *n);
 
+/* `load_mtx` (scan-rs/src/mtx.rs:10-51): gzipped MatrixMarket coordinate file -> CSR arrays in the same handle type
+ * (no string tables; scanrs_h5_matrix_arrays / _shape / _free apply). Comments '%', header "NROW NCOL NNZ", 1-based
+ * "ROW COL VAL" triplets with u32 values, duplicates summed, indices ascending inside a row (TriMat::to_csr). */
+int scanrs_mtx_read(const char *path, scanrs_h5_matrix **out);
+
 /* `read_umi_counts_from_matrix` (:270-299): per-barcode sums of the stored values, read in blocks of 2000 columns */
 int scanrs_h5_read_umi_counts(const char *path, uint32_t *out, uint64_t cap, uint64_t *n);
 

@@ -406,4 +406,14 @@ inline Array2 get_differential_expression(const std::string &analysis_h5, const 
 }
 } // namespace hdf5_io
 
+namespace mtx {
+// scan_rs::mtx::load_mtx (scan-rs/src/mtx.rs:10-51): the CSR arrays; `.to_device()` is the AdaptiveMat the reference returns
+inline hdf5_io::FeatureBarcodeMatrix read_mtx(const std::string &path) {
+    scanrs_h5_matrix *h = nullptr;
+    check(scanrs_mtx_read(path.c_str(), &h));
+    return hdf5_io::detail::take(h);
+}
+inline AdaptiveMat load_mtx(const std::string &path) { return read_mtx(path).to_device(); }
+} // namespace mtx
+
 } // namespace scanrs

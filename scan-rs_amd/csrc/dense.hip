@@ -252,6 +252,7 @@ void launch_gram_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, c
 void launch_gemm_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *W, uint32_t ldw, uint32_t m,
                        uint64_t rows, double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo) {
     if (st.prof.on) st.prof.begin(st.stream, "gemm_tiled_mfma_f64", (double)rows * (n + m) * 8.0 + (double)n * m * 8.0);
+    if (trace_on()) fprintf(stderr, "[scanrs trace] gemm_tiled rows=%llu n=%u m=%u ldx=%u ldw=%u beta=%g\n", (unsigned long long)rows, n, m, ldx, ldw, beta);
     hipLaunchKernelGGL(gemm_tiled_kernel, dim3((unsigned)((rows + DT - 1) / DT), (m + DT - 1) / DT), dim3(256), 0, st.stream, X, ldx,
                        n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
     if (st.prof.on) st.prof.end(st.stream);

@@ -11,21 +11,11 @@
 
 #include "common_err.hpp"
 #include "h5lite.hpp"
+#include "host_matrix.hpp"
 
 using scanrs::fail;
 using scanrs::Failure;
 namespace h5 = scanrs::h5;
-
-struct scanrs_h5_matrix {
-    std::string name;
-    std::vector<std::string> barcodes, feature_ids, feature_names, feature_types;
-    bool has_matrix = false;
-    int storage = SCANRS_CSC;
-    uint64_t rows = 0, cols = 0, nnz = 0;
-    std::vector<uint64_t> indptr;
-    std::vector<uint32_t> indices, values;
-    std::vector<uint64_t> removed;
-};
 
 namespace {
 
