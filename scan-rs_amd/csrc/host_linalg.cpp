@@ -7,7 +7,13 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <numeric>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "common.hpp"
@@ -201,6 +207,84 @@ bool sym_eig(const double *a_in, int n, double *w, double *z) {
 }
 
 
+// A small persistent team of host threads for the threaded part of sym_eig_topk: creating threads costs more than the
+// whole 6 ms it saves (measured 1-3 ms per std::thread in a container), so they are created once, parked on a condition
+// variable between uses, and never destroyed (the object is leaked on purpose: no destructor runs while they wait).
+// One user at a time: a second concurrent caller (the shards of a MultiMat run their replicated eigenproblems at the same
+// time) simply does not get the team and works alone — the arithmetic does not depend on it.
+class HostTeam {
+  public:
+    static HostTeam *acquire(int n_threads) { // nullptr: busy, unavailable, or a forked child without the threads
+        static HostTeam *inst = new HostTeam();
+        if (inst->pid_ != getpid()) return nullptr; // the threads did not survive a fork
+        if (!inst->busy_.try_lock()) return nullptr;
+        if (!inst->ensure(n_threads)) {
+            inst->busy_.unlock();
+            return nullptr;
+        }
+        return inst;
+    }
+    void release() { busy_.unlock(); }
+    // runs fn(t) on team threads t = 1 .. n-1 (asynchronously); the caller is thread 0 and must call join() afterwards
+    void start(int n, std::function<void(int)> fn) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = std::move(fn);
+            active_ = n;
+            remaining_.store(n - 1, std::memory_order_relaxed);
+            epoch_++;
+        }
+        cv_.notify_all();
+    }
+    void join() {
+        int spins = 0;
+        while (remaining_.load(std::memory_order_acquire) != 0) {
+            if (++spins < 2000)
+                __builtin_ia32_pause();
+            else
+                std::this_thread::yield();
+        }
+    }
+
+  private:
+    HostTeam() : pid_(getpid()) {}
+    bool ensure(int n) {
+        try {
+            while ((int)threads_.size() < n - 1) {
+                const int t = (int)threads_.size() + 1;
+                threads_.emplace_back([this, t] { loop(t); });
+                threads_.back().detach();
+            }
+        } catch (...) {
+            return false;
+        }
+        return true;
+    }
+    void loop(int t) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(int)> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return epoch_ != seen; });
+                seen = epoch_;
+                if (t >= active_) continue;
+                job = job_;
+            }
+            job(t);
+            remaining_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    pid_t pid_;
+    std::mutex busy_, m_;
+    std::condition_variable cv_;
+    std::vector<std::thread> threads_;
+    std::function<void(int)> job_;
+    int active_ = 0;
+    uint64_t epoch_ = 0;
+    std::atomic<int> remaining_{0};
+};
+
 // Top-k eigenpairs of a symmetric matrix: Householder tridiagonalisation, all eigenvalues by implicit QL
 // on (d, e) alone (O(n^2)), the k leading eigenvectors by inverse iteration on the tridiagonal matrix with
 // re-orthogonalisation against the vectors already found, then back-transformation through the stored
@@ -282,46 +366,149 @@ bool sym_eig_topk(const double *a_in, int n, int k, double *w, double *z) {
             for (int i = 1; i < n; i++) vk[i] = v[i];
         }
     }
-    for (int kk = 0; kk < n - 2; kk++) {
-        // apply the pending reflector of step kk to column kk+1 and the diagonal entry (kk+1, kk+1)
-        const int c = kk + 1;
-        if (have) {
-            for (int i = c; i < n; i++) A[(size_t)i * n + c] -= v[i] * p[c] + p[i] * v[c];
-        }
-        bool have_next = false;
-        if (c < n - 2) {
-            for (int i = c + 1; i < n; i++) colbuf[i] = A[(size_t)i * n + c];
-            have_next = make_reflector(c, colbuf.data(), vn.data());
-        }
-        // one pass over rows c+1..n-1, columns c+1..i: update with (v, p), accumulate pn = A' vn
-        if (have_next)
-            for (int j = c + 1; j < n; j++) pn[j] = 0.0;
-        if (have || have_next) {
-            for (int i = c + 1; i < n; i++) {
-                double *__restrict__ ai = A.data() + (size_t)i * n;
-                if (have) {
-                    const double vi = v[i], pi = p[i];
-                    const double *__restrict__ pp = p.data();
-                    const double *__restrict__ vv = v.data();
-                    for (int j = c + 1; j <= i; j++) ai[j] -= vi * pp[j] + pi * vv[j];
-                }
-                if (have_next) {
-                    double *__restrict__ pq = pn.data();
-                    const double *__restrict__ vq = vn.data();
-                    const double vi = vq[i];
-                    double s = 0.0;
-                    {
-#pragma clang fp reassociate(on)
-                        for (int j = c + 1; j < i; j++) {
-                            s += ai[j] * vq[j];
-                            pq[j] += ai[j] * vi;
-                        }
-                    }
-                    pq[i] += s + ai[i] * vi;
+    // Steps kk = 0 .. n-3. The pass over the trailing rows is cut into VS = 4 fixed slots — row i belongs to slot
+    // (i - c - 1) % 4 — each folding its rows into ITS OWN partial of p' (the scatter half of the symmetric product would
+    // race otherwise); the partials are added in slot order after the pass. The arithmetic is therefore the same whether
+    // one thread walks the four slots or a team of 2 / 4 shares them: results do not depend on the thread count, the
+    // host, or on timing (replicated ranks must get identical factors). With a team (n >= 768) there are four spin barriers
+    // per step; thread 0 keeps the serial parts (column update, reflector, finishing p'). If the barriers turn out slow
+    // (an oversubscribed or CPU-throttled host: the others are not running), the team is dismissed and thread 0 goes on alone.
+    constexpr int VS = 4;
+    static const int T_env = [] {
+        const char *e_ = getenv("SCANRS_EIG_THREADS");
+        const int t_ = e_ ? atoi(e_) : 4;
+        return t_ >= 4 ? 4 : (t_ >= 2 ? 2 : 1);
+    }();
+    // measured on the MI355X host (256 cores): n = 1000: 48.6 -> 31 ms with 4 threads; n = 500: 6.1 -> 7.8 ms (the 2 MB matrix
+    // lives in one core's L2 and the three barriers per step cost more than the split saves) -> team from n = 768 on
+    int T = (n >= 768 && std::thread::hardware_concurrency() >= 8) ? T_env : 1;
+    HostTeam *pool = T > 1 ? HostTeam::acquire(T) : nullptr;
+    if (!pool) T = 1;
+    std::vector<std::vector<double>> pn_part(VS - 1, std::vector<double>(n, 0.0)); // slot 0 uses pn itself
+    struct SpinBarrier {
+        std::atomic<int> count{0}, gen{0};
+        int n_threads = 1;
+        void wait() {
+            if (n_threads == 1) return;
+            const int g = gen.load(std::memory_order_acquire);
+            if (count.fetch_add(1, std::memory_order_acq_rel) == n_threads - 1) {
+                count.store(0, std::memory_order_relaxed);
+                gen.store(g + 1, std::memory_order_release);
+            } else {
+                int spins = 0;
+                while (gen.load(std::memory_order_acquire) == g) {
+                    if (++spins < 20000)
+                        __builtin_ia32_pause();
+                    else
+                        std::this_thread::yield();
                 }
             }
         }
+    } bar;
+    bar.n_threads = T;
+    // shared step state, written by thread 0 between the barriers
+    int step_c = 0;
+    bool step_have = false, step_have_next = false, team_done = false;
+    auto slot_pass = [&](int slot) {
+        const int c = step_c;
+        const bool hv = step_have, hn = step_have_next;
+        if (!hv && !hn) return;
+        double *__restrict__ pq = slot == 0 ? pn.data() : pn_part[slot - 1].data();
+        if (hn)
+            for (int j = c + 1; j < n; j++) pq[j] = 0.0;
+        for (int i = c + 1 + ((slot - (c + 1)) % VS + VS) % VS; i < n; i += VS) { // rows with i % VS == slot: a row never changes owner
+            double *__restrict__ ai = A.data() + (size_t)i * n;
+            if (hv) {
+                const double vi = v[i], pi = p[i];
+                const double *__restrict__ pp = p.data();
+                const double *__restrict__ vv = v.data();
+                for (int j = c + 1; j <= i; j++) ai[j] -= vi * pp[j] + pi * vv[j];
+            }
+            if (hn) {
+                const double *__restrict__ vq = vn.data();
+                const double vi = vq[i];
+                double s_ = 0.0;
+                {
+#pragma clang fp reassociate(on)
+                    for (int j = c + 1; j < i; j++) {
+                        s_ += ai[j] * vq[j];
+                        pq[j] += ai[j] * vi;
+                    }
+                }
+                pq[i] += s_ + ai[i] * vi;
+            }
+        }
+    };
+    // the pending reflector applied to column c, by the owners of the rows (thread 0 never touches their cache lines):
+    // the updated entries also go to colbuf, from which thread 0 builds the next reflector
+    auto col_pass = [&](int slot) {
+        const int c = step_c;
+        for (int i = c + ((slot - c) % VS + VS) % VS; i < n; i += VS) {
+            double &a = A[(size_t)i * n + c];
+            if (step_have) a -= v[i] * p[c] + p[i] * v[c];
+            colbuf[i] = a;
+        }
+    };
+    const int T_team = T;
+    if (pool)
+        pool->start(T_team, [&](int t) {
+            for (;;) {
+                bar.wait(); // step state (c, have) published
+                if (team_done) return;
+                for (int slot = t; slot < VS; slot += T_team) col_pass(slot);
+                bar.wait(); // column c complete
+                bar.wait(); // reflector published
+                for (int slot = t; slot < VS; slot += T_team) slot_pass(slot);
+                bar.wait(); // partials complete
+            }
+        });
+    double waited_ms = 0.0;
+    for (int kk = 0; kk < n - 2; kk++) {
+        // apply the pending reflector of step kk to column kk+1 and the diagonal entry (kk+1, kk+1)
+        const int c = kk + 1;
+        step_c = c;
+        step_have = have;
+        bool have_next = false;
+        auto since = [](std::chrono::steady_clock::time_point t0_) {
+            return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count();
+        };
+        if (T > 1) {
+            auto w0 = std::chrono::steady_clock::now();
+            bar.wait();
+            double w = kk > 0 ? since(w0) : 0.0; // the first barrier includes waking the team
+            for (int slot = 0; slot < VS; slot += T_team) col_pass(slot);
+            w0 = std::chrono::steady_clock::now();
+            bar.wait();
+            w += since(w0);
+            if (c < n - 2) have_next = make_reflector(c, colbuf.data(), vn.data());
+            step_have_next = have_next;
+            bar.wait();
+            // one pass over rows c+1..n-1, columns c+1..i: update with (v, p), accumulate pn = A' vn
+            for (int slot = 0; slot < VS; slot += T_team) slot_pass(slot);
+            w0 = std::chrono::steady_clock::now();
+            bar.wait();
+            waited_ms += w + since(w0);
+            if (kk >= 7 && waited_ms > 0.05 * (kk + 1) + 0.3) { // > 50 us per step waiting for the others: they are not running
+                team_done = true;
+                bar.wait();
+                pool->join();
+                pool->release();
+                pool = nullptr;
+                T = 1;
+                if (tr) fprintf(stderr, "[eig] team dismissed after %d steps (%.2f ms spent waiting)\n", kk + 1, waited_ms);
+            }
+        } else {
+            for (int slot = 0; slot < VS; slot++) col_pass(slot);
+            if (c < n - 2) have_next = make_reflector(c, colbuf.data(), vn.data());
+            step_have_next = have_next;
+            for (int slot = 0; slot < VS; slot++) slot_pass(slot);
+        }
         if (have_next) {
+            for (int slot = 1; slot < VS; slot++) {
+                const double *__restrict__ part = pn_part[slot - 1].data();
+                double *__restrict__ pq = pn.data();
+                for (int j = c + 1; j < n; j++) pq[j] += part[j];
+            }
             finish_p(c, pn.data(), vn.data());
             double *vk = V.data() + (size_t)c * n;
             for (int i = c + 1; i < n; i++) vk[i] = vn[i];
@@ -329,6 +516,14 @@ bool sym_eig_topk(const double *a_in, int n, int k, double *w, double *z) {
             std::swap(p, pn);
         }
         have = have_next;
+    }
+    if (pool) {
+        team_done = true;
+        bar.wait();
+        pool->join();
+        pool->release();
+        pool = nullptr;
+        if (tr) fprintf(stderr, "[eig] team of %d: %.3f ms spent waiting at barriers\n", T, waited_ms);
     }
     for (int i = 0; i < n; i++) d[i] = A[(size_t)i * n + i];
     if (n >= 2) e[n - 2] = A[(size_t)(n - 1) * n + (n - 2)];

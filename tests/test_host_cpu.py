@@ -242,3 +242,25 @@ def test_host_sym_eig_topk(sa):
     assert np.max(np.abs(w - ws) / ws) < 1e-12
     assert np.max(np.abs(z.T @ z - np.eye(60))) < 1e-12
     assert np.max(np.abs(g @ z - z * w)) < 1e-12 * ws[0]
+
+
+def test_sym_eig_topk_does_not_depend_on_the_thread_count():
+    """The tridiagonalisation sums its partial products in four fixed slots whether one thread or a team walks them
+    (host_linalg.cpp): replicated ranks, hosts with fewer cores and a dismissed team all get bit-identical factors."""
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, scanrs_amd as sa, sys\n"
+        "rng = np.random.default_rng(4)\n"
+        "b = rng.standard_normal((800, 800)); a = b @ b.T\n"
+        "w, z = sa.host_sym_eig_topk(a, 40)\n"
+        "sys.stdout.write(w.tobytes().hex() + z.tobytes().hex())\n"
+    )
+    outs = []
+    for t in ("1", "2", "4"):
+        env = dict(os.environ, SCANRS_EIG_THREADS=t, PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 1000
