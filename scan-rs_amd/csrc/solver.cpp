@@ -540,9 +540,13 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
     double *dEs = c.dev("ritz_es", (size_t)q * k);
     c.h2d(dEs, Es.data(), Es.size());
     launch_gemm_nn(c.st, T, ldt, q, dEs, k, k, dt, 1.0, 0.0, nullptr, 0, dT, ldk);
-    if (hS) download_panel(c, dS, ldk, ds, k, hS); // null: the caller keeps the result in HBM (scanrs_pca_result_device)
-    if (hT) download_panel(c, dT, ldk, dt, k, hT);
-    c.sync();
+    {
+        c.sync();
+        Tick tk("ritz: download of the factors");
+        if (hS) download_panel(c, dS, ldk, ds, k, hS); // null: the caller keeps the result in HBM (scanrs_pca_result_device)
+        if (hT) download_panel(c, dT, ldk, dt, k, hT);
+        c.sync();
+    }
     // where the factors live on the device: side S first, side T second (the drivers map them to U / V)
     c.st.pca_dev.k = k;
     c.st.pca_dev.ld_u = c.st.pca_dev.ld_v = ldk;
