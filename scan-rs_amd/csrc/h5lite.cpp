@@ -8,9 +8,13 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
+#include <thread>
 #include <type_traits>
 
 #include "common_err.hpp"
@@ -700,7 +704,7 @@ void File::unfilter(std::vector<uint8_t> &buf, const std::vector<Filter> &filter
         if (mask & (1u << i)) continue;
         const Filter &f = filters[i];
         if (f.id == 1) { // deflate
-            std::vector<uint8_t> out((size_t)std::min<uint64_t>(std::max<uint64_t>(buf.size() * 4, 1024), limit));
+            std::vector<uint8_t> out((size_t)limit); // the declared chunk size (+ checksum): one allocation, no regrowth
             z_stream zs;
             memset(&zs, 0, sizeof(zs));
             if (inflateInit(&zs) != Z_OK) H5FAIL("%s: zlib initialisation failed", path_.c_str());
@@ -736,8 +740,25 @@ void File::unfilter(std::vector<uint8_t> &buf, const std::vector<Filter> &filter
             if (es > 1 && buf.size() >= es) {
                 const size_t n = buf.size() / es;
                 std::vector<uint8_t> out(buf.size());
-                for (size_t b = 0; b < es; b++)
-                    for (size_t i = 0; i < n; i++) out[i * es + b] = buf[b * n + i];
+                if (es == 4) {
+                    const uint8_t *b0 = buf.data(), *b1 = b0 + n, *b2 = b1 + n, *b3 = b2 + n;
+                    uint8_t *o = out.data();
+                    for (size_t i = 0; i < n; i++, o += 4) {
+                        o[0] = b0[i];
+                        o[1] = b1[i];
+                        o[2] = b2[i];
+                        o[3] = b3[i];
+                    }
+                } else if (es == 8) {
+                    const uint8_t *bb[8];
+                    for (int b = 0; b < 8; b++) bb[b] = buf.data() + (size_t)b * n;
+                    uint8_t *o = out.data();
+                    for (size_t i = 0; i < n; i++, o += 8)
+                        for (int b = 0; b < 8; b++) o[b] = bb[b][i];
+                } else {
+                    for (size_t b = 0; b < es; b++)
+                        for (size_t i = 0; i < n; i++) out[i * es + b] = buf[b * n + i];
+                }
                 for (size_t r = n * es; r < buf.size(); r++) out[r] = buf[r];
                 buf.swap(out);
             }
@@ -783,12 +804,15 @@ std::vector<uint8_t> File::read_raw(Object dataset, uint64_t start, uint64_t end
             if (c == 0) H5FAIL("%s: zero chunk dimension", path_.c_str());
             chunk_elems *= c;
         }
-        std::vector<uint64_t> idx(rank);
+        // the chunks that intersect the slice; each lands in its own region of `out`, so they can be inflated side by side
+        std::vector<const Chunk *> todo;
         for (const Chunk &c : lay.chunks) {
             if (c.offset[0] >= end || c.offset[0] + lay.chunk_dims[0] <= start) continue;
             bool inside = true;
             for (unsigned i = 0; i < rank; i++) inside = inside && c.offset[i] < di.dims[i];
-            if (!inside) continue;
+            if (inside) todo.push_back(&c);
+        }
+        auto place = [&](const Chunk &c, std::vector<uint64_t> &idx) {
             const uint8_t *src = at(base_addr_ + c.addr, c.size);
             std::vector<uint8_t> buf(src, src + c.size);
             unfilter(buf, lay.filters, c.filter_mask, chunk_elems * elem + 8);
@@ -822,6 +846,53 @@ std::vector<uint8_t> File::read_raw(Object dataset, uint64_t start, uint64_t end
                 }
                 if (k < 0) break;
             }
+        };
+        // Cell Ranger's `data` / `indices` of a 10^6-cell matrix are ~10^4 deflated chunks (12 GB inflated): zlib on one
+        // core is the whole load time, so large reads deal the chunks over a few threads (libhdf5 reads them one by one)
+        unsigned n_thr = 1;
+        if (!lay.filters.empty() && todo.size() >= 16 && out.size() >= (64u << 20)) {
+            static const unsigned cap = [] {
+                const char *e_ = getenv("SCANRS_H5_THREADS");
+                return e_ ? (unsigned)std::max(1, atoi(e_)) : 8u;
+            }();
+            n_thr = std::max(1u, std::min({cap, std::thread::hardware_concurrency(), (unsigned)(todo.size() / 4)}));
+        }
+        if (n_thr == 1) {
+            std::vector<uint64_t> idx(rank);
+            for (const Chunk *c : todo) place(*c, idx);
+        } else {
+            std::atomic<size_t> next{0};
+            std::atomic<bool> failed{false};
+            std::mutex err_m;
+            std::string err_msg;
+            int err_code = SCANRS_ERR_IO;
+            auto worker = [&] {
+                std::vector<uint64_t> idx(rank);
+                try {
+                    for (;;) {
+                        const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+                        if (i >= todo.size() || failed.load(std::memory_order_relaxed)) return;
+                        place(*todo[i], idx);
+                    }
+                } catch (const Failure &f) { // the message lives in this thread's error slot: carry it over
+                    std::lock_guard<std::mutex> lk(err_m);
+                    if (!failed.exchange(true)) {
+                        err_msg = scanrs_last_error();
+                        err_code = f.code;
+                    }
+                } catch (const std::exception &e) {
+                    std::lock_guard<std::mutex> lk(err_m);
+                    if (!failed.exchange(true)) err_msg = e.what();
+                }
+            };
+            std::vector<std::thread> pool;
+            try {
+                for (unsigned t = 1; t < n_thr; t++) pool.emplace_back(worker);
+            } catch (...) { // fewer helpers than planned: the caller's thread finishes the queue
+            }
+            worker();
+            for (auto &th : pool) th.join();
+            if (failed.load()) ::scanrs::fail(err_code, "%s", err_msg.c_str());
         }
     }
     return out;
@@ -863,6 +934,28 @@ std::vector<T> File::read(Object dataset, uint64_t start, uint64_t end, DatasetI
     const size_t es = di.type.size;
     const size_t n = es ? raw.size() / es : 0;
     std::vector<T> out(n);
+    // little-endian stored types (every 10x file): typed loads instead of assembling bytes
+    if (!di.type.big_endian && n) {
+        const uint8_t *r = raw.data();
+        auto typed = [&](auto tag) {
+            typedef decltype(tag) S;
+            for (size_t i = 0; i < n; i++) {
+                S v;
+                memcpy(&v, r + i * sizeof(S), sizeof(S));
+                out[i] = saturate<T, typename std::conditional<std::is_floating_point<S>::value, double,
+                                                               typename std::conditional<std::is_signed<S>::value, int64_t, uint64_t>::type>::type>(v);
+            }
+        };
+        bool done = true;
+        if (di.type.cls == TypeInfo::FLOAT && es == 8) typed(double());
+        else if (di.type.cls == TypeInfo::FLOAT && es == 4) typed(float());
+        else if (di.type.cls == TypeInfo::FIXED && di.type.is_signed && es == 8) typed(int64_t());
+        else if (di.type.cls == TypeInfo::FIXED && di.type.is_signed && es == 4) typed(int32_t());
+        else if (di.type.cls == TypeInfo::FIXED && !di.type.is_signed && es == 8) typed(uint64_t());
+        else if (di.type.cls == TypeInfo::FIXED && !di.type.is_signed && es == 4) typed(uint32_t());
+        else done = false;
+        if (done) return out;
+    }
     for (size_t i = 0; i < n; i++) {
         uint64_t bits = 0;
         const uint8_t *p = raw.data() + i * es;
