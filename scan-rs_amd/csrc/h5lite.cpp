@@ -704,7 +704,10 @@ void File::unfilter(std::vector<uint8_t> &buf, const std::vector<Filter> &filter
         if (mask & (1u << i)) continue;
         const Filter &f = filters[i];
         if (f.id == 1) { // deflate
-            std::vector<uint8_t> out((size_t)limit); // the declared chunk size (+ checksum): one allocation, no regrowth
+            // the declared chunk size (+ checksum) in one allocation — but never more than deflate can produce from this
+            // many input bytes (1032:1), so a corrupt chunk shape cannot ask for gigabytes
+            limit = std::min<uint64_t>(limit, (uint64_t)buf.size() * 1100 + 4096);
+            std::vector<uint8_t> out((size_t)limit);
             z_stream zs;
             memset(&zs, 0, sizeof(zs));
             if (inflateInit(&zs) != Z_OK) H5FAIL("%s: zlib initialisation failed", path_.c_str());
