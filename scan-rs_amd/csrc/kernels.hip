@@ -803,6 +803,116 @@ __global__ __launch_bounds__(1024) void spmv_lds_kernel(const uint64_t *__restri
     }
 }
 
+// Walk of the copy with few, long outer vectors (genes as outer vectors) against arrays indexed by the INNER position
+// (the per-barcode scale of normalize(), the vector of an Ix1 product): gathered from L2 every nonzero is its own line
+// request — 64 per load instruction, which the texture addresser serves at ~3.6 clk each: 5.9 ms for 10^9 nonzeros however
+// few bytes move (moments pass 5.8 ms, gene-major SpMV 6.0 ms, both at 1.4 TB/s). Here the inner dimension is cut into
+// slices of whole bounds tiles whose piece of the array fits in LDS; a 16-wave workgroup stages one slice, walks the
+// segments of its share of the outer vectors (dealt from the longest-first list) through it with ds_read gathers, and
+// leaves one partial per (slice, vector) in a slab that slice_reduce_kernel adds in slice order (deterministic).
+//   MODE 1: sums of f and f^2 (moments), optionally storing f per nonzero (the materialized prefix, see ensure_fvals)
+//   MODE 0: sum of f * x[inner] (Ix1 product)
+// Value of a nonzero: fvals given -> chain from link `fstart` on applied to fvals[p]; else, with `lazy_scale`, the chain's
+// first link is an inner-indexed ScaleAxis whose array is staged as well (`sa`); else the plain lazy chain.
+template <int MODE>
+__global__ __launch_bounds__(1024) void slice_walk_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                          const uint32_t *__restrict__ values, const double *__restrict__ fvals, int fstart,
+                                                          const uint32_t *__restrict__ bounds, uint32_t nb, uint32_t tiles_per_slice,
+                                                          uint64_t n_outer, uint64_t n_inner, const uint32_t *__restrict__ order,
+                                                          uint32_t n_groups, DevMap map, int lazy_scale, const double *__restrict__ X,
+                                                          uint32_t ldx, double *__restrict__ slab, double *__restrict__ fout) {
+    extern __shared__ double sl[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t slice = blockIdx.x, group = blockIdx.y;
+    const uint64_t c0 = (uint64_t)slice * tiles_per_slice << BT_SHIFT;
+    const uint32_t slice_len = tiles_per_slice << BT_SHIFT;
+    const uint32_t clen = (uint32_t)min((uint64_t)slice_len, n_inner - c0);
+    double *__restrict__ sx = sl;                       // MODE 0: x[c0 ..]
+    double *__restrict__ sa = MODE == 0 ? sl + slice_len : sl; // the staged scale array (after x for the Ix1 product)
+    if (MODE == 0)
+        for (uint32_t i = threadIdx.x; i < clen; i += 1024u) sx[i] = X[(c0 + i) * ldx];
+    if (lazy_scale) {
+        const double *__restrict__ a = map.ops[0].a;
+        for (uint32_t i = threadIdx.x; i < clen; i += 1024u) sa[i] = a[c0 + i];
+    }
+    __syncthreads();
+    const uint32_t b0 = slice * tiles_per_slice, b1 = min(nb, b0 + tiles_per_slice);
+    const uint32_t cbase = (uint32_t)c0;
+    for (uint64_t j = (uint64_t)group + (uint64_t)n_groups * wave; j < n_outer; j += (uint64_t)n_groups * 16u) {
+        const uint32_t row = order ? order[j] : (uint32_t)j;
+        const uint32_t *__restrict__ bd = bounds + (uint64_t)row * (nb + 1);
+        const uint32_t o0 = bd[b0], len = bd[b1] - o0;
+        const uint64_t base = indptr[row] + o0;
+        const RowMap rm = row_map(map, row);
+        double s = 0.0, s2 = 0.0;
+        for (uint32_t p0 = lane; p0 < len; p0 += 64u * SCAN_U) {
+            uint32_t g[SCAN_U], vv[SCAN_U];
+            double fv[SCAN_U];
+            bool ok[SCAN_U];
+#pragma unroll
+            for (int u = 0; u < SCAN_U; u++) {
+                const uint32_t p = p0 + 64u * u;
+                ok[u] = p < len;
+                const uint64_t q = base + (ok[u] ? p : len - 1u);
+                g[u] = indices[q];
+                if (fvals)
+                    fv[u] = fvals[q];
+                else
+                    vv[u] = values[q];
+            }
+#pragma unroll
+            for (int u = 0; u < SCAN_U; u++) {
+                double f;
+                if (fvals)
+                    f = eval_map_from(map, fstart, fv[u], row, g[u]);
+                else if (lazy_scale)
+                    f = eval_map_from(map, 1, sa[g[u] - cbase] * (double)vv[u], row, g[u]);
+                else
+                    f = eval_map(map, rm, vv[u], row, g[u]);
+                if constexpr (MODE == 1) {
+                    s = ok[u] ? s + f : s;
+                    s2 = ok[u] ? fma(f, f, s2) : s2;
+                    if (fout && ok[u]) fout[base + p0 + 64u * u] = f;
+                } else {
+                    s = ok[u] ? fma(f, sx[g[u] - cbase], s) : s;
+                }
+            }
+        }
+        s = wave_sum(s);
+        if constexpr (MODE == 1) s2 = wave_sum(s2);
+        if (lane == 0) {
+            if constexpr (MODE == 1) {
+                slab[((uint64_t)slice * n_outer + row) * 2u] = s;
+                slab[((uint64_t)slice * n_outer + row) * 2u + 1u] = s2;
+            } else {
+                slab[(uint64_t)slice * n_outer + row] = s;
+            }
+        }
+    }
+}
+// partials of slice_walk_kernel added in slice order; MODE 0 also applies the rank-r offset of the product
+template <int MODE>
+__global__ void slice_reduce_kernel(const double *__restrict__ slab, uint32_t n_slices, uint64_t n_outer, double *__restrict__ out_a,
+                                    uint32_t ld_a, double *__restrict__ out_b, const double *__restrict__ off_a, uint32_t rank,
+                                    const double *__restrict__ off_w, uint32_t ldw) {
+    const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_outer) return;
+    if constexpr (MODE == 1) {
+        double s = 0.0, s2 = 0.0;
+        for (uint32_t k = 0; k < n_slices; k++) {
+            s += slab[((uint64_t)k * n_outer + row) * 2u];
+            s2 += slab[((uint64_t)k * n_outer + row) * 2u + 1u];
+        }
+        out_a[row] = s;
+        if (out_b) out_b[row] = s2;
+    } else {
+        double s = 0.0;
+        for (uint32_t k = 0; k < n_slices; k++) s += slab[(uint64_t)k * n_outer + row];
+        for (uint32_t q = 0; q < rank; q++) s += off_a[row * rank + q] * off_w[(size_t)q * ldw];
+        out_a[row * ld_a] = s;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void row_reduce_kernel(const uint32_t *__restrict__ indices,
                                                          const uint32_t *__restrict__ values,
@@ -1548,6 +1658,49 @@ static const double *ensure_fvals(Storage &st, SparseCopy &cp, const DevMap &map
     return cp.fvals.p;
 }
 
+// ---- slice walk (slice_walk_kernel): eligibility and launch --------------------------------------------------------
+// chain shapes the slice walk evaluates: no inner-indexed link at all, or exactly one — a ScaleAxis in first position
+static bool slice_walk_chain(const DevMap &map, int from, bool &lazy_scale) {
+    lazy_scale = false;
+    for (int i = from; i < map.n; i++) {
+        const bool inner = (map.ops[i].a && !map.ops[i].a_outer) || (map.ops[i].b && !map.ops[i].b_outer);
+        if (!inner) continue;
+        if (i == 0 && from == 0 && map.ops[0].kind == OP_SCALE_AXIS && !map.ops[0].a_outer)
+            lazy_scale = true;
+        else
+            return false;
+    }
+    return true;
+}
+static bool slice_walk_enabled() { // read per call (tests flip it)
+    const char *e = getenv("SCANRS_SLICE_WALK");
+    return !(e && atoi(e) == 0);
+}
+// MODE 1: out_a = sums, out_b = sums of squares (may be null), fout optional.  MODE 0: out_a[row * ld_a] = product (+ offset)
+template <int MODE>
+static void launch_slice_walk(Storage &st, SparseCopy &cp, const DevMap &map, const double *fvals, int fstart, bool lazy_scale,
+                              const double *X, uint32_t ldx, double *out_a, uint32_t ld_a, double *out_b, double *fout,
+                              const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw, const char *label, double bytes) {
+    const uint32_t nb = ensure_bounds(st, cp);
+    const uint32_t arrays = (MODE == 0 ? 1u : 0u) + (lazy_scale ? 1u : 0u);
+    const uint32_t tps = arrays >= 2 ? 8u : 16u; // 8 / 16 tiles of 1024 positions: 128 KB of LDS either way
+    const uint32_t n_slices = (nb + tps - 1u) / tps;
+    const uint32_t n_groups = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((2048u + n_slices - 1u) / n_slices, (cp.n_outer + 15) / 16));
+    const bool ordered = cp.n_outer <= 65536u;
+    if (ordered) ensure_order(st, cp);
+    const size_t shmem = (size_t)std::max(1u, arrays) * ((size_t)tps << BT_SHIFT) * 8;
+    double *slab = st.scratch.get<double>("slice_slab", (size_t)n_slices * cp.n_outer * (MODE == 1 ? 2 : 1));
+    // per device, and handles of one process may live on different devices: set on every use (a cheap call)
+    SCANRS_HIP(hipFuncSetAttribute((const void *)slice_walk_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    ProfScope ps(st, label, bytes);
+    hipLaunchKernelGGL((slice_walk_kernel<MODE>), dim3(n_slices, n_groups), dim3(1024), shmem, st.stream, cp.indptr.p, cp.indices.p,
+                       cp.values.p, fvals, fstart, cp.bounds.p, nb, tps, cp.n_outer, cp.n_inner, ordered ? cp.order.p : nullptr, n_groups, map,
+                       lazy_scale ? 1 : 0, X, ldx, slab, fout);
+    hipLaunchKernelGGL((slice_reduce_kernel<MODE>), grid1(cp.n_outer, 256), dim3(256), 0, st.stream, slab, n_slices, cp.n_outer, out_a, ld_a,
+                       out_b, off_a, rank, off_w, ldw);
+    SCANRS_HIP(hipGetLastError());
+}
+
 // L2-blocked gather: see spmm_gather2d_kernel.
 static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
                            double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w,
@@ -1718,6 +1871,19 @@ void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const doubl
     if (l <= 2 && l > 0 && cp.n_outer > 0) {
         if ((ldx & 1u) || (ldo & 1u)) fail(SCANRS_ERR_ARGUMENT, "panel leading dimensions must be even");
         const bool long_outer = cp.n_outer >= cp.n_inner;
+        if (st.spmm_path != 1 && slice_walk_enabled() && l == 1 && !long_outer && cp.nnz >= st.blocked_min_nnz && cp.n_inner >= (1ull << 19)) {
+            // few long vectors against an inner-indexed vector far beyond L2: slices of it (and of the barcode scale, unless
+            // the mapped values are materialized) staged in LDS
+            const int fstart = fvals_prefix_len(map);
+            bool lazy = false;
+            const double *fv = fvals_wanted(st, cp, map, fstart) ? ensure_fvals(st, cp, map, fstart) : nullptr;
+            if (fv ? slice_walk_chain(map, fstart, lazy) : slice_walk_chain(map, 0, lazy)) {
+                launch_slice_walk<0>(st, cp, map, fv, fstart, lazy, X, ldx, out, ldo, nullptr, nullptr, off_a, rank, off_w, ldw,
+                                     "slice_walk_spmv/short-outer",
+                                     (double)cp.nnz * (fv ? 12.0 : 8.0) + (double)(cp.n_outer + 1) * 8.0 + (double)(cp.n_inner + cp.n_outer) * 8.0);
+                return;
+            }
+        }
         if (st.spmm_path != 1 && cp.nnz >= st.blocked_min_nnz && cp.n_inner >= (1ull << 19)) {
             // the vector does not fit an XCD's L2: walk it in 2 MB slices (base tiles of 1024 positions x ldx x 8 B)
             const uint32_t nb = ensure_bounds(st, cp);
@@ -1798,6 +1964,15 @@ void launch_row_reduce(Storage &st, SparseCopy &cp, const DevMap &map, int mode,
         bool inner_indexed = false;
         for (int i = 0; i < map.n; i++)
             inner_indexed = inner_indexed || (map.ops[i].a && !map.ops[i].a_outer) || (map.ops[i].b && !map.ops[i].b_outer);
+        bool lazy = false;
+        if (inner_indexed && slice_walk_enabled() && cp.n_outer < cp.n_inner && slice_walk_chain(map, 0, lazy) && lazy) {
+            // the barcode scale staged in LDS slice by slice instead of gathered from L2 (see slice_walk_kernel)
+            double *fout = mode == 2 && fvals_wanted(st, cp, map, map.n) ? fvals_claim(st, cp, map, map.n) : nullptr;
+            launch_slice_walk<1>(st, cp, map, nullptr, 0, true, nullptr, 0, out_sum, 1, mode == 2 ? out_sumsq : nullptr, fout, nullptr, 0,
+                                 nullptr, 0, mode == 1 ? "slice_walk_sum" : "slice_walk_moments",
+                                 (double)cp.nnz * (fout ? 16.0 : 8.0) + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_outer * 16.0);
+            return;
+        }
         if (inner_indexed) {
             const uint32_t nb = ensure_bounds(st, cp);
             const uint32_t m = 256; // 256 * 1024 inner positions * 8 B = 2 MB slice of the scale array

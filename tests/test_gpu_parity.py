@@ -1029,3 +1029,47 @@ def test_materialized_map_values_are_bit_identical_and_never_stale(sa, monkeypat
     assert not np.array_equal(mat["dot"], mat["renorm_dot"])
     # the view's chain was not left by a moments pass: its values were computed by the dedicated walk
     assert "materialize_map_values" in names_mat, names_mat
+
+
+@pytest.mark.parametrize("knobs", [{"SCANRS_SLICE_WALK": "1", "SCANRS_MATERIALIZE": "1"}, {"SCANRS_SLICE_WALK": "1", "SCANRS_MATERIALIZE": "0"},
+                                   {"SCANRS_SLICE_WALK": "0", "SCANRS_MATERIALIZE": "1"}, {"SCANRS_SLICE_WALK": "0", "SCANRS_MATERIALIZE": "0"}])
+def test_slice_walk_moments_and_spmv_match_the_oracle(sa, monkeypatch, knobs):
+    """The walk of a few long vectors against barcode-indexed arrays staged slice by slice in LDS (slice_walk_kernel):
+    moments of the mapped values and Ix1 products, with the mapped values lazy or materialized, against the oracle and
+    against the L2-blocked kernels it replaces (SCANRS_SLICE_WALK=0); repeatable bit for bit."""
+    import scipy.sparse as sp
+
+    for k_, v_ in knobs.items():
+        monkeypatch.setenv(k_, v_)
+    rng = np.random.default_rng(21)
+    rows, cols, nnz = 40, 600_000, 6_500_000
+    r = rng.integers(0, rows, size=nnz)
+    r[: nnz // 8] = 7  # one vector far longer than the rest
+    c = rng.integers(0, cols, size=nnz)
+    m = sp.csr_matrix((rng.integers(1, 9, size=nnz).astype(np.uint32), (r, c)), shape=(rows, cols))
+    m.sum_duplicates()
+    m.sort_indices()
+    assert m.nnz > (1 << 22)  # above the blocked kernels' threshold
+    f = rng.random(cols) + 0.5
+    g = sa.AdaptiveMat.from_csmat(rows, cols, sa.CSR, m.indptr, m.indices, m.data)
+    g.profile_enable(True)
+    g.compose_scale_axis(1, f).apply(sa.FN_LOG2_1P)
+    o = so.AdaptiveMat(rows, cols, so.CSR, m.indptr, m.indices, m.data)
+    o = o.compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=1, a=f)).apply(so.OP_LOG2_1P)
+    mean, var = g.mean_var_axis(1)
+    mean_o, var_o = o.mean_var_axis(1)
+    assert_close(mean, mean_o, rtol=1e-12, atol=1e-15)
+    assert_close(var, var_o, rtol=1e-10, atol=1e-15)
+    s_rows = g.sum_axis(1)
+    assert_close(s_rows, o.sum_axis(1), rtol=1e-12, atol=1e-12)
+    u, v = rng.standard_normal((rows, 1)), rng.standard_normal((1, cols))
+    g.set_offset(u, v)
+    lo = so.LowRankOffset(o, u, v)
+    x = rng.standard_normal(cols)
+    y = g.dot(x)
+    assert_close(np.ravel(y), lo.dot(x.reshape(-1, 1)).ravel(), rtol=1e-10, atol=1e-7)
+    assert np.array_equal(y, g.dot(x))
+    m2, v2 = g.mean_var_axis(1)
+    assert np.array_equal(m2, mean) and np.array_equal(v2, var)
+    names = set(g.profile_get())
+    assert any(n.startswith("slice_walk") for n in names) == (knobs["SCANRS_SLICE_WALK"] == "1"), names
