@@ -25,7 +25,7 @@ def one(pattern):
 def classify(name, grid):
     if "spmm_gather2d_kernel" in name:
         return "spmm_gather2d_kernel<1>/long-outer" if grid > 10_000_000 else "spmm_gather2d_kernel<1>/short-outer"
-    for k in ("gram_tiled_kernel", "gemm_tiled_kernel", "row_reduce2d_kernel<2>", "row_reduce_kernel<2>", "row_reduce_kernel<0>",
+    for k in ("gram_tiled_kernel", "gemm_tiled_kernel", "slice_walk_kernel<1>", "slice_walk_kernel<0>", "row_reduce2d_kernel<2>", "row_reduce_kernel<2>", "row_reduce_kernel<0>",
               "weighted_colsum_partial_kernel", "spmv2d_kernel", "spmv_lds_kernel", "gram_kernel", "gemm_nn_kernel"):
         if k in name:
             return k
