@@ -87,7 +87,7 @@ void read_mtx(const char *path, scanrs_h5_matrix &m) {
             if (a > 0xFFFFFFFFull || b > 0xFFFFFFFFull) fail(SCANRS_ERR_SHAPE, "dimensions must fit in u32 (AdaptiveVec limit)");
             nrow = a;
             ncol = b;
-            const size_t cap = (size_t)std::min<uint64_t>(c, 1ull << 32); // with_capacity: a hint, not a promise
+            const size_t cap = (size_t)std::min<uint64_t>(c, 1ull << 27); // with_capacity: a hint, not a promise (a corrupt header must not reserve gigabytes)
             tr.reserve(cap);
             tc.reserve(cap);
             tv.reserve(cap);
