@@ -237,3 +237,53 @@ def test_h5_matrix_feeds_the_device_path():
     u, s, v = sa.BkSvd().run_pca(a, 3)
     s_ref = np.linalg.svd(dense[keep], compute_uv=False)[:3]
     np.testing.assert_allclose(s, s_ref, rtol=1e-6)
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA_PY), reason="needs the container's h5py to write the files")
+@pytest.mark.parametrize("libver", ["earliest", "latest"])
+def test_random_datasets_written_by_libhdf5(tmp_path, libver):
+    """Differential test: 60 datasets of random type, rank, shape, chunking, filters and resizability per format version,
+    written by libhdf5 and read back element for element."""
+    import subprocess
+
+    f = str(tmp_path / f"rand_{libver}.h5")
+    script = r'''
+import h5py, numpy as np, sys, json
+rng = np.random.default_rng(int(sys.argv[3]))
+dts = ["<i1", "<u1", "<i2", ">i2", "<u2", "<i4", ">i4", "<u4", "<i8", ">i8", "<u8", "<f4", ">f4", "<f8", ">f8"]
+meta = []
+with h5py.File(sys.argv[1], "w", libver=sys.argv[2]) as f:
+    for i in range(60):
+        g = f.require_group(f"g{i // 8}")          # at most 8 links per group (root included): compact link storage in new-style groups
+        dt = np.dtype(dts[int(rng.integers(len(dts)))])
+        rank = int(rng.integers(1, 4))
+        shape = tuple(int(rng.integers(1, [3000, 60, 14][rank - 1])) for _ in range(rank))
+        if dt.kind == "f":
+            a = rng.normal(size=shape).astype(dt)
+        else:
+            info = np.iinfo(dt)
+            a = rng.integers(max(info.min, -2**52), min(info.max, 2**52), size=shape, endpoint=True).astype(dt)
+        kw = {}
+        layout = int(rng.integers(4))
+        if layout >= 1:
+            kw["chunks"] = tuple(int(rng.integers(1, s + 1)) for s in shape)
+            if rng.random() < 0.6: kw["compression"] = "gzip"; kw["compression_opts"] = int(rng.integers(1, 9))
+            if rng.random() < 0.5: kw["shuffle"] = True
+            if rng.random() < 0.3: kw["fletcher32"] = True
+            if layout == 3:                          # one unlimited dimension (extensible array under libver=latest)
+                u = int(rng.integers(rank))
+                kw["maxshape"] = tuple(None if j == u else s + int(rng.integers(0, 3)) for j, s in enumerate(shape))
+        name = f"g{i // 8}/d{i}"
+        f.create_dataset(name, data=a, **kw)
+        meta.append(name)
+        np.save(sys.argv[1] + f".{i}.npy", a.astype(np.float64))
+print(json.dumps(meta))
+'''
+    r = subprocess.run([CONDA_PY, "-c", script, f, libver, "11"], check=True, timeout=600, capture_output=True, text=True)
+    names = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(names) == 60
+    for i, name in enumerate(names):
+        want = np.load(f + f".{i}.npy")
+        got = h5.read_dataset(f, name)
+        assert got.shape == want.shape, name
+        np.testing.assert_array_equal(got, want, err_msg=name)
