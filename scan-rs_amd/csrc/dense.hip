@@ -147,26 +147,28 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const double *__restric
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] = (d4){0, 0, 0, 0};
-    // A staging: thread -> (row i = tid / 2, 8 consecutive k starting at (tid % 2) * 8), written transposed
-    const uint32_t ai = tid >> 1, ak = (tid & 1u) * 8u;
-    const uint64_t arow = r0 + ai;
-    const bool arv = arow < rows;
+    // A staging: thread -> (rows tid / 8 + 32 h, the k pair tid % 8), written transposed. Eight lanes share a row's 128
+    // bytes, so one load instruction touches 8 lines instead of one per lane (the texture path is what the sparse
+    // passes running beside these kernels live on); the transposed LDS stores pay an 8-way bank conflict for it,
+    // ~6 % of the MFMA time of a step.
+    const uint32_t ai = tid >> 3, ak = (tid & 7u) * 2u;
     // B staging: thread -> (k = tid / 16, 8 consecutive columns)
     const uint32_t bk = tid >> 4, bc = (tid & 15u) * 8u;
     d2 av[4], bv[4];
     auto load_block = [&](uint32_t k0) {
-        const double *xr = X + arow * ldx + k0 + ak;
         const uint32_t kb = k0 + bk;
         const double *wr = W + (size_t)kb * ldw + j0 + bc;
+        const uint32_t kk = k0 + ak;
 #pragma unroll
         for (int h = 0; h < 4; h++) {
-            const uint32_t kk = k0 + ak + 2u * h;
+            const uint64_t arow = r0 + ai + 32u * h;
             av[h] = (d2){0.0, 0.0};
-            if (arv) {
+            if (arow < rows) {
+                const double *xr = X + arow * ldx + kk;
                 if (kk + 1 < n)
-                    av[h] = *reinterpret_cast<const d2 *>(xr + 2 * h);
+                    av[h] = *reinterpret_cast<const d2 *>(xr);
                 else if (kk < n)
-                    av[h].x = xr[2 * h];
+                    av[h].x = xr[0];
             }
             const uint32_t c = bc + 2u * h;
             bv[h] = (d2){0.0, 0.0};
@@ -181,8 +183,8 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const double *__restric
     auto store_block = [&]() {
 #pragma unroll
         for (int h = 0; h < 4; h++) {
-            As[(ak + 2u * h) * DLD + ai] = av[h].x;
-            As[(ak + 2u * h + 1u) * DLD + ai] = av[h].y;
+            As[ak * DLD + ai + 32u * h] = av[h].x;
+            As[(ak + 1u) * DLD + ai + 32u * h] = av[h].y;
             *reinterpret_cast<d2 *>(&Bs[bk * DLD + bc + 2u * h]) = bv[h];
         }
     };
@@ -208,6 +210,101 @@ __global__ __launch_bounds__(256) void gemm_tiled_kernel(const double *__restric
 #pragma unroll
             for (int nj = 0; nj < 4; nj++) {
                 const uint32_t col = j0 + wj * 64 + nj * 16 + li;
+                if (col >= m) continue;
+                double r = alpha * acc[mi][nj][reg];
+                if (beta != 0.0) r = fma(beta, Cin[row * ldc + col], r);
+                Out[row * ldo + col] = r;
+            }
+        }
+}
+
+// Narrow results (m <= 64 columns: the Ritz factors U = T W, 10^6 x 500 -> 50): a 128-column tile would spend 61 % of
+// its MFMAs on padding. Here the workgroup tile is 256 rows x 64 columns, each of the 4 waves owning 64 rows x 64 columns
+// (the same 4 x 4 MFMA tiles per wave); LDS images [k][256 + 16] and [k][64 + 16] keep the bank property of DLD.
+constexpr uint32_t SK_R = 256, SK_C = 64, SK_ALD = 272, SK_BLD = 80;
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const double *__restrict__ X, uint32_t ldx, uint32_t n,
+                                                          const double *__restrict__ W, uint32_t ldw, uint32_t m, uint64_t rows,
+                                                          double alpha, double beta, const double *Cin, uint32_t ldc,
+                                                          double *Out, uint32_t ldo) {
+    __shared__ double As[DK * SK_ALD];
+    __shared__ double Bs[DK * SK_BLD];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint32_t li = lane & 15u, lk = lane >> 4;
+    const uint64_t r0 = (uint64_t)blockIdx.x * SK_R;
+    const uint32_t j0 = blockIdx.y * SK_C;
+    d4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = (d4){0, 0, 0, 0};
+    // A staging: thread -> (rows tid / 8 + 32 h, the k pair tid % 8): eight lanes share a row's 128 bytes (see gemm_tiled_kernel)
+    const uint32_t ai = tid >> 3, ak = (tid & 7u) * 2u;
+    // B staging: thread -> (k = tid / 16, 4 consecutive columns)
+    const uint32_t bk = tid >> 4, bc = (tid & 15u) * 4u;
+    d2 av[8];
+    double bv[4];
+    auto load_block = [&](uint32_t k0) {
+        const uint32_t kk = k0 + ak;
+#pragma unroll
+        for (int h = 0; h < 8; h++) {
+            const uint64_t arow = r0 + ai + 32u * h;
+            av[h] = (d2){0.0, 0.0};
+            if (arow < rows) {
+                const double *xr = X + arow * ldx + kk;
+                if (kk + 1 < n)
+                    av[h] = *reinterpret_cast<const d2 *>(xr);
+                else if (kk < n)
+                    av[h].x = xr[0];
+            }
+        }
+        const uint32_t kb = k0 + bk;
+        const double *wr = W + (size_t)kb * ldw + j0 + bc;
+#pragma unroll
+        for (int h = 0; h < 4; h++) bv[h] = (kb < n && j0 + bc + h < m) ? wr[h] : 0.0;
+    };
+    auto store_block = [&]() {
+#pragma unroll
+        for (int h = 0; h < 8; h++) {
+            As[ak * SK_ALD + ai + 32u * h] = av[h].x;
+            As[(ak + 1u) * SK_ALD + ai + 32u * h] = av[h].y;
+        }
+#pragma unroll
+        for (int h = 0; h < 4; h++) Bs[bk * SK_BLD + bc + h] = bv[h];
+    };
+    if (n > 0) {
+        load_block(0);
+        store_block();
+    }
+    __syncthreads();
+    for (uint32_t k0 = 0; k0 < n; k0 += DK) {
+        const bool more = k0 + DK < n;
+        if (more) load_block(k0 + DK);
+#pragma unroll
+        for (uint32_t kk = 0; kk < DK / 4; kk++) {
+            double a[4], b[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                a[t] = As[(kk * 4 + lk) * SK_ALD + w * 64 + t * 16 + li];
+                b[t] = Bs[(kk * 4 + lk) * SK_BLD + t * 16 + li];
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                for (int nj = 0; nj < 4; nj++) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) store_block();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const uint64_t row = r0 + w * 64 + mi * 16 + lk + 4 * reg;
+            if (row >= rows) continue;
+#pragma unroll
+            for (int nj = 0; nj < 4; nj++) {
+                const uint32_t col = j0 + nj * 16 + li;
                 if (col >= m) continue;
                 double r = alpha * acc[mi][nj][reg];
                 if (beta != 0.0) r = fma(beta, Cin[row * ldc + col], r);
@@ -251,6 +348,14 @@ void launch_gram_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, c
 
 void launch_gemm_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *W, uint32_t ldw, uint32_t m,
                        uint64_t rows, double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo) {
+    if ((m - 1u) % DT < SK_C) { // the last (or only) 128-column tile would be at most half full
+        if (st.prof.on) st.prof.begin(st.stream, "gemm_skinny_mfma_f64", (double)rows * (n + m) * 8.0 + (double)n * m * 8.0);
+        hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)((rows + SK_R - 1) / SK_R), (m + SK_C - 1) / SK_C), dim3(256), 0, st.stream, X,
+                           ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
+        if (st.prof.on) st.prof.end(st.stream);
+        SCANRS_HIP(hipGetLastError());
+        return;
+    }
     if (st.prof.on) st.prof.begin(st.stream, "gemm_tiled_mfma_f64", (double)rows * (n + m) * 8.0 + (double)n * m * 8.0);
     if (trace_on()) fprintf(stderr, "[scanrs trace] gemm_tiled rows=%llu n=%u m=%u ldx=%u ldw=%u beta=%g\n", (unsigned long long)rows, n, m, ldx, ldw, beta);
     hipLaunchKernelGGL(gemm_tiled_kernel, dim3((unsigned)((rows + DT - 1) / DT), (m + DT - 1) / DT), dim3(256), 0, st.stream, X, ldx,
