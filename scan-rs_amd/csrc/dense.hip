@@ -57,17 +57,18 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const double *__restric
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] = (d4){0, 0, 0, 0};
-    // staging map: thread -> (k = tid / 16, 8 consecutive columns starting at (tid % 16) * 8).
     // Register-staged pipeline: the global loads of block t+1 are issued before the MFMAs of block t and
     // written to LDS after them, so their latency hides under 64 MFMAs per wave.
-    const uint32_t sk = tid >> 4, sc = (tid & 15u) * 8u;
+    // staging map: wave w, trip h -> panel row 4 w + h; lane -> column pair 2 lane: one load instruction reads one
+    // row's 1 KB slice as 64 consecutive 16-byte pieces (8 lines; the older map spread 4 rows over 32 half-used lines)
+    const uint32_t sc = lane * 2u;
     d2 xa[4], yb[4];
     auto load_block = [&](uint64_t r) {
-        const uint64_t gr = r + sk;
-        const bool rv = gr < r1;
 #pragma unroll
         for (int h = 0; h < 4; h++) {
-            const uint32_t c = sc + 2u * h;
+            const uint64_t gr = r + w * 4u + h;
+            const bool rv = gr < r1;
+            const uint32_t c = sc;
             xa[h] = (d2){0.0, 0.0};
             yb[h] = (d2){0.0, 0.0};
             if (rv) {
@@ -87,9 +88,8 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const double *__restric
     auto store_block = [&]() {
 #pragma unroll
         for (int h = 0; h < 4; h++) {
-            const uint32_t c = sc + 2u * h;
-            *reinterpret_cast<d2 *>(&As[sk * DLD + c]) = xa[h];
-            *reinterpret_cast<d2 *>(&Bs[sk * DLD + c]) = yb[h];
+            *reinterpret_cast<d2 *>(&As[(w * 4u + h) * DLD + sc]) = xa[h];
+            *reinterpret_cast<d2 *>(&Bs[(w * 4u + h) * DLD + sc]) = yb[h];
         }
     };
     if (r0 < r1) {
