@@ -358,6 +358,12 @@ const char *scanrs_h5_matrix_string(const scanrs_h5_matrix *m, int what, uint64_
 /* indices (in the file's feature order) of the features that were filtered out — the BTreeSet the reference returns */
 int scanrs_h5_matrix_removed(const scanrs_h5_matrix *m, const uint64_t **removed, uint64_t *n);
 
+/* One call from a file to the device handle: `read_adaptive_csr_matrix` (or `load_mtx` when `path` does not end in
+ * ".h5") followed by scanrs_mat_create on the CSR arrays. `meta` (optional) receives the host-side handle with the
+ * barcodes / feature tables / removed set; free it with scanrs_h5_matrix_free. Needs a gfx950 device. */
+int scanrs_mat_create_from_file(const char *path, const char *retain_feature_like, int64_t shrink_row, scanrs_mat **out,
+                                scanrs_h5_matrix **meta);
+
 /* `load_mtx` (scan-rs/src/mtx.rs:10-51): gzipped MatrixMarket coordinate file -> CSR arrays in the same handle type
  * (no string tables; scanrs_h5_matrix_arrays / _shape / _free apply). Comments '%', header "NROW NCOL NNZ", 1-based
  * "ROW COL VAL" triplets with u32 values, duplicates summed, indices ascending inside a row (TriMat::to_csr). */

@@ -824,5 +824,5 @@ EXPORTED_SYMBOLS = [
     "scanrs_h5_read_csc_matrix", "scanrs_h5_read_adaptive_csr_matrix", "scanrs_h5_read_matrix_metadata", "scanrs_h5_matrix_free",
     "scanrs_h5_matrix_shape", "scanrs_h5_matrix_arrays", "scanrs_h5_matrix_n_strings", "scanrs_h5_matrix_string", "scanrs_h5_matrix_removed",
     "scanrs_h5_read_umi_counts", "scanrs_h5_get_clustering_keys", "scanrs_h5_get_clustering", "scanrs_h5_get_differential_expression",
-    "scanrs_h5_read_f64", "scanrs_h5_read_strings", "scanrs_h5_member_names", "scanrs_mtx_read",
+    "scanrs_h5_read_f64", "scanrs_h5_read_strings", "scanrs_h5_member_names", "scanrs_mtx_read", "scanrs_mat_create_from_file",
 ]

@@ -1082,6 +1082,29 @@ int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uin
         *n = i;
     });
 }
+int scanrs_mat_create_from_file(const char *path, const char *retain_feature_like, int64_t shrink_row, scanrs_mat **out,
+                                scanrs_h5_matrix **meta) {
+    if (out) *out = nullptr;
+    if (meta) *meta = nullptr;
+    if (!path || !out) return guard([&] { fail(SCANRS_ERR_ARGUMENT, "null argument"); });
+    const size_t n = strlen(path);
+    const bool is_h5 = n > 3 && strcmp(path + n - 3, ".h5") == 0;
+    scanrs_h5_matrix *h = nullptr;
+    int rc = is_h5 ? scanrs_h5_read_adaptive_csr_matrix(path, retain_feature_like, shrink_row, &h) : scanrs_mtx_read(path, &h);
+    if (rc != SCANRS_OK) return rc;
+    uint64_t rows = 0, cols = 0, nnz = 0;
+    int storage = 0;
+    const uint64_t *ip = nullptr;
+    const uint32_t *ix = nullptr, *vv = nullptr;
+    (void)scanrs_h5_matrix_shape(h, &rows, &cols, &nnz, &storage);
+    (void)scanrs_h5_matrix_arrays(h, &ip, &ix, &vv);
+    rc = scanrs_mat_create(rows, cols, storage, ip, ix, vv, out);
+    if (rc == SCANRS_OK && meta)
+        *meta = h;
+    else
+        scanrs_h5_matrix_free(h);
+    return rc;
+}
 int scanrs_mat_set_spmm_path(scanrs_mat *m, int path) {
     return guard([&] {
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");

@@ -168,3 +168,12 @@ def read_strings(path: str, dataset: str) -> List[str]:
 def member_names(path: str, group: str = "/") -> List[str]:
     p, g = str(path).encode(), group.encode()
     return _packed(lambda buf, cap, n, nb: _lib.scanrs_h5_member_names(p, g, buf, cap, n, nb))
+
+
+def mat_from_file(path: str, retain_feature_like: Optional[str] = None, shrink_row: Optional[int] = None):
+    """File -> device handle in one call (`scanrs_mat_create_from_file`): a 10x `.h5` through `read_adaptive_csr_matrix`,
+    anything else through `load_mtx`. Returns (AdaptiveMat, FeatureBarcodeMatrix metadata without the arrays' copies)."""
+    h, meta = ctypes.c_void_p(), ctypes.c_void_p()
+    _check(_lib.scanrs_mat_create_from_file(str(path).encode(), _opt(retain_feature_like),
+                                            ctypes.c_int64(-1 if shrink_row is None else int(shrink_row)), ctypes.byref(h), ctypes.byref(meta)))
+    return AdaptiveMat(h.value), _take(meta)

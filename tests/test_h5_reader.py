@@ -287,3 +287,22 @@ print(json.dumps(meta))
         got = h5.read_dataset(f, name)
         assert got.shape == want.shape, name
         np.testing.assert_array_equal(got, want, err_msg=name)
+
+
+@pytest.mark.gpu
+def test_file_to_device_in_one_call(tmp_path):
+    """scanrs_mat_create_from_file: .h5 through read_adaptive_csr_matrix, anything else through load_mtx."""
+    import gzip
+
+    a, meta = h5.mat_from_file(p("tiny_10x.h5"), "Gene Expression", 1)
+    dense = np.array(T["dense"], dtype=np.float64)
+    keep = [j for j in range(T["n_features"]) if j not in meta.removed_features]
+    assert tuple(a.shape()) == (len(keep), T["n_cells"]) and meta.feature_ids == [T["feature_ids"][j] for j in keep]
+    np.testing.assert_array_equal(a.to_dense(), dense[keep])
+    lines = ["%%MatrixMarket matrix coordinate integer general", "3 4 3", "1 1 5", "3 4 2", "1 1 1"]
+    f = tmp_path / "m.mtx.gz"
+    f.write_bytes(gzip.compress(("\n".join(lines) + "\n").encode()))
+    b, _ = h5.mat_from_file(str(f))
+    np.testing.assert_array_equal(b.to_dense(), [[6, 0, 0, 0], [0, 0, 0, 0], [0, 0, 0, 2]])
+    with pytest.raises(sa.ScanrsError, match="unable to open file"):
+        h5.mat_from_file(str(tmp_path / "nope.h5"))
