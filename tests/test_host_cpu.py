@@ -176,6 +176,23 @@ def test_world2_sharded_c_abi_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
+def test_world4_sharded_c_abi_on_one_gpu(tmp_path):
+    """Four ranks (four processes sharing the box's one GPU, exchange through the host hook): 300 cells per shard."""
+    vs = _run_world2("gpu", tmp_path, world=4)
+    assert len({v["target_umi"] for v in vs}) == 1
+    for v in vs:
+        assert v["v_rows"] == 300
+        assert v["s_rel"] < 1e-8 and v["u_abs"] < 1e-6 and v["v_abs"] < 1e-6, v
+        assert v["rand_s_rel"] < 1e-8 and v["rand_u_abs"] < 1e-6 and v["rand_v_abs"] < 1e-6, v
+
+
+def test_world4_sharded_schedule_gloo(tmp_path):
+    for v in _run_world2("cpu", tmp_path, world=4):
+        assert v["hook_u64_ok"]
+        assert v["s_rel"] < 1e-9 and v["u_abs"] < 1e-7 and v["v_abs"] < 1e-7, v
+
+
+@pytest.mark.gpu
 def test_rccl_hook_serves_the_exchange_steps(tmp_path):
     """backend "nccl" (RCCL) on the library's own device buffers, one rank per visible GPU (1 on the test box)."""
     import torch
