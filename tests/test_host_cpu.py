@@ -238,6 +238,19 @@ def test_bench_two_ranks_equal_one_rank(tmp_path):
         assert d["config"]["host_delivered_cells_per_s"] > 0 and d["config"]["v_col_norm_err_device_result"] < 1e-9
 
 
+@pytest.mark.gpu
+def test_bench_eight_ranks_equal_one_rank(tmp_path):
+    """The driver's widest command form, `python bench.py --gpus 8`, end to end on the one GPU of the test box (eight
+    ranks sharing it, host-hook exchange): eight nnz-balanced shards, one JSON line, the same singular values."""
+    one = _bench_line({}, [], tmp_path, 1)
+    eight = _bench_line({"SCANRS_BENCH_SHARED_GPU": "1"}, [], tmp_path, 8)
+    assert eight["n_gpus"] == 8 and len(eight["config"]["per_rank_nnz"]) == 8
+    assert sum(eight["config"]["per_rank_nnz"]) == one["config"]["nnz"]
+    assert max(eight["config"]["per_rank_nnz"]) - min(eight["config"]["per_rank_nnz"]) < 0.02 * one["config"]["nnz"] / 8  # balanced by nonzeros
+    a, b = np.array(one["config"]["sigma_top3"]), np.array(eight["config"]["sigma_top3"])
+    assert np.max(np.abs(a - b) / a) < 1e-9
+
+
 def test_host_sym_eig_topk(sa):
     rng = np.random.default_rng(5)
     for n, k in ((1, 1), (2, 2), (7, 3), (64, 64), (200, 20)):
