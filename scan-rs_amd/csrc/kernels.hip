@@ -1769,11 +1769,8 @@ static bool launch_spmm_2d_persist(Storage &st, SparseCopy &cp, const DevMap &ma
     const uint32_t n_chunks = (l + 127u) / 128u;
     uint32_t lc = (l + n_chunks - 1u) / n_chunks;
     lc = (lc + 1u) & ~1u;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SCANRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_gather2d_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        attr_set = true;
-    }
+    // per device, and handles of one process may live on different devices: set on every use (a cheap call)
+    SCANRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_gather2d_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     for (uint32_t c0 = 0; c0 < l; c0 += lc) { // eligibility of every column chunk before anything is launched
         const uint32_t lw = std::min(lc, l - c0);
         const uint32_t m = std::max(1u, (uint32_t)(st.persist_tile_bytes / ((size_t)(1u << BT_SHIFT) * lw * 8)));
