@@ -144,6 +144,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    def dbg(msg):  # SCANRS_BENCH_DEBUG=1: stage markers on stderr (where does a multi-rank run stop?)
+        if os.environ.get("SCANRS_BENCH_DEBUG"):
+            print(f"[bench rank {rank}] {msg} t={time.time():.3f}", file=sys.stderr, flush=True)
+
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # SCANRS_BENCH_SHARED_GPU=1 (tests only): every rank uses GPU 0 and the exchange steps go through the host hook on
     # gloo (RCCL cannot put two ranks on one device), so the N > 1 flow runs end to end on a 1-GPU box. Never set by the driver.
@@ -178,7 +183,9 @@ def main():
 
     lo, hi = shard_bounds(args.cells, world)[rank]
     t0 = time.time()
+    dbg("datagen")
     indptr, indices, values = synth_counts_torch(args.cells, args.genes, args.density, args.seed, dev, lo, hi)
+    dbg("datagen done")
     if world > 1:
         # scanrs_plan_shards on the global per-cell counts (every rank holds the counts of its equal-count range)
         counts = (indptr[1:] - indptr[:-1]).cpu()
@@ -186,7 +193,9 @@ def main():
         padded = torch.zeros(per, dtype=torch.int64)
         padded[: counts.shape[0]] = counts
         gathered = [torch.zeros(per, dtype=torch.int64) for _ in range(world)]
+        dbg("all_gather counts")
         dist.all_gather(gathered, padded)
+        dbg("all_gather done")
         allc = torch.cat(gathered)[: args.cells].numpy()
         gip = np.zeros(args.cells + 1, dtype=np.uint64)
         np.cumsum(allc, out=gip[1:])
@@ -203,6 +212,7 @@ def main():
     n_local = hi - lo
 
     # genes x cells (Cell Ranger orientation), stored cell-major = CSC
+    dbg(f"shard [{lo}, {hi}) nnz {nnz_local}: create handle")
     t0 = time.time()
     mat = sa.AdaptiveMat.from_device(args.genes, n_local, sa.CSC, indptr.data_ptr(), indices.data_ptr(), values.data_ptr())
     del indptr, indices, values
@@ -250,6 +260,7 @@ def main():
             mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev, group=nccl_group))
             transport = f"torch.distributed RCCL group through the library's all-reduce hook (library communicator failed: {comm_err or 'on another rank'})"
 
+    dbg(f"transport: {transport}")
     if args.f32_panels:
         mat.set_panel_precision(1)
     if args.spmm_path:
