@@ -757,7 +757,8 @@ __global__ __launch_bounds__(1024) void spmv_lds_kernel(const uint64_t *__restri
                                                         uint64_t rows_per_block, DevMap map, const double *__restrict__ X, uint32_t ldx,
                                                         uint64_t n_inner, double *__restrict__ out, uint32_t ldo,
                                                         const double *__restrict__ off_a, uint32_t rank,
-                                                        const double *__restrict__ off_w, uint32_t ldw) {
+                                                        const double *__restrict__ off_w, uint32_t ldw,
+                                                        const double *__restrict__ fvals, int fstart) {
     extern __shared__ double xs[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_block, r1 = min(n_outer, r0 + rows_per_block);
@@ -777,6 +778,7 @@ __global__ __launch_bounds__(1024) void spmv_lds_kernel(const uint64_t *__restri
             double s0 = 0.0;
             for (uint32_t q0 = lane; q0 < len; q0 += 64u * SCAN_U) {
                 uint32_t g[SCAN_U], vv[SCAN_U];
+                double fv[SCAN_U];
                 bool ok[SCAN_U];
 #pragma unroll
                 for (int u = 0; u < SCAN_U; u++) {
@@ -784,11 +786,14 @@ __global__ __launch_bounds__(1024) void spmv_lds_kernel(const uint64_t *__restri
                     ok[u] = q < len;
                     const uint64_t e = base + (ok[u] ? q : len - 1u);
                     g[u] = indices[e];
-                    vv[u] = values[e];
+                    if (fvals) // the mapped values, materialized: no logarithm per nonzero per product
+                        fv[u] = fvals[e];
+                    else
+                        vv[u] = values[e];
                 }
 #pragma unroll
                 for (int u = 0; u < SCAN_U; u++) {
-                    const double f = eval_map(map, rm, vv[u], (uint32_t)row, g[u]);
+                    const double f = fvals ? eval_map_from(map, fstart, fv[u], (uint32_t)row, g[u]) : eval_map(map, rm, vv[u], (uint32_t)row, g[u]);
                     s0 = ok[u] ? fma(f, xs[g[u] - (uint32_t)g0], s0) : s0;
                 }
             }
@@ -1622,6 +1627,21 @@ static bool fvals_wanted(Storage &st, const SparseCopy &cp, const DevMap &map, i
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
     return free_b > cp.nnz * 8 + (size_t(8) << 30); // leave room for the solver's panels
 }
+// the same store on a copy of any shape when the reason is arithmetic, not a gather: the chain holds a logarithm (or a
+// residual map) and the caller is a product that runs many times on a bandwidth budget (the Ix1 products of IRLBA)
+static bool fvals_wanted_for_alu(Storage &st, const SparseCopy &cp, const DevMap &map, int n) {
+    if (!st.materialize || n <= 0 || n > MAX_OPS || cp.nnz < st.blocked_min_nnz) return false;
+    bool heavy = false;
+    for (int i = 0; i < n; i++) {
+        const int k = map.ops[i].kind;
+        heavy = heavy || k == OP_LN_1P || k == OP_LOG2_1P || k == OP_LOG10_1P || k == OP_BINOM_DEV || k == OP_BINOM_PEARSON;
+    }
+    if (!heavy) return false;
+    if (cp.fvals.n == cp.nnz) return true;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    return free_b > cp.nnz * 8 + (size_t(8) << 30);
+}
 static bool fvals_match(const SparseCopy &cp, const DevMap &map, int n) {
     if (cp.fsig_n != n || cp.fvals.n != cp.nnz) return false;
     for (int i = 0; i < n; i++)
@@ -1923,9 +1943,12 @@ void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const doubl
             (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
             const uint32_t n_blocks = (uint32_t)std::min<uint64_t>((uint64_t)n_cu * 4u, (cp.n_outer + 15) / 16);
             const uint64_t rows_per_block = (cp.n_outer + n_blocks - 1) / n_blocks;
-            ProfScope ps(st, "spmv_lds_kernel/long-outer", (double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)(cp.n_inner + cp.n_outer) * 8.0);
+            const int fstart = fvals_prefix_len(map);
+            const double *fv = fvals_wanted_for_alu(st, cp, map, fstart) ? ensure_fvals(st, cp, map, fstart) : nullptr;
+            ProfScope ps(st, "spmv_lds_kernel/long-outer", (double)cp.nnz * (fv ? 12.0 : 8.0) + (double)(cp.n_outer + 1) * 8.0 + (double)(cp.n_inner + cp.n_outer) * 8.0);
             hipLaunchKernelGGL(spmv_lds_kernel, dim3(n_blocks), dim3(1024), shmem, st.stream, cp.indptr.p, cp.indices.p, cp.values.p, cp.bounds.p, nb,
-                               tiles_per_part, n_parts, cp.n_outer, rows_per_block, map, X, ldx, cp.n_inner, out, ldo, off_a, rank, off_w, ldw);
+                               tiles_per_part, n_parts, cp.n_outer, rows_per_block, map, X, ldx, cp.n_inner, out, ldo, off_a, rank, off_w, ldw, fv,
+                               fstart);
             SCANRS_HIP(hipGetLastError());
             return;
         }
