@@ -271,7 +271,7 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
     // stream that produced a device-resident input) stay ordered with the kernels launched here
     SCANRS_HIP(hipStreamCreate(&st->stream));
     st->scratch.stream = st->stream;
-    if (const char *e = getenv("SCANRS_L2_TILE_KB")) { // tuning knob for the L2-blocked gather (default 3072)
+    if (const char *e = getenv("SCANRS_L2_TILE_KB")) { // tuning knob for the L2-blocked gather (default 3584)
         const long kb = atol(e);
         if (kb >= 64) st->l2_tile_bytes = (size_t)kb << 10;
     }

@@ -216,7 +216,7 @@ struct Storage {
     } pca_dev;
     int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 L2-blocked gather, 3 LDS-staged tiles (quad layout)
     int panel_precision = 0;              // 0: f64 panels (default); 1: gathered panels rounded to f32, f64 sums (opt-in)
-    size_t l2_tile_bytes = 3u << 20;      // panel slice per step of the L2-blocked gather (4 MB L2 per XCD)
+    size_t l2_tile_bytes = 3584u << 10;   // panel slice per step of the L2-blocked gather (4 MB L2 per XCD): whole 1024-row base tiles up to 3.5 MB — 4 tiles (3.2 MB) at 100 columns, 3 (2.9 MB) at 122; measured 40.55 / 39.71 ms per pass against 41.30 / 40.23 with 3 tiles and 40.86 / 39.61 with 5, and 4 tiles of 122 columns (3.9 MB) lose 1.8 ms
     int spmm_order = 1;                   // L2-blocked gather: launch outer vectors longest first: 0 never, 1 auto, 2 always (SCANRS_SPMM_ORDER)
     uint32_t hot_segment = 512;           // ... and give a workgroup to vectors with >= this many nonzeros per step (0 = never)
     uint64_t blocked_min_nnz = 1ull << 22; // auto: matrices below this stay on the plain gather kernel
