@@ -134,6 +134,8 @@ Storage::~Storage() {
     }
 }
 hipStream_t Storage::aux() {
+    static const bool no_overlap = getenv("SCANRS_NO_OVERLAP") && atoi(getenv("SCANRS_NO_OVERLAP")) != 0; // experiment knob
+    if (no_overlap) return stream;
     if (!aux_stream) SCANRS_HIP(hipStreamCreate(&aux_stream));
     return aux_stream;
 }
