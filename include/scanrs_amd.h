@@ -308,10 +308,22 @@ int scanrs_profile_reset(scanrs_mat *m);
 /* Fills up to `cap` entries, writes the total count to *n. */
 int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uint32_t *n);
 /* Which f64 product kernel serves this handle (and its views): 0 = auto (L2-blocked gather for large matrices and
- * panels of 16+ columns, plain gather otherwise), 1 = plain gather, 2 = L2-blocked gather, 3 = LDS-staged panel tiles over
- * a tile-bucketed second layout of the matrix (panels of 16..104 columns; built on first use; other widths take path 2).
+ * panels of 16+ columns, plain gather otherwise), 1 = plain gather, 2 = L2-blocked gather, 3 = hybrid: LDS-staged panel
+ * tiles over a tile-bucketed layout of the matrix plus the L2-blocked gather over the nonzeros that overflow it, run side
+ * by side (panels of 16..104 columns; the layout is built on first use under a given map; other widths take path 2).
  * All are HIP kernels; results agree to rounding. */
 int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
+/* Tuning options of a handle (shared by its views); defaults are the measured optimum on MI355X.
+ *   "tile_k" (4)        hybrid product: record positions per (outer vector, panel tile): 2, 3 or 4
+ *   "tile_s" (32)       hybrid product: outer vectors per wave (32; 28 with tile_k 4)
+ *   "tile_overlap" (1)  hybrid product: the overflow gather runs beside the tile kernel (0: after it; measurement only)
+ *   "l2_tile_kb" (3584) panel slice per step of the L2-blocked gather
+ *   "spmm_order" (1)    L2-blocked gather launch order: 0 storage order, 1 longest vectors first when a launch is a few
+ *                       rounds of waves, 2 always longest first
+ *   "hot_segment" (512) nonzeros per step from which a vector gets a whole workgroup (0 = never)
+ *   "materialize" (1)   keep the values of the map prefix per nonzero on the copy with few, long outer vectors
+ * Unknown keys return SCANRS_ERR_ARGUMENT. */
+int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value);
 /* Arithmetic of the large sparse products: 0 (default) = f64 throughout, the reference's arithmetic; 1 = opt-in fast
  * mode: the dense panel is rounded to f32 before it is gathered (half the on-chip bytes per nonzero), products and
  * sums stay f64. Singular values / loadings then agree with the f64 path to ~1e-7 relative, not to rounding. */

@@ -128,6 +128,12 @@ Storage::~Storage() {
         (void)hipStreamSynchronize(aux_stream);
         (void)hipStreamDestroy(aux_stream);
     }
+    if (ov_stream) {
+        (void)hipStreamSynchronize(ov_stream);
+        (void)hipStreamDestroy(ov_stream);
+    }
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_ov) (void)hipEventDestroy(ev_ov);
     if (stream) {
         (void)hipStreamSynchronize(stream);
         (void)hipStreamDestroy(stream);
@@ -138,6 +144,17 @@ hipStream_t Storage::aux() {
     if (no_overlap) return stream;
     if (!aux_stream) SCANRS_HIP(hipStreamCreate(&aux_stream));
     return aux_stream;
+}
+hipStream_t Storage::ov() {
+    if (!ov_stream) {
+        // lowest priority: the persistent tile kernel's workgroups are placed first, the gather fills what is left of a CU
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        SCANRS_HIP(hipStreamCreateWithPriority(&ov_stream, hipStreamNonBlocking, least));
+        SCANRS_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+        SCANRS_HIP(hipEventCreateWithFlags(&ev_ov, hipEventDisableTiming));
+    }
+    return ov_stream;
 }
 SparseCopy &Storage::copy_with_outer_rows(bool outer_rows) {
     const bool primary_outer_rows = storage == SCANRS_CSR;
@@ -279,9 +296,6 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
     }
     if (const char *e = getenv("SCANRS_SPMM_ORDER")) st->spmm_order = atoi(e);
     if (const char *e = getenv("SCANRS_MATERIALIZE")) st->materialize = atoi(e);
-    if (const char *e = getenv("SCANRS_SPMM_PERSIST")) st->persist = atoi(e);
-    if (const char *e = getenv("SCANRS_PERSIST_SLACK")) st->persist_slack = (uint32_t)std::max(0, atoi(e));
-    if (const char *e = getenv("SCANRS_PERSIST_TILE_KB")) st->persist_tile_bytes = (size_t)std::max(64, atoi(e)) << 10;
     if (const char *e = getenv("SCANRS_HOT_SEGMENT")) st->hot_segment = (uint32_t)std::max(0, atoi(e));
     SparseCopy &cp = st->primary;
     cp.n_outer = storage == SCANRS_CSR ? rows : cols;
@@ -1111,8 +1125,32 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path) {
     return guard([&] {
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
         if (path < 0 || path > 3)
-            fail(SCANRS_ERR_ARGUMENT, "path must be 0 (auto), 1 (plain gather), 2 (L2-blocked gather) or 3 (LDS-staged tiles)");
+            fail(SCANRS_ERR_ARGUMENT, "path must be 0 (auto), 1 (plain gather), 2 (L2-blocked gather) or 3 (LDS-staged tiles + gather)");
         m->st->spmm_path = path;
+    });
+}
+int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
+    return guard([&] {
+        if (!m || !key) fail(SCANRS_ERR_ARGUMENT, "null handle or key");
+        Storage &st = *m->st;
+        const std::string k(key);
+        if (k == "tile_k" || k == "tile_s") {
+            const uint32_t K = k == "tile_k" ? (uint32_t)value : st.tile_k, S = k == "tile_s" ? (uint32_t)value : st.tile_s;
+            if (k == "tile_k") st.tile_k = K; else st.tile_s = S; // validated as a pair when the product runs
+        } else if (k == "tile_overlap") {
+            st.tile_overlap = value != 0.0;
+        } else if (k == "l2_tile_kb") {
+            if (value < 64) fail(SCANRS_ERR_ARGUMENT, "l2_tile_kb must be >= 64");
+            st.l2_tile_bytes = (size_t)value << 10;
+        } else if (k == "spmm_order") {
+            st.spmm_order = (int)value;
+        } else if (k == "materialize") {
+            st.materialize = value != 0.0;
+        } else if (k == "hot_segment") {
+            st.hot_segment = (uint32_t)std::max(0.0, value);
+        } else {
+            fail(SCANRS_ERR_ARGUMENT, "unknown option '%s'", key);
+        }
     });
 }
 int scanrs_mat_set_panel_precision(scanrs_mat *m, int precision) {

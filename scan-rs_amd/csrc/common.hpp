@@ -140,9 +140,10 @@ struct MultiRow {
     uint32_t _pad;
 };
 
-// quad.hip: the tile-bucketed second layout of an orientation that the LDS-staged product walks
-struct QuadLayout;
-void quad_layout_free(QuadLayout *q);
+// tiles.hip: the split of an orientation (under one map) into fixed record positions per (outer vector, panel tile) and an
+// overflow matrix — what the hybrid LDS-tile + gather product walks
+struct TileLayout;
+void tile_layout_free(TileLayout *t);
 
 // A compressed orientation: n_outer vectors over n_inner positions.
 struct SparseCopy {
@@ -157,7 +158,7 @@ struct SparseCopy {
     // on the host (how many vectors are "hot" for a given step count is a binary search)
     DevBuf<uint32_t> order;
     std::vector<uint32_t> sorted_len;
-    std::shared_ptr<QuadLayout> quad; // built on first use of the LDS-staged product (spmm path 3)
+    std::shared_ptr<TileLayout> tiles; // built on first use of the hybrid tile product under a given map (tiles.hip)
     // Materialized map values (kernels.hip, "materialized prefix"): f64 per nonzero, in this copy's order, of the first
     // `fsig_n` links of a map chain — kept for the copy with few, long outer vectors, where evaluating the chain costs a
     // scattered 8-byte gather per nonzero per product (the per-barcode scale while walking a gene's vector).
@@ -188,6 +189,9 @@ struct Storage {
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr; // small dense work that overlaps a sparse pass (svd_bk's cross-block orthogonalisation)
     hipStream_t aux();
+    hipStream_t ov_stream = nullptr; // the gather over the overflow part of a tile layout runs here, beside the tile kernel (tiles.hip)
+    hipEvent_t ev_in = nullptr, ev_ov = nullptr;
+    hipStream_t ov();
     Scratch scratch;
     // GF(2) jump tables of the device-side seeded-panel generator (solver.cpp / omega_jump_kernel)
     DevBuf<uint64_t> jump_tab;
@@ -214,18 +218,15 @@ struct Storage {
         uint32_t ld_u = 0, ld_v = 0, k = 0;
         uint64_t rows_u = 0, rows_v = 0;
     } pca_dev;
-    int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 L2-blocked gather, 3 LDS-staged tiles (quad layout)
+    int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 L2-blocked gather, 3 hybrid: LDS-staged tiles + gather of the overflow (tiles.hip)
+    uint32_t tile_k = 4, tile_s = 32;     // hybrid product: record positions per (outer vector, tile), outer vectors per wave
+    int tile_overlap = 1;                 // hybrid product: 1 = the overflow gather runs beside the tile kernel (own stream); 0 = after it (measurement)
     int panel_precision = 0;              // 0: f64 panels (default); 1: gathered panels rounded to f32, f64 sums (opt-in)
     size_t l2_tile_bytes = 3584u << 10;   // panel slice per step of the L2-blocked gather (4 MB L2 per XCD): whole 1024-row base tiles up to 3.5 MB — 4 tiles (3.2 MB) at 100 columns, 3 (2.9 MB) at 122; measured 40.55 / 39.71 ms per pass against 41.30 / 40.23 with 3 tiles and 40.86 / 39.61 with 5, and 4 tiles of 122 columns (3.9 MB) lose 1.8 ms
     int spmm_order = 1;                   // L2-blocked gather: launch outer vectors longest first: 0 never, 1 auto, 2 always (SCANRS_SPMM_ORDER)
     uint32_t hot_segment = 512;           // ... and give a workgroup to vectors with >= this many nonzeros per step (0 = never)
     uint64_t blocked_min_nnz = 1ull << 22; // auto: matrices below this stay on the plain gather kernel
-    // persistent form of the L2-blocked gather on copies with <= 16 outer vectors per wave of the chip (65536 on MI355X) (kernels.hip, spmm_gather2d_persist_kernel)
     int materialize = 1;                  // keep the map prefix's values per nonzero on the short-outer copy (SCANRS_MATERIALIZE=0: off)
-    int persist = 0;                      // 0 off, 1 on (SCANRS_SPMM_PERSIST)
-    uint32_t persist_slack = 1;           // steps a wave may run ahead of the slowest workgroup (0: never wait)
-    size_t persist_tile_bytes = 3u << 19; // panel slice per step: (slack + 1) slices share a 4 MB L2
-    bool persist_broken = false;          // a product saw the grid fall out of step (wait timed out): multi-launch form from then on
     ~Storage();
     // the copy whose outer dimension is the base matrix's rows (true) or cols (false)
     SparseCopy &copy_with_outer_rows(bool outer_rows);
@@ -288,11 +289,11 @@ void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const doubl
                      double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw);
 void launch_spmm_u32(Storage &st, const SparseCopy &cp, const uint32_t *X, uint32_t ldx, uint32_t l, uint32_t *out,
                      uint32_t ldo);
-// quad.hip
-QuadLayout *quad_layout_build(Storage &st, const SparseCopy &cp);
-bool spmm_quad_ok(const SparseCopy &cp, const DevMap &map, uint32_t ldx, uint32_t l);
-void launch_spmm_quad(Storage &st, SparseCopy &cp, QuadLayout &q, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
-                      double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw);
+// tiles.hip
+bool spmm_tiles_ok(const SparseCopy &cp, uint32_t ldx, uint32_t l);
+bool tile_shape_ok(uint32_t K, uint32_t S);
+void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l, double *out,
+                       uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw);
 // per-outer-vector reductions. mode 0: sum of raw u32 counts; 1: sum of mapped values; 2: sum and sum of squares.
 void launch_row_reduce(Storage &st, SparseCopy &cp, const DevMap &map, int mode, uint32_t *out_u32, double *out_sum,
                        double *out_sumsq);

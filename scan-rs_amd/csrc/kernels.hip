@@ -188,17 +188,19 @@ __global__ void build_bounds_kernel(const uint64_t *__restrict__ indptr, const u
 // MAT: the first `fstart` links of the map were evaluated once per nonzero into `fvals` (materialized prefix, see
 // ensure_fvals); the kernel reads that f64 instead of the u32 count and applies only the remaining links, which index
 // their arrays by the outer position (wave-uniform) — no scattered gather of a scale per nonzero.
-template <int NACC, bool MAT>
+// HOT = false: no vector ever gets a workgroup (n_hot must be 0) and the kernel declares no LDS at all — the form that runs
+// beside the persistent tile kernel of tiles.hip, whose two tile buffers leave 6 KB of a CU's LDS.
+template <int NACC, bool MAT, bool HOT = true>
 __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
     const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices, const uint32_t *__restrict__ values,
     const uint32_t *__restrict__ bounds, uint32_t nb, uint32_t b0, uint32_t b1, int first, int last, uint64_t n_outer,
     const uint32_t *__restrict__ order, uint32_t n_hot, DevMap map, const double *__restrict__ X, uint32_t ldx, uint32_t l,
     double *out, uint32_t ldo, const double *__restrict__ off_a, uint32_t rank, const double *__restrict__ off_w, uint32_t ldw,
     const double *__restrict__ fvals, int fstart) {
-    __shared__ d2 part[3][NACC][64];
+    __shared__ d2 part[HOT ? 3 : 1][HOT ? NACC : 1][HOT ? 64 : 1];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const bool hot = blockIdx.x < n_hot; // block-uniform
+    const bool hot = HOT && blockIdx.x < n_hot; // block-uniform
     const uint64_t slot = hot ? (uint64_t)blockIdx.x : (uint64_t)n_hot + ((uint64_t)blockIdx.x - n_hot) * 4u + wave;
     if (slot >= n_outer) return; // never taken by a hot block
     const uint64_t row64 = order ? (uint64_t)order[slot] : slot;
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
             }
         }
     }
-    if (hot) { // block-uniform: all four waves of a hot block reach the barrier
+    if (HOT && hot) { // block-uniform: all four waves of a hot block reach the barrier
         if (wave > 0) {
 #pragma unroll
             for (int a = 0; a < NACC; a++) part[wave - 1][a][lane] = acc[a];
@@ -312,161 +314,6 @@ __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
     }
 }
 
-// Persistent form of the L2-blocked gather for copies with few, long outer vectors (the gene-major copy: 33 k vectors,
-// hundreds of steps). One launch per product instead of one per step: every wave OWNS up to G outer vectors for the whole
-// product (dealt from the longest-first list in snake order, so the waves' totals balance), keeps their running sums in
-// registers across all steps, and writes each output row once — the per-step carry of the sums through HBM (3.5-5.3x
-// the algorithmic bytes of the multi-launch form) and the per-step launch tails are gone.
-// What the per-step launches gave for free has to be rebuilt: all waves must work on the SAME panel slice at about the
-// same time or the slice falls out of the 4 MB L2s. A wave may therefore run at most `slack` steps ahead of the slowest
-// workgroup: finished steps are counted per workgroup in LDS (no __syncthreads: the last of the 16 waves to finish a
-// step reports it), per grid in `sync[step]`, and the wave that completes a step grid-wide raises `progress`; a wave
-// entering step s waits for progress > s - slack. The counters carry NO data dependency — every wave reads only the
-// input panel and its own rows — so the wait is bounded: after `timeout_clk` it raises `flags[0]` and every wave stops
-// waiting (results unchanged, only the L2 residency is lost).
-// The running sums live in LDS (one 16-byte slot per lane per owned vector), so the kernel needs no more registers than
-// the multi-launch one and two 12-wave workgroups fill a CU at 6 waves / SIMD.
-// MEASURED (round 2, 1 M x 33 k x 3 %, b = 100, gene-major copy): 58.9 ms per pass against 42.7 ms for the multi-launch
-// form (3 MB slices, strict per-step barrier; 1.5 MB slices: 67.6 ms; one step of slack with 1 MB slices: 66.5 ms; no
-// synchronisation at all: 126 ms; a register-resident variant at 4 waves / SIMD: 67.8 ms). The HBM carry it removes was
-// never on the critical path (the pass is bound by the texture addresser), and static ownership
-// gives up what the hardware dispatcher does for the per-step launches: 33 k segments dealt dynamically over 1280
-// workgroup slots. With fixed owners every step lasts as long as its slowest wave (6 segments, first-touch misses of the
-// new slice included), and slack cannot absorb that without shrinking the slices until the per-segment fixed costs
-// take over. Kept opt-in (SCANRS_SPMM_PERSIST=1) with its parity test; the default is the multi-launch form.
-__global__ __launch_bounds__(768, 6) void spmm_gather2d_persist_kernel(
-    const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices, const uint32_t *__restrict__ values,
-    const uint32_t *__restrict__ bounds, uint32_t nb, uint32_t m, uint32_t steps, uint64_t n_outer,
-    const uint32_t *__restrict__ order, DevMap map, const double *__restrict__ X, uint32_t ldx, uint32_t l, double *out, uint32_t ldo,
-    const double *__restrict__ off_a, uint32_t rank, const double *__restrict__ off_w, uint32_t ldw, uint32_t *sync,
-    uint32_t *progress, uint32_t *flags, uint32_t slack, long long timeout_clk, uint32_t G) {
-    // [nwave][G][64] running sums (one 16-byte slot per lane: conflict-free b128 accesses), then
-    // [steps] waves of this workgroup that finished the step, then [1] cached progress
-    extern __shared__ d2 lds_acc[];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = rfl(threadIdx.x >> 6);
-    const uint32_t nwave = blockDim.x >> 6;
-    const uint32_t W = gridDim.x * nwave, gw = blockIdx.x * nwave + wave;
-    uint32_t *lds_done = reinterpret_cast<uint32_t *>(lds_acc + (size_t)nwave * G * 64u);
-    for (uint32_t i = threadIdx.x; i <= steps; i += blockDim.x) lds_done[i] = 0u;
-    for (uint32_t i = threadIdx.x; i < nwave * G * 64u; i += blockDim.x) lds_acc[i] = (d2){0.0, 0.0};
-    __syncthreads();
-    d2 *my_acc = lds_acc + (size_t)wave * G * 64u + lane;
-    // lane k < G holds what the wave needs to know about its k-th vector; the per-vector loop below reads it with
-    // v_readlane (runtime k), so only the sums themselves are G-sized register state
-    uint32_t my_row = 0, my_has = 0, my_base_lo = 0, my_base_hi = 0;
-    if (lane < G) {
-        const uint64_t r = (uint64_t)lane * W + ((lane & 1u) ? (W - 1u - gw) : gw);
-        if (r < n_outer) {
-            my_has = 1u;
-            my_row = order[r];
-            const uint64_t b = indptr[my_row];
-            my_base_lo = (uint32_t)b;
-            my_base_hi = (uint32_t)(b >> 32);
-        }
-    }
-    const uint32_t col = lane * 2u;
-    const bool act = col < l;
-    const uint32_t lcol = act ? col : 0u;
-    bool waiting = slack > 0u; // cleared for good once any wave timed out
-    for (uint32_t s = 0; s < steps; s++) {
-        const uint32_t b0 = s * m, b1 = min(nb, b0 + m);
-        uint32_t my_o0 = 0, my_o1 = 0; // issued before the wait: the bounds do not depend on the other workgroups
-        if (my_has) {
-            const uint32_t *__restrict__ bd = bounds + (uint64_t)my_row * (nb + 1);
-            my_o0 = bd[b0];
-            my_o1 = bd[b1];
-        }
-        if (waiting && s >= slack) {
-            const uint32_t need = s - slack + 1u;
-            if (rfl(lds_done[steps]) < need) {
-                const long long t0 = wall_clock64();
-                for (;;) {
-                    const uint32_t p = rfl(__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    if (p >= need) {
-                        if (lane == 0) atomicMax(&lds_done[steps], p);
-                        break;
-                    }
-                    if (rfl(__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0u) {
-                        waiting = false;
-                        break;
-                    }
-                    if (wall_clock64() - t0 > timeout_clk) {
-                        if (lane == 0) __hip_atomic_store(flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        waiting = false;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
-        }
-#pragma unroll 1
-        for (uint32_t k = 0; k < G; k++) {
-            if (!rdlane(my_has, k)) continue;
-            const uint32_t row = rdlane(my_row, k);
-            const uint64_t base = ((uint64_t)rdlane(my_base_hi, k) << 32) | rdlane(my_base_lo, k);
-            const uint32_t s0 = rdlane(my_o0, k), len = rdlane(my_o1, k) - s0;
-            if (len == 0u) continue;
-            const uint32_t *__restrict__ ind = indices + base + s0;
-            const uint32_t *__restrict__ val = values + base + s0;
-            const RowMap rm = row_map(map, row);
-            d2 a = my_acc[k * 64u];
-            for (uint32_t c = 0; c < len; c += 64u) {
-                const uint32_t p = c + lane;
-                uint32_t idx = 0;
-                double f = 0.0;
-                if (p < len) {
-                    idx = ind[p];
-                    f = eval_map(map, rm, val[p], row, idx);
-                }
-                const uint32_t n = min(64u, len - c);
-                if (act) {
-                    uint32_t j = 0;
-                    for (; j + 8u <= n; j += 8u) {
-#pragma unroll
-                        for (uint32_t u = 0; u < 8u; u++) {
-                            const uint32_t g = rdlane(idx, j + u);
-                            const double fv = bcast<double>(f, j + u);
-                            const d2 x = *reinterpret_cast<const d2 *>(X + (size_t)g * ldx + lcol);
-                            a.x = fma(fv, x.x, a.x);
-                            a.y = fma(fv, x.y, a.y);
-                        }
-                    }
-                    for (; j < n; j++) {
-                        const uint32_t g = rdlane(idx, j);
-                        const double fv = bcast<double>(f, j);
-                        const d2 x = *reinterpret_cast<const d2 *>(X + (size_t)g * ldx + lcol);
-                        a.x = fma(fv, x.x, a.x);
-                        a.y = fma(fv, x.y, a.y);
-                    }
-                }
-            }
-            my_acc[k * 64u] = a;
-        }
-        if (slack > 0u && lane == 0) {
-            if (atomicAdd(&lds_done[s], 1u) == nwave - 1u) { // last wave of the workgroup through step s
-                const uint32_t g = __hip_atomic_fetch_add(sync + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (g == gridDim.x - 1u) __hip_atomic_fetch_max(progress, s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    for (uint32_t k = 0; k < G; k++) {
-        if (!rdlane(my_has, k) || !act) continue;
-        const uint32_t rowk = rdlane(my_row, k);
-        d2 r = my_acc[k * 64u];
-        for (uint32_t q = 0; q < rank; q++) {
-            const double aq = off_a[(size_t)rowk * rank + q];
-            r.x += aq * off_w[(size_t)q * ldw + col];
-            r.y += aq * off_w[(size_t)q * ldw + col + 1];
-        }
-        *reinterpret_cast<d2 *>(out + (size_t)rowk * ldo + col) = r;
-    }
-}
-
-// Opt-in "f32 gather panel" form of the L2-blocked product (scanrs_mat_set_panel_precision): the panel is
-// rounded to f32 once per product, every gathered row costs half the L2 -> CU bytes, and the sums stay in f64.
-// Two nonzeros share one load instruction: lanes 0-31 fetch the row of nonzero j, lanes 32-63 that of nonzero
-// j+1 (4 columns = 16 B per lane, 128 columns per half-wave); the two half-wave partial sums are added at the end.
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 __global__ void f64_to_f32_panel_kernel(const double *__restrict__ src, uint32_t lds_, uint64_t rows, uint32_t l,
@@ -1769,53 +1616,29 @@ static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const
     SCANRS_HIP(hipGetLastError());
 }
 
-// Persistent L2-blocked gather (see spmm_gather2d_persist_kernel). Returns false when the copy / shape is not eligible
-// or an earlier product on this handle saw the grid fall out of step (then the multi-launch form is used).
-// Two workgroups of 12 waves per CU = 6 waves / SIMD (the multi-launch kernel runs at 5); the running sums live in
-// LDS (1 KB per owned vector per wave), so the kernel needs no more registers than that one.
-static bool launch_spmm_2d_persist(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
-                                   double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w,
-                                   uint32_t ldw) {
-    if ((ldx & 1u) || (ldo & 1u) || st.persist_broken) return false;
-    int dev = 0, n_cu = 0;
-    SCANRS_HIP(hipGetDevice(&dev));
-    SCANRS_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    constexpr unsigned NWAVE = 12; // 3 waves per SIMD per workgroup: two workgroups pack every SIMD evenly
-    const unsigned n_wg = (unsigned)n_cu * 2u;
-    const uint64_t W = (uint64_t)n_wg * NWAVE;
-    const uint32_t G = (uint32_t)((cp.n_outer + W - 1) / W);
-    if (G > 64u) return false;
-    const uint32_t nb = ensure_bounds(st, cp);
-    const uint32_t n_chunks = (l + 127u) / 128u;
-    uint32_t lc = (l + n_chunks - 1u) / n_chunks;
-    lc = (lc + 1u) & ~1u;
-    // per device, and handles of one process may live on different devices: set on every use (a cheap call)
-    SCANRS_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(spmm_gather2d_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    for (uint32_t c0 = 0; c0 < l; c0 += lc) { // eligibility of every column chunk before anything is launched
-        const uint32_t lw = std::min(lc, l - c0);
-        const uint32_t m = std::max(1u, (uint32_t)(st.persist_tile_bytes / ((size_t)(1u << BT_SHIFT) * lw * 8)));
-        const uint32_t steps = (nb + m - 1u) / m;
-        if ((size_t)NWAVE * G * 1024 + ((size_t)steps + 1) * 4 > 80u * 1024u) return false; // two workgroups share a CU's 160 KB
-    }
-    ensure_order(st, cp);
-    for (uint32_t c0 = 0; c0 < l; c0 += lc) {
-        const uint32_t lw = std::min(lc, l - c0);
-        const uint32_t m = std::max(1u, (uint32_t)(st.persist_tile_bytes / ((size_t)(1u << BT_SHIFT) * lw * 8)));
-        const uint32_t steps = (nb + m - 1u) / m;
-        const size_t lds = (size_t)NWAVE * G * 1024 + ((size_t)steps + 1) * 4;
-        // [0] progress, [1] flags, [2 ..] per-step workgroup counts
-        uint32_t *sync = st.scratch.get<uint32_t>("spmm_persist_sync", (size_t)steps + 2);
-        SCANRS_HIP(hipMemsetAsync(sync, 0, ((size_t)steps + 2) * 4, st.stream));
-        const double bytes = (double)cp.nnz * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_inner * lw * 8.0 + (double)cp.n_outer * lw * 8.0;
-        const double *offw = off_w ? off_w + c0 : nullptr;
-        const long long timeout_clk = 5000000ll; // 50 ms of the 100 MHz wall clock
-        ProfScope ps(st, "spmm_gather2d_persist/short-outer", bytes, (double)cp.nnz * 8.0 * lw);
-        hipLaunchKernelGGL(spmm_gather2d_persist_kernel, dim3(n_wg), dim3(NWAVE * 64), lds, st.stream, cp.indptr.p, cp.indices.p,
-                           cp.values.p, cp.bounds.p, nb, m, steps, cp.n_outer, cp.order.p, map, X + c0, ldx, lw, out + c0, ldo, off_a, rank,
-                           offw, ldw, sync + 2, sync, sync + 1, st.persist_slack, timeout_clk, G);
+uint32_t ensure_bounds_public(Storage &st, SparseCopy &cp) { return ensure_bounds(st, cp); }
+
+// The overflow part of a tile layout (tiles.hip) through the L2-blocked gather on stream `s`: weights are materialized
+// (ov.fvals holds the whole chain's value), no vector gets a workgroup, no LDS, the sums start at zero and carry no offset.
+void launch_gather2d_ov(Storage &st, hipStream_t s, SparseCopy &ov, const double *X, uint32_t ldx, uint32_t l, double *out,
+                        uint32_t ldo) {
+    const uint32_t nb = (uint32_t)((ov.n_inner + (1ull << BT_SHIFT) - 1) >> BT_SHIFT); // bounds were built with the layout
+    uint32_t m = (uint32_t)(st.l2_tile_bytes / ((size_t)(1u << BT_SHIFT) * l * 8));
+    if (m < 1u) m = 1u;
+    const uint32_t steps = (nb + m - 1u) / m;
+    const dim3 grid((unsigned)((ov.n_outer + 3) / 4)), block(256);
+    DevMap none;
+    memset(&none, 0, sizeof(none));
+    const double bytes = ((double)ov.nnz * 12.0 + (double)(ov.n_outer + 1) * 8.0 + (double)ov.n_inner * l * 8.0 + (double)ov.n_outer * l * 8.0) / steps;
+    for (uint32_t sidx = 0; sidx < steps; sidx++) {
+        const uint32_t b0 = sidx * m, b1 = std::min(nb, b0 + m);
+        if (st.prof.on) st.prof.begin(s, ov.n_outer >= ov.n_inner ? "spmm_gather2d_ov/long-outer" : "spmm_gather2d_ov/short-outer", bytes, (double)ov.nnz * 8.0 * l / steps);
+        hipLaunchKernelGGL((spmm_gather2d_kernel<1, true, false>), grid, block, 0, s, ov.indptr.p, ov.indices.p, (const uint32_t *)nullptr,
+                           ov.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, sidx + 1 == steps ? 1 : 0, ov.n_outer, (const uint32_t *)nullptr, 0u, none,
+                           X, ldx, l, out, ldo, (const double *)nullptr, 0u, (const double *)nullptr, 0u, ov.fvals.p, 0);
+        if (st.prof.on) st.prof.end(s);
     }
     SCANRS_HIP(hipGetLastError());
-    return true;
 }
 
 // L2-blocked gather over an f32 copy of the panel (opt-in, see spmm_gather2d_f32_kernel)
@@ -1872,16 +1695,15 @@ void launch_scale_rows(Storage &st, const double *X, uint32_t ldx, uint64_t rows
 
 void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
                      double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw) {
-    if (st.spmm_path == 3 && spmm_quad_ok(cp, map, ldx, l)) { // LDS-staged tiles over the quad layout (quad.hip)
-        if (!cp.quad) cp.quad.reset(quad_layout_build(st, cp), quad_layout_free);
-        launch_spmm_quad(st, cp, *cp.quad, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
+    if (st.spmm_path == 3 && spmm_tiles_ok(cp, ldx, l)) { // hybrid: LDS-staged tiles + gather of the overflow part (tiles.hip)
+        launch_spmm_tiles(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
         return;
     }
     const bool want_2d = st.spmm_path == 2 || st.spmm_path == 3 || (st.spmm_path == 0 && cp.nnz >= st.blocked_min_nnz && l >= 16);
     if (want_2d && l > 0 && cp.n_outer > 0 && cp.n_inner > 0) {
         if (st.panel_precision == 1)
             launch_spmm_2d_f32(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
-        else if (!(st.persist && cp.n_outer < cp.n_inner && launch_spmm_2d_persist(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw)))
+        else
             launch_spmm_2d(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
         return;
     }

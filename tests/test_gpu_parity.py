@@ -500,21 +500,23 @@ def test_blocked_kernel_matches_gather_and_oracle(sa, storage):
 
 
 @pytest.mark.parametrize("storage", [so.CSR, so.CSC])
-def test_lds_staged_product_matches_gather_and_oracle(sa, storage):
-    """spmm path 3 (quad.hip: panel tiles staged in LDS, tile-bucketed second layout, static register accumulators) against the
-    gather kernels and the oracle: shapes around the slot (40) / workgroup (320) / tile (96) edges, empty vectors, dense spots that
-    fill the overflow lists (more than 4 nonzeros per vector and tile, more than 64 per visit), with and without the rank-r offset,
-    panel widths 16 .. 104 (other widths fall through to path 2)."""
+@pytest.mark.parametrize("tile_k,tile_s", [(4, 32), (3, 32), (2, 32), (4, 28)])
+def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_s):
+    """spmm path 3 (tiles.hip: the hybrid product — panel tiles staged in LDS over K fixed record positions per (outer vector,
+    tile) with materialized weights, and the L2-blocked gather over the nonzeros that overflow them, on two streams) against the
+    plain gather kernel and the oracle: shapes around the slot (32) / workgroup (256) / tile (96) edges, empty vectors, dense
+    spots that fill the overflow part, matrices with no overflow at all, with and without the rank-r offset, panel widths
+    16 .. 104 (other widths fall through to path 2)."""
     rng = np.random.default_rng(31 + storage)
-    for rows, cols, fill in ((1, 1, 1.0), (39, 95, 0.5), (40, 96, 0.3), (41, 97, 0.9), (321, 200, 0.05), (700, 1000, 0.03),
-                             (97, 5000, 0.02), (2000, 193, 0.2)):
+    for rows, cols, fill in ((1, 1, 1.0), (31, 95, 0.5), (32, 96, 0.3), (33, 97, 0.9), (257, 200, 0.05), (700, 1000, 0.03),
+                             (97, 5000, 0.02), (2000, 193, 0.2), (300, 400, 0.004)):
         dense = random_counts(rng, rows, cols, fill, 40)
         dense[rng.random(rows) < 0.2, :] = 0  # some empty rows
         dense[0, 0] = 7
         g1, o = pair(sa, dense, storage)
         g3, _ = pair(sa, dense, storage)
         g1.set_spmm_path(1)
-        g3.set_spmm_path(3)
+        g3.set_spmm_path(3).set_option("tile_k", tile_k).set_option("tile_s", tile_s)
         f = rng.random(cols) + 0.5
         fr = rng.random(rows) + 0.5
         for gm in (g1, g3):
@@ -532,14 +534,20 @@ def test_lds_staged_product_matches_gather_and_oracle(sa, storage):
                 a1, a3, ref = g1.dot(q), g3.dot(q), ref_m.dot(q)
                 assert_close(a3, ref, rtol=1e-10, atol=1e-9)
                 assert_close(a1, a3, rtol=1e-11, atol=1e-10)
+                assert np.array_equal(a3, g3.dot(q))  # bitwise repeatable
                 ql = rng.standard_normal((l, rows))
                 a1, a3, ref = g1.rdot(ql), g3.rdot(ql), ref_m.rdot(ql)
                 assert_close(a3, ref, rtol=1e-10, atol=1e-9)
                 assert_close(a1, a3, rtol=1e-11, atol=1e-10)
-    # bitwise repeatable, and the whole PCA through it agrees with the default path
+
+
+def test_lds_staged_product_whole_pca_and_remap(sa):
+    """The whole PCA through the hybrid product agrees with the default path and is bitwise repeatable; re-normalizing the
+    handle (new map ids) rebuilds the tile layout instead of reusing stale weights."""
     m = _synth(4000, 900, 0.06, 5)
     ga = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
     gb = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+    ga.set_spmm_path(2)
     gb.set_spmm_path(3)
     ua, s_a, va = sa.BkSvd().run_pca(sa.normalize(ga, sa.Normalization.CellRanger), 10)
     ub, s_b, vb = sa.BkSvd().run_pca(sa.normalize(gb, sa.Normalization.CellRanger), 10)
@@ -547,6 +555,12 @@ def test_lds_staged_product_matches_gather_and_oracle(sa, storage):
     assert np.max(np.abs(_sign_fix(ub, ua) - ua)) < 1e-7 and np.max(np.abs(_sign_fix(vb, va) - va)) < 1e-7
     ub2, s_b2, vb2 = sa.BkSvd().run_pca(gb, 10)
     assert np.array_equal(s_b, s_b2) and np.array_equal(ub, ub2) and np.array_equal(vb, vb2)
+    # another map on the same handles: the layouts must follow
+    for g in (ga, gb):
+        g.reset_map()
+        sa.log_normalize_with_size_factor(g, None, sa.FN_LN_1P)
+    q = np.random.default_rng(3).standard_normal((m.shape[0], 40))
+    assert_close(ga.dot(q), gb.dot(q), rtol=1e-11, atol=1e-10)
 
 
 def test_blocked_kernel_many_steps_and_determinism(sa):

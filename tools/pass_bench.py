@@ -1,5 +1,6 @@
-"""Time of one sparse pass (b-wide product) in both orientations, with the raw map, the CellRanger map, and the
-centred / scaled operator — what the map evaluation and the rank-1 offset cost on top of the bare gather."""
+"""Time of one sparse pass (b-wide product) in both orientations under the CellRanger map (scale, log2, centre / scale),
+for a list of product configurations: `path[:tile_k:tile_s]`, e.g. `0 3:4:32 3:3:32` (0 = default, 2 = L2-blocked gather,
+3 = hybrid LDS tiles + gather). usage: pass_bench.py [cells] [l] config..."""
 import os
 import sys
 import time
@@ -13,39 +14,59 @@ from scanrs_amd.synth import synth_counts_torch
 
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 genes, l = 33_000, int(sys.argv[2]) if len(sys.argv) > 2 else 100
-path = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+configs = sys.argv[3:] or ["0"]
 dev = torch.device("cuda", 0)
 ip, ix, vv = synth_counts_torch(cells, genes, 0.03, 0, dev)
-m = sa.AdaptiveMat.from_device(genes, cells, sa.CSC, ip.data_ptr(), ix.data_ptr(), vv.data_ptr())
 nnz = int(ip[-1].item())
-if path:
-    m.set_spmm_path(path)
-del ip, ix, vv
 xg = torch.randn(genes, l, device=dev, dtype=torch.float64)
 xc = torch.randn(cells, l, device=dev, dtype=torch.float64)
 og = torch.zeros(genes, l, device=dev, dtype=torch.float64)
 oc = torch.zeros(cells, l, device=dev, dtype=torch.float64)
+ref = {}
 
+for cfg in configs:
+    parts = [int(x) for x in cfg.split(":")]
+    m = sa.AdaptiveMat.from_device(genes, cells, sa.CSC, ip.data_ptr(), ix.data_ptr(), vv.data_ptr())
+    m.set_spmm_path(parts[0])
+    if len(parts) > 1:
+        m.set_option("tile_k", parts[1])
+    if len(parts) > 2:
+        m.set_option("tile_s", parts[2])
+    if len(parts) > 3:
+        m.set_option("tile_overlap", parts[3])
+    if len(parts) > 4:
+        m.set_option("tile_ablate", parts[4])
+    sa.normalize(m, sa.Normalization.CellRanger)
 
-def t(fn, reps=5):
-    fn()
-    m.sync()
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    def t(fn, reps=5):
+        t0 = time.perf_counter()
         fn()
+        m.sync()
+        first = (time.perf_counter() - t0) * 1e3
+        fn()
+        m.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        m.sync()
+        return (time.perf_counter() - t0) / reps * 1e3, first
+
+    a, fa = t(lambda: m.dot_device(False, xc.data_ptr(), l, l, og.data_ptr(), l))  # A X: out rows = genes (gene-major copy)
+    b, fb = t(lambda: m.dot_device(True, xg.data_ptr(), l, l, oc.data_ptr(), l))   # A^T X: out rows = cells (cell-major copy)
+    err = ""
+    if not ref:
+        ref["g"], ref["c"] = og.clone(), oc.clone()
+    else:
+        eg = float((og - ref["g"]).abs().max() / ref["g"].abs().max())
+        ec = float((oc - ref["c"]).abs().max() / ref["c"].abs().max())
+        err = f"  max rel diff vs first config: {eg:.1e} / {ec:.1e}"
+    m.profile_enable(True)
+    m.profile_reset()
+    m.dot_device(False, xc.data_ptr(), l, l, og.data_ptr(), l)
+    m.dot_device(True, xg.data_ptr(), l, l, oc.data_ptr(), l)
     m.sync()
-    return (time.perf_counter() - t0) / reps * 1e3
-
-
-def both(tag):
-    a = t(lambda: m.dot_device(False, xc.data_ptr(), l, l, og.data_ptr(), l))   # A X: out rows = genes (gene-major copy)
-    b = t(lambda: m.dot_device(True, xg.data_ptr(), l, l, oc.data_ptr(), l))    # A^T X: out rows = cells (cell-major copy)
-    print(f"{tag:28s} gene-major pass {a:7.2f} ms ({a*1e6*256/nnz:5.2f} ns/nnz/CU)   cell-major pass {b:7.2f} ms ({b*1e6*256/nnz:5.2f} ns/nnz/CU)")
-
-
-both("raw counts (no map)")
-sa.log_normalize_with_size_factor(m, None, sa.FN_LOG2_1P)
-both("scale + log2(1+x)")
-m.reset_map()
-sa.normalize(m, sa.Normalization.CellRanger)
-both("CellRanger (scale, centre)")
+    prof = "; ".join(f"{name} x{st['launches']} {st['total_ms']:.2f} ms" for name, st in m.profile_get().items() if st["total_ms"] > 0.3)
+    m.profile_enable(False)
+    print(f"{cfg:10s} gene-major pass {a:7.2f} ms ({a*1e6*256/nnz:5.2f} ns/nnz/CU, first call {fa:7.1f} ms)   "
+          f"cell-major pass {b:7.2f} ms ({b*1e6*256/nnz:5.2f} ns/nnz/CU, first call {fb:7.1f} ms){err}\n           {prof}", flush=True)
+    del m
