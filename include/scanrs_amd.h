@@ -314,8 +314,12 @@ int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uin
  * All are HIP kernels; results agree to rounding. */
 int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
 /* Tuning options of a handle (shared by its views); defaults are the measured optimum on MI355X.
- *   "tile_k" (4)        hybrid product: record positions per (outer vector, panel tile): 2, 3 or 4
- *   "tile_s" (32)       hybrid product: outer vectors per wave (32; 28 with tile_k 4)
+ *   "tile_k" (2)        hybrid product: record positions per (outer vector, visit): 2, 3 or 4
+ *   "tile_s" (32)       hybrid product: outer vectors per wave (32; 28 with tile_k 2 or 4)
+ *   "tile_t" (48)       hybrid product: panel rows per tile (<= 24 tile_k)
+ *   "tile_b" (4)        hybrid product: tile buffers in the LDS ring (tile_t * tile_b <= 192); a nonzero may wait tile_b - 2 visits
+ *   "tile_auto" (1)     path 0 may use the hybrid product for matrices of 2^24+ nonzeros (layout built when svd_bk / svd_rand
+ *                       start, or at the second product under the same map, if the device has room: ~12 B per nonzero)
  *   "tile_overlap" (1)  hybrid product: the overflow gather runs beside the tile kernel (0: after it; measurement only)
  *   "l2_tile_kb" (3584) panel slice per step of the L2-blocked gather
  *   "spmm_order" (1)    L2-blocked gather launch order: 0 storage order, 1 longest vectors first when a launch is a few

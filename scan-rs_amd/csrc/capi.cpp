@@ -1134,9 +1134,16 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
         if (!m || !key) fail(SCANRS_ERR_ARGUMENT, "null handle or key");
         Storage &st = *m->st;
         const std::string k(key);
-        if (k == "tile_k" || k == "tile_s") {
-            const uint32_t K = k == "tile_k" ? (uint32_t)value : st.tile_k, S = k == "tile_s" ? (uint32_t)value : st.tile_s;
-            if (k == "tile_k") st.tile_k = K; else st.tile_s = S; // validated as a pair when the product runs
+        if (k == "tile_k") { // the tile shape is validated as a whole when the product runs
+            st.tile_k = (uint32_t)value;
+        } else if (k == "tile_s") {
+            st.tile_s = (uint32_t)value;
+        } else if (k == "tile_t") {
+            st.tile_t = (uint32_t)value;
+        } else if (k == "tile_b") {
+            st.tile_b = (uint32_t)value;
+        } else if (k == "tile_auto") {
+            st.tile_auto = value != 0.0;
         } else if (k == "tile_overlap") {
             st.tile_overlap = value != 0.0;
         } else if (k == "l2_tile_kb") {

@@ -159,6 +159,9 @@ struct SparseCopy {
     DevBuf<uint32_t> order;
     std::vector<uint32_t> sorted_len;
     std::shared_ptr<TileLayout> tiles; // built on first use of the hybrid tile product under a given map (tiles.hip)
+    int tsig_n = -1;                   // ... the map the last eligible product came with (auto path: build on the second sighting)
+    uint32_t tsig_id[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int tsig_outer[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // Materialized map values (kernels.hip, "materialized prefix"): f64 per nonzero, in this copy's order, of the first
     // `fsig_n` links of a map chain — kept for the copy with few, long outer vectors, where evaluating the chain costs a
     // scattered 8-byte gather per nonzero per product (the per-barcode scale while walking a gene's vector).
@@ -219,7 +222,10 @@ struct Storage {
         uint64_t rows_u = 0, rows_v = 0;
     } pca_dev;
     int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 L2-blocked gather, 3 hybrid: LDS-staged tiles + gather of the overflow (tiles.hip)
-    uint32_t tile_k = 4, tile_s = 32;     // hybrid product: record positions per (outer vector, tile), outer vectors per wave
+    uint32_t tile_k = 2, tile_s = 32;     // hybrid product: record positions per (outer vector, visit), outer vectors per wave
+    uint32_t tile_t = 48, tile_b = 4;     // ... panel rows per tile (<= 24 tile_k) and tile buffers in the LDS ring (tile_t * tile_b <= 192)
+    int tile_auto = 1;                    // auto path may use the hybrid product (0: only spmm_path 3 does)
+    int tile_hint = 0;                    // > 0 while a solver that repeats the same products is running (svd_bk, svd_rand)
     int tile_overlap = 1;                 // hybrid product: 1 = the overflow gather runs beside the tile kernel (own stream); 0 = after it (measurement)
     int panel_precision = 0;              // 0: f64 panels (default); 1: gathered panels rounded to f32, f64 sums (opt-in)
     size_t l2_tile_bytes = 3584u << 10;   // panel slice per step of the L2-blocked gather (4 MB L2 per XCD): whole 1024-row base tiles up to 3.5 MB — 4 tiles (3.2 MB) at 100 columns, 3 (2.9 MB) at 122; measured 40.55 / 39.71 ms per pass against 41.30 / 40.23 with 3 tiles and 40.86 / 39.61 with 5, and 4 tiles of 122 columns (3.9 MB) lose 1.8 ms
@@ -290,8 +296,9 @@ void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const doubl
 void launch_spmm_u32(Storage &st, const SparseCopy &cp, const uint32_t *X, uint32_t ldx, uint32_t l, uint32_t *out,
                      uint32_t ldo);
 // tiles.hip
-bool spmm_tiles_ok(const SparseCopy &cp, uint32_t ldx, uint32_t l);
-bool tile_shape_ok(uint32_t K, uint32_t S);
+bool spmm_tiles_ok(const Storage &st, const SparseCopy &cp, uint32_t ldx, uint32_t l);
+bool tile_shape_ok(uint32_t K, uint32_t S, uint32_t T, uint32_t B);
+bool spmm_tiles_auto(Storage &st, SparseCopy &cp, const DevMap &map);
 void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l, double *out,
                        uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw);
 // per-outer-vector reductions. mode 0: sum of raw u32 counts; 1: sum of mapped values; 2: sum and sum of squares.

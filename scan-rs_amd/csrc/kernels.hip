@@ -1618,6 +1618,21 @@ static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const
 
 uint32_t ensure_bounds_public(Storage &st, SparseCopy &cp) { return ensure_bounds(st, cp); }
 
+// fout[p] = the whole chain of `map` at nonzero p of `cp` (tiles.hip: weights of the overflow part)
+void materialize_map_values(Storage &st, SparseCopy &cp, const DevMap &map, double *fout) {
+    const uint32_t nb = ensure_bounds(st, cp);
+    const uint32_t m = 256;
+    const uint32_t steps = (nb + m - 1) / m;
+    const dim3 grid((unsigned)((cp.n_outer + 3) / 4)), block(256);
+    for (uint32_t sidx = 0; sidx < steps; sidx++) {
+        const uint32_t b0 = sidx * m, b1 = std::min(nb, b0 + m);
+        ProfScope ps(st, "materialize_map_values", (double)cp.nnz * 16.0 / steps);
+        hipLaunchKernelGGL((row_reduce2d_kernel<3>), grid, block, 0, st.stream, cp.indptr.p, cp.indices.p, cp.values.p, cp.bounds.p, nb, b0, b1,
+                           sidx == 0 ? 1 : 0, cp.n_outer, map, (double *)nullptr, (double *)nullptr, fout);
+    }
+    SCANRS_HIP(hipGetLastError());
+}
+
 // The overflow part of a tile layout (tiles.hip) through the L2-blocked gather on stream `s`: weights are materialized
 // (ov.fvals holds the whole chain's value), no vector gets a workgroup, no LDS, the sums start at zero and carry no offset.
 void launch_gather2d_ov(Storage &st, hipStream_t s, SparseCopy &ov, const double *X, uint32_t ldx, uint32_t l, double *out,
@@ -1695,7 +1710,9 @@ void launch_scale_rows(Storage &st, const double *X, uint32_t ldx, uint64_t rows
 
 void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
                      double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw) {
-    if (st.spmm_path == 3 && spmm_tiles_ok(cp, ldx, l)) { // hybrid: LDS-staged tiles + gather of the overflow part (tiles.hip)
+    if (spmm_tiles_ok(st, cp, ldx, l) && tile_shape_ok(st.tile_k, st.tile_s, st.tile_t, st.tile_b) &&
+        (st.spmm_path == 3 || (st.spmm_path == 0 && st.panel_precision == 0 && spmm_tiles_auto(st, cp, map)))) {
+        // hybrid: LDS-staged tiles + gather of the overflow part (tiles.hip)
         launch_spmm_tiles(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
         return;
     }

@@ -175,7 +175,11 @@ struct Ctx {
     scanrs_mat *m;
     Storage &st;
     hipStream_t s;
-    explicit Ctx(scanrs_mat *mm) : m(mm), st(*mm->st), s(mm->st->stream) {}
+    // a solver repeats the same products many times: lets the auto path build the hybrid product's tile layout up front
+    explicit Ctx(scanrs_mat *mm) : m(mm), st(*mm->st), s(mm->st->stream) { st.tile_hint++; }
+    ~Ctx() { st.tile_hint--; }
+    Ctx(const Ctx &) = delete;
+    Ctx &operator=(const Ctx &) = delete;
     double *dev(const char *key, size_t count) { return st.scratch.get<double>(key, count); }
     void sync() { SCANRS_HIP(hipStreamSynchronize(s)); }
     void h2d(double *d, const double *h, size_t n) {

@@ -4,22 +4,28 @@
 // Why two pipes. The gather form pulls one 800-byte panel row per nonzero through the CU's texture addresser (64 B/clk,
 // busy 91-96 % of a launch: DESIGN.md section 4) while the LDS (256 B/clk for ds_read_b128) idles; an LDS-only form (round 2,
 // quad.hip) pays for every nonzero that does not fit its fixed record structure. Here the matrix is SPLIT once per map:
-//   * tile part: every (outer vector, tile of TL_T = 96 panel rows) pair owns exactly K record positions (K = 2..4); its
-//     first K nonzeros go there as (row inside the tile u8, weight f64) — the weight is the whole map chain evaluated
-//     once at build time (materialized, so a padded position costs no logarithm) — and unused positions hold weight 0;
-//   * overflow part: the nonzeros beyond the K-th of a pair form an ordinary compressed matrix of the same shape (indptr /
-//     indices / f64 weights) that the existing L2-blocked gather kernel walks unchanged.
+//   * tile part: the panel is walked in tiles of T rows through a RING of B tile buffers in LDS (B T <= 192 rows of 800 B);
+//     visit v of an outer vector happens when tile v has just landed, with tiles v-B+2 .. v resident, and owns exactly K
+//     record positions; the vector's nonzeros are dealt to the positions first come first served — a nonzero of tile t may
+//     be worked at any visit t .. t+B-2 — as (ring row u8, weight f64); the weight is the whole map chain evaluated once at
+//     build time (so a padded position costs no logarithm), unused positions hold weight 0. Letting a nonzero wait for up
+//     to B-2 visits is what keeps the overflow small at a fixed number of positions per nonzero: at 3 % density, T = 48,
+//     K = 2, B = 4 leave 5.7 % of the nonzeros over (K = 4 positions per 96-row tile with two buffers: 13.5 %);
+//   * overflow part: the nonzeros no visit had room for form an ordinary compressed matrix of the same shape (indptr /
+//     indices / f64 weights) that the L2-blocked gather kernel walks unchanged.
 // product = tile kernel (this file) + gather over the overflow part, launched on two streams so that their workgroups share
-// the CUs: the tile kernel is PERSISTENT (one workgroup of 8 waves per CU, resident for the whole product, 2 x 77 KB of LDS,
-// <= 184 VGPRs so that 2 waves / SIMD leave registers for gather waves); the gather kernel's workgroups fill what is left of
-// every SIMD. The tile kernel keeps the LDS pipe and the f64 FMA pipe busy, the gather kernel the texture addresser.
+// the CUs: the tile kernel is PERSISTENT (one workgroup of 8 waves per CU, resident for the whole product, all of the LDS,
+// <= 192 VGPRs so that 2 waves / SIMD leave registers for gather waves); the gather kernel's workgroups fill what is left
+// of every SIMD. The tile kernel keeps the LDS pipe and the f64 FMA pipe busy, the gather kernel the texture addresser.
 //
 // Tile kernel: a wave owns S outer vectors ("slots") of one group for a whole item (a range of tiles): 2 f64 accumulators
 // per lane per slot (lane = column pair), every FMA destination a compile-time register because the code is unrolled over
 // the positions; the 64 lanes of a record set hold the set's positions (slot q, position j -> lane q K + j), so the serial
-// part reads them with v_readlane at immediate lanes; panel tiles are staged by LDS-DMA (global_load_lds, double buffered,
-// one barrier per tile); ds_read_b128 of position p + W is issued before the FMAs of position p (W reads in flight).
-// Sums are bit-reproducible: positions in order, tiles ascending, parts and the overflow sum added in a fixed order.
+// part reads them with v_readlane at immediate lanes (the four row bytes of a lane quad with ONE v_readlane, taken apart by
+// scalar instructions: v_readlane is the slowest instruction of the loop, profiles/microbench/issue_bench.hip); tiles are
+// staged by LDS-DMA (global_load_lds, one barrier per visit), a few chunks at a time between the positions. The positions
+// of a visit run as a software pipeline (readlane / address / ds_read_b128 / FMA of four different positions per step).
+// Sums are bit-reproducible: positions in order, visits ascending, parts and the overflow sum added in a fixed order.
 #include "common.hpp"
 #include "device_map.hpp"
 
@@ -30,123 +36,142 @@ namespace scanrs {
 
 namespace {
 
-constexpr uint32_t TL_T = 96;     // panel rows per tile
-constexpr uint32_t TL_NW = 8;     // waves per workgroup (2 per SIMD)
-constexpr uint32_t TL_LMAX = 104; // 2 x 96 x 104 x 8 B = 159744 B of LDS for the two tile buffers
-constexpr int TL_W = 6;           // LDS row reads in flight per wave
+constexpr uint32_t TL_NW = 8;          // waves per workgroup (2 per SIMD)
+constexpr uint32_t TL_LMAX = 104;      // widest panel: 192 ring rows x 104 x 8 B = 159744 B of LDS
+constexpr uint32_t TL_LDS = 160u << 10;
+constexpr int TL_W = 6;                // LDS row reads in flight per wave
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef __attribute__((address_space(3))) const char *lds_cptr_t;
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (uint32_t d = 1; d < 64u; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)v, d, 64);
-        if (lane >= d) v += t;
-    }
-    return v;
-}
+struct TileShape {
+    uint32_t T, B, K, S, sps, nset, nt, n_parts, tpp;
+};
 
 // ---- builder -------------------------------------------------------------------------------------------------------
-// One workgroup per outer vector. tb[o * (nt + 1) + t] = offset inside the vector of its first nonzero with inner index
-// >= t * TL_T; ovtot[o] = number of its nonzeros beyond the K-th of a tile.
-__global__ __launch_bounds__(256) void tile_bounds_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
-                                                          uint64_t n_outer, uint32_t nt, uint32_t K, uint32_t *__restrict__ tb,
-                                                          unsigned long long *__restrict__ ovtot) {
-    const uint64_t o = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
-    if (o >= n_outer) return;
-    const uint32_t tid = threadIdx.x;
-    const uint64_t s = indptr[o];
-    const uint32_t len = (uint32_t)(indptr[o + 1] - s);
-    uint32_t *row = tb + o * ((uint64_t)nt + 1);
-    for (uint32_t p = tid; p < len; p += 256u) {
-        const uint32_t tc = indices[s + p] / TL_T;
-        const uint32_t tp = p ? indices[s + p - 1] / TL_T + 1u : 0u;
-        for (uint32_t t = tp; t <= tc; t++) row[t] = p;
+// One thread per (outer vector, part): walks the part's nonzeros in order and deals them to visits first come first served.
+// FILL = false: counts the nonzeros left over (ovc[outer * n_parts + part]); FILL = true: writes records and overflow.
+// Record index of (group g, visit v, set b, lane): ((g nt + v) nset + b) 64 + lane, lane = q K + j for slot b sps + q.
+// The layout is STRUCTURE (this kernel: which nonzero sits where; row bytes and raw counts) and WEIGHTS (tile_weights_kernel:
+// the map chain evaluated per position) — a re-normalized handle keeps the structure and refreshes the weights in one
+// streaming pass.
+template <bool FILL>
+__global__ __launch_bounds__(256) void tile_assign_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                          const uint32_t *__restrict__ values, uint64_t n_outer, TileShape sh,
+                                                          unsigned long long *__restrict__ ovc, const unsigned long long *__restrict__ ov_off,
+                                                          uint8_t *__restrict__ prow, uint32_t *__restrict__ pcnt,
+                                                          uint32_t *__restrict__ ov_indices, uint32_t *__restrict__ ov_values) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_outer * sh.n_parts) return;
+    const uint64_t o = e / sh.n_parts;
+    const uint32_t part = (uint32_t)(e % sh.n_parts);
+    const uint32_t t0 = part * sh.tpp, t1 = min(sh.nt, t0 + sh.tpp);
+    const uint64_t s = indptr[o], end = indptr[o + 1];
+    // first nonzero of the part
+    uint64_t lo = s, hi = end;
+    const uint64_t key = (uint64_t)t0 * sh.T;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((uint64_t)indices[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
     }
-    const uint32_t tl = len ? indices[s + len - 1] / TL_T + 1u : 0u;
-    for (uint32_t t = tl + tid; t <= nt; t += 256u) row[t] = len;
-    __syncthreads();
-    uint32_t ov = 0;
-    for (uint32_t t = tid; t < nt; t += 256u) {
-        const uint32_t c = row[t + 1] - row[t];
-        ov += c > K ? c - K : 0u;
+    const uint64_t g = o / sh.S;
+    const uint32_t sl = (uint32_t)(o % sh.S), b = sl / sh.sps, q = sl % sh.sps;
+    const uint64_t idx_end = (uint64_t)t1 * sh.T;
+    uint32_t v = t0, cap = sh.K;
+    unsigned long long n_ov = 0;
+    unsigned long long op = FILL ? ov_off[e] : 0ull;
+    for (uint64_t p = lo; p < end; p++) {
+        const uint32_t idx = indices[p];
+        if ((uint64_t)idx >= idx_end) break;
+        const uint32_t tau = idx / sh.T;
+        if (tau > v) {
+            v = tau;
+            cap = sh.K;
+        }
+        if (cap == 0) {
+            v++;
+            cap = sh.K;
+        }
+        if (v > tau + sh.B - 2u || v >= t1) { // tile tau has left the ring (or the part is over): overflow
+            if (FILL) {
+                ov_indices[op] = idx;
+                ov_values[op] = values[p];
+                op++;
+            } else {
+                n_ov++;
+            }
+            continue;
+        }
+        if (FILL) {
+            const uint64_t rec = ((g * sh.nt + v) * sh.nset + b) * 64u + (uint64_t)q * sh.K + (sh.K - cap);
+            prow[rec] = (uint8_t)((tau % sh.B) * sh.T + (idx - tau * sh.T));
+            pcnt[rec] = values[p];
+        }
+        cap--;
     }
-    __shared__ uint32_t ws[4];
-    const uint32_t lane = tid & 63u;
-    ov = wave_incl_scan(ov, lane);
-    if (lane == 63u) ws[tid >> 6] = ov;
-    __syncthreads();
-    if (tid == 0) ovtot[o] = (unsigned long long)ws[0] + ws[1] + ws[2] + ws[3];
+    if (!FILL) ovc[e] = n_ov;
 }
 
-// One workgroup per outer vector: fills the vector's record positions of every tile and its overflow entries.
-// Record index of (group g, tile t, set b, lane): ((g nt + t) nset + b) 64 + lane, lane = q K + j for slot 16.. q of the set.
-__global__ __launch_bounds__(256) void tile_fill_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
-                                                        const uint32_t *__restrict__ values, const uint32_t *__restrict__ tb, uint64_t n_outer,
-                                                        uint32_t nt, uint32_t K, uint32_t S, uint32_t sps, uint32_t nset, DevMap map,
-                                                        const unsigned long long *__restrict__ ov_indptr, uint8_t *__restrict__ prow,
-                                                        double *__restrict__ pw, uint32_t *__restrict__ ov_indices, double *__restrict__ ov_w) {
-    const uint64_t o = (uint64_t)blockIdx.y * gridDim.x + blockIdx.x;
-    if (o >= n_outer) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint64_t s = indptr[o];
-    const uint32_t *row = tb + o * ((uint64_t)nt + 1);
-    const uint64_t g = o / S;
-    const uint32_t sl = (uint32_t)(o % S), b = sl / sps, q = sl % sps;
-    const unsigned long long ov0 = ov_indptr[o];
-    __shared__ uint32_t ws[4];
-    uint32_t carry = 0; // overflow entries of the tiles before this chunk (same value in every thread)
-    for (uint32_t t0 = 0; t0 < nt; t0 += 256u) {
-        const uint32_t t = t0 + tid;
-        uint32_t a = 0, c = 0;
-        if (t < nt) {
-            a = row[t];
-            c = row[t + 1] - a;
-        }
-        const uint32_t ovc = c > K ? c - K : 0u;
-        const uint32_t incl = wave_incl_scan(ovc, lane);
-        __syncthreads(); // ws of the previous chunk has been read
-        if (lane == 63u) ws[wave] = incl;
-        __syncthreads();
-        uint32_t before = carry;
-        for (uint32_t w = 0; w < wave; w++) before += ws[w];
-        before += incl - ovc;
-        carry += ws[0] + ws[1] + ws[2] + ws[3];
-        if (t < nt) {
-            const uint64_t base = ((g * nt + t) * nset + b) * 64u + (uint64_t)q * K;
-            const uint32_t kept = c < K ? c : K;
-            for (uint32_t j = 0; j < kept; j++) {
-                const uint32_t idx = indices[s + a + j];
-                prow[base + j] = (uint8_t)(idx - t * TL_T);
-                pw[base + j] = eval_map(map, values[s + a + j], (uint32_t)o, idx);
-            }
-            unsigned long long op = ov0 + before;
-            for (uint32_t j = K; j < c; j++, op++) {
-                const uint32_t idx = indices[s + a + j];
-                ov_indices[op] = idx;
-                ov_w[op] = eval_map(map, values[s + a + j], (uint32_t)o, idx);
-            }
-        }
+// an unused position reads a row that is certainly in the ring at its visit — row 0 of the visit's own tile — with weight 0
+__global__ void tile_init_rows_kernel(uint8_t *__restrict__ prow, uint64_t n_rec, TileShape sh) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // one thread per 4 records
+    if (e * 4u >= n_rec) return;
+    const uint32_t v = (uint32_t)((e * 4u / (sh.nset * 64u)) % sh.nt);
+    const uint32_t code = (v % sh.B) * sh.T;
+    reinterpret_cast<uint32_t *>(prow)[e] = code * 0x01010101u;
+}
+
+// pw[rec] = the map chain at the record's (count, outer, inner); unused positions (count 0) get weight 0
+__global__ __launch_bounds__(256) void tile_weights_kernel(const uint8_t *__restrict__ prow, const uint32_t *__restrict__ pcnt,
+                                                           double *__restrict__ pw, uint64_t n_rec, uint64_t n_outer, TileShape sh, DevMap map) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_rec) return;
+    const uint32_t cnt = pcnt[e];
+    double w = 0.0;
+    if (cnt) {
+        const uint32_t lane = (uint32_t)(e & 63u);
+        const uint64_t sv = e >> 6;
+        const uint32_t b = (uint32_t)(sv % sh.nset);
+        const uint64_t gv = sv / sh.nset;
+        const uint32_t v = (uint32_t)(gv % sh.nt);
+        const uint64_t g = gv / sh.nt;
+        const uint64_t o = g * sh.S + (uint64_t)b * sh.sps + lane / sh.K;
+        const uint32_t code = prow[e];
+        const uint32_t bufi = code / sh.T, r = code % sh.T;
+        const uint32_t d = (v % sh.B + sh.B - bufi) % sh.B; // visits the nonzero waited
+        const uint32_t inner = (v - d) * sh.T + r;
+        w = eval_map(map, cnt, (uint32_t)o, inner);
     }
+    pw[e] = w;
+}
+
+__global__ void tile_ovptr_kernel(const unsigned long long *__restrict__ ov_off, uint64_t n_outer, uint32_t n_parts,
+                                  uint64_t *__restrict__ indptr) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o <= n_outer) indptr[o] = ov_off[o * n_parts];
 }
 
 } // namespace
 
 // the tile layout of one orientation under one map
 struct TileLayout {
-    uint32_t K = 0, S = 0, sps = 0, nset = 0, n_tiles = 0;
+    TileShape sh{};
     uint64_t n_groups = 0;
-    DevBuf<uint8_t> prow; // [group][tile][set][64]
-    DevBuf<double> pw;    // same index
-    SparseCopy ov;        // the overflow part: indptr / indices / fvals (weights); `values` stays empty
-    // identity of the map the weights were evaluated under (MapOp ids are never reused)
+    DevBuf<uint8_t> prow;  // [group][visit][set][64]: ring row of the position
+    DevBuf<uint32_t> pcnt; // same index: the raw count (0 = unused position)
+    DevBuf<double> pw;     // same index: the weight under the map `sig_*`
+    SparseCopy ov;         // the overflow part: indptr / indices / values (counts) / fvals (weights)
+    // identity of the map the weights were evaluated under (MapOp ids are never reused); -1: none yet
     int sig_n = -1;
     uint32_t sig_id[MAX_OPS] = {};
     int sig_outer[MAX_OPS] = {};
-    double bytes() const { return (double)prow.n + (double)pw.n * 8.0 + (double)ov.nnz * 12.0; }
-    bool matches(const DevMap &map, uint32_t k, uint32_t s) const {
-        if (sig_n != map.n || K != k || S != s) return false;
+    double bytes() const { return (double)prow.n + (double)pcnt.n * 4.0 + (double)pw.n * 8.0 + (double)ov.nnz * 16.0; }
+    bool structure_matches(const Storage &st) const { return sh.K == st.tile_k && sh.S == st.tile_s && sh.T == st.tile_t && sh.B == st.tile_b; }
+    bool weights_match(const DevMap &map) const {
+        if (sig_n != map.n) return false;
         for (int i = 0; i < map.n; i++)
             if (sig_id[i] != map.ops[i].id || sig_outer[i] != map.ops[i].a_outer) return false;
         return true;
@@ -156,60 +181,94 @@ struct TileLayout {
 void tile_layout_free(TileLayout *t) { delete t; }
 
 uint32_t ensure_bounds_public(Storage &st, SparseCopy &cp); // kernels.hip
+void materialize_map_values(Storage &st, SparseCopy &cp, const DevMap &map, double *fout); // kernels.hip
 
-TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, const DevMap &map, uint32_t K, uint32_t S) {
+bool tile_shape_ok(uint32_t K, uint32_t S, uint32_t T, uint32_t B) {
+    const bool ks = (K == 2 && (S == 32 || S == 28)) || (K == 3 && S == 32) || (K == 4 && (S == 32 || S == 28));
+    return ks && B >= 2 && T >= 8 && T <= 24u * K && B * T <= 192;
+}
+
+TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
     Tick tick("tile layout build");
+    if (!tile_shape_ok(st.tile_k, st.tile_s, st.tile_t, st.tile_b))
+        fail(SCANRS_ERR_ARGUMENT, "unsupported tile shape K=%u S=%u T=%u B=%u", st.tile_k, st.tile_s, st.tile_t, st.tile_b);
     auto tl = std::make_unique<TileLayout>();
-    tl->K = K;
-    tl->S = S;
-    tl->sps = 64u / K;
-    tl->nset = (S + tl->sps - 1) / tl->sps;
-    tl->n_groups = (cp.n_outer + S - 1) / S;
-    tl->n_tiles = (uint32_t)((cp.n_inner + TL_T - 1) / TL_T);
-    tl->sig_n = map.n;
-    for (int i = 0; i < map.n; i++) {
-        tl->sig_id[i] = map.ops[i].id;
-        tl->sig_outer[i] = map.ops[i].a_outer;
-    }
+    TileShape &sh = tl->sh;
+    sh.K = st.tile_k;
+    sh.S = st.tile_s;
+    sh.T = st.tile_t;
+    sh.B = st.tile_b;
+    sh.sps = 64u / sh.K;
+    sh.nset = (sh.S + sh.sps - 1) / sh.sps;
+    sh.nt = (uint32_t)((cp.n_inner + sh.T - 1) / sh.T);
+    tl->n_groups = (cp.n_outer + sh.S - 1) / sh.S;
+    // items = (workgroup of TL_NW groups, part of the tile range), dealt round-robin to one persistent workgroup per CU: about
+    // 16 rounds, the part count chosen so that the last round is nearly full. A nonzero never waits across a part boundary.
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t wgg = (uint32_t)((tl->n_groups + TL_NW - 1) / TL_NW);
+    uint32_t parts = std::max<uint32_t>(1u, (uint32_t)(16ull * (uint32_t)n_cu / std::max<uint32_t>(1u, wgg)));
+    parts = std::min<uint32_t>(parts, std::max<uint32_t>(1u, sh.nt / 16u));
+    sh.tpp = (sh.nt + parts - 1) / parts;
+    sh.n_parts = (sh.nt + sh.tpp - 1) / sh.tpp;
     hipStream_t s = st.stream;
-    const uint32_t nt = tl->n_tiles;
-    const uint64_t n_rec = tl->n_groups * nt * tl->nset * 64u;
+    const uint64_t n_rec = tl->n_groups * sh.nt * sh.nset * 64u;
     if (n_rec == 0) return tl.release();
-    DevBuf<uint32_t> tb(cp.n_outer * ((uint64_t)nt + 1));
-    DevBuf<unsigned long long> ovtot(cp.n_outer + 1), ovptr(cp.n_outer + 1);
-    SCANRS_HIP(hipMemsetAsync(ovtot.p + cp.n_outer, 0, 8, s));
-    const dim3 grid((unsigned)std::min<uint64_t>(cp.n_outer, 1u << 20), (unsigned)((cp.n_outer + (1u << 20) - 1) >> 20));
-    hipLaunchKernelGGL(tile_bounds_kernel, grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.n_outer, nt, K, tb.p, ovtot.p);
+    const uint64_t n_seg = cp.n_outer * sh.n_parts;
+    DevBuf<unsigned long long> ovc(n_seg + 1), ovo(n_seg + 1);
+    SCANRS_HIP(hipMemsetAsync(ovc.p + n_seg, 0, 8, s));
+    const dim3 grid((unsigned)((n_seg + 255) / 256));
+    hipLaunchKernelGGL((tile_assign_kernel<false>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, cp.n_outer, sh, ovc.p,
+                       (const unsigned long long *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     size_t tmp_bytes = 0;
-    SCANRS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, ovtot.p, ovptr.p, 0ull, (size_t)cp.n_outer + 1, rocprim::plus<unsigned long long>(), s));
+    SCANRS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, ovc.p, ovo.p, 0ull, (size_t)n_seg + 1, rocprim::plus<unsigned long long>(), s));
     DevBuf<char> tmp(std::max<size_t>(tmp_bytes, 16));
-    SCANRS_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, ovtot.p, ovptr.p, 0ull, (size_t)cp.n_outer + 1, rocprim::plus<unsigned long long>(), s));
+    SCANRS_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, ovc.p, ovo.p, 0ull, (size_t)n_seg + 1, rocprim::plus<unsigned long long>(), s));
     unsigned long long n_ov = 0;
-    SCANRS_HIP(hipMemcpyAsync(&n_ov, ovptr.p + cp.n_outer, 8, hipMemcpyDeviceToHost, s));
+    SCANRS_HIP(hipMemcpyAsync(&n_ov, ovo.p + n_seg, 8, hipMemcpyDeviceToHost, s));
     SCANRS_HIP(hipStreamSynchronize(s));
     tl->prow.alloc(n_rec);
+    tl->pcnt.alloc(n_rec);
     tl->pw.alloc(n_rec);
-    SCANRS_HIP(hipMemsetAsync(tl->prow.p, 0, n_rec, s));
-    SCANRS_HIP(hipMemsetAsync(tl->pw.p, 0, n_rec * 8, s));
+    hipLaunchKernelGGL(tile_init_rows_kernel, dim3((unsigned)((n_rec / 4 + 255) / 256)), dim3(256), 0, s, tl->prow.p, n_rec, sh);
+    SCANRS_HIP(hipMemsetAsync(tl->pcnt.p, 0, n_rec * 4, s));
     SparseCopy &ov = tl->ov;
     ov.n_outer = cp.n_outer;
     ov.n_inner = cp.n_inner;
     ov.nnz = n_ov;
     ov.indptr.alloc(cp.n_outer + 1);
-    SCANRS_HIP(hipMemcpyAsync(ov.indptr.p, ovptr.p, (cp.n_outer + 1) * 8, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(tile_ovptr_kernel, dim3((unsigned)((cp.n_outer + 256) / 256)), dim3(256), 0, s, ovo.p, cp.n_outer, sh.n_parts, ov.indptr.p);
     ov.indices.alloc(std::max<uint64_t>(n_ov, 1));
+    ov.values.alloc(std::max<uint64_t>(n_ov, 1));
     ov.fvals.alloc(std::max<uint64_t>(n_ov, 1));
-    hipLaunchKernelGGL(tile_fill_kernel, grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, tb.p, cp.n_outer, nt, K, S, tl->sps,
-                       tl->nset, map, ovptr.p, tl->prow.p, tl->pw.p, ov.indices.p, ov.fvals.p);
+    hipLaunchKernelGGL((tile_assign_kernel<true>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, cp.n_outer, sh,
+                       (unsigned long long *)nullptr, ovo.p, tl->prow.p, tl->pcnt.p, ov.indices.p, ov.values.p);
     SCANRS_HIP(hipGetLastError());
     if (n_ov) ensure_bounds_public(st, ov);
     SCANRS_HIP(hipStreamSynchronize(s)); // the temporaries are released on return
     if (trace_on())
-        fprintf(stderr, "[scanrs trace] tile layout: %llu outer x %llu inner, K %u, S %u, %llu groups x %u tiles, nnz %llu, overflow %llu (%.1f %%), slot use %.1f %%, %.2f GB\n",
-                (unsigned long long)cp.n_outer, (unsigned long long)cp.n_inner, K, S, (unsigned long long)tl->n_groups, nt,
-                (unsigned long long)cp.nnz, (unsigned long long)n_ov, 100.0 * (double)n_ov / (double)std::max<uint64_t>(1, cp.nnz),
-                100.0 * (double)(cp.nnz - n_ov) / ((double)cp.n_outer * nt * K), tl->bytes() / 1e9);
+        fprintf(stderr, "[scanrs trace] tile layout: %llu outer x %llu inner, T %u x B %u, K %u, S %u, %llu groups x %u tiles in %u parts, nnz %llu, overflow %llu (%.1f %%), positions per nonzero %.2f, %.2f GB\n",
+                (unsigned long long)cp.n_outer, (unsigned long long)cp.n_inner, sh.T, sh.B, sh.K, sh.S, (unsigned long long)tl->n_groups, sh.nt,
+                sh.n_parts, (unsigned long long)cp.nnz, (unsigned long long)n_ov, 100.0 * (double)n_ov / (double)std::max<uint64_t>(1, cp.nnz),
+                ((double)cp.n_outer * sh.nt * sh.K) / (double)std::max<uint64_t>(1, cp.nnz), tl->bytes() / 1e9);
     return tl.release();
+}
+
+// weights of every position and of the overflow part under `map`
+static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &cp, const DevMap &map) {
+    Tick tick("tile layout weights");
+    const uint64_t n_rec = tl.prow.n;
+    if (n_rec)
+        hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st.stream, tl.prow.p, tl.pcnt.p, tl.pw.p, n_rec,
+                           cp.n_outer, tl.sh, map);
+    if (tl.ov.nnz) materialize_map_values(st, tl.ov, map, tl.ov.fvals.p);
+    SCANRS_HIP(hipGetLastError());
+    tl.sig_n = map.n;
+    for (int i = 0; i < map.n; i++) {
+        tl.sig_id[i] = map.ops[i].id;
+        tl.sig_outer[i] = map.ops[i].a_outer;
+    }
 }
 
 // ---- product -------------------------------------------------------------------------------------------------------
@@ -219,105 +278,104 @@ struct TileArgs {
     const uint8_t *prow;
     const double *pw;
     uint64_t n_groups, n_outer, n_inner;
-    uint32_t n_tiles;
+    TileShape sh;
 };
 
-// parts[part][outer][:] = sum over the part's tiles of weight * X[inner, :]
-// The VGPR cap is what lets gather waves share the SIMDs: 2 tile waves x 184 leave 144 registers per SIMD (S = 32), 2 x 168
-// leave 176 (S = 28).
+// parts[part][outer][:] = sum over the part's visits of weight * X[inner, :]
 template <int K, int S>
 __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double *__restrict__ X, uint32_t ldx, uint32_t l,
-                                               double *__restrict__ parts, uint32_t ldo, uint64_t part_stride, uint32_t n_parts,
-                                               uint32_t tiles_per_part, uint32_t n_items) {
+                                               double *__restrict__ parts, uint32_t ldo, uint64_t part_stride, uint32_t n_items) {
     constexpr int SPS = 64 / K;
     constexpr int NSET = (S + SPS - 1) / SPS;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t rowbytes = ldx * 8u;
-    const uint32_t tile_bytes = TL_T * rowbytes;
+    const uint32_t tile_bytes = ta.sh.T * rowbytes;
+    const uint32_t n_parts = ta.sh.n_parts, tpp = ta.sh.tpp, nt = ta.sh.nt, nbuf = ta.sh.B;
     const char *Xb = reinterpret_cast<const char *>(X);
     const uint64_t x_bytes = ta.n_inner * (uint64_t)rowbytes;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
 
-    // LDS-DMA staging of tile t into buffer `buf`: 1 KB per wave-instruction, chunk i of this wave. No branches (a join
-    // makes the compiler wait for ALL outstanding LDS reads at the next use): every wave issues CH chunks per tile, chunk
-    // numbers past the tile's last one repeat that one (same bytes to the same place), lanes past the end of the panel or of
-    // the tile re-read the last 16 valid bytes — the buffers are whole KBs apart, so what they write is never read.
-    constexpr int CH = (int)((TL_T * TL_LMAX * 8u / 1024u + TL_NW - 1) / TL_NW); // chunks per wave and tile
-    const uint32_t n_chunks = (tile_bytes + 1023u) / 1024u;
-    const uint32_t buf_stride = n_chunks * 1024u;
+    // LDS-DMA staging of tile t into ring buffer `buf`: 1 KB per wave-instruction, chunk i of this wave. No branches (a join
+    // makes the compiler wait for ALL outstanding LDS reads at the next use) and hand-issued for the same reason (with the
+    // builtin anywhere in the block of the position pipeline the compiler stops counting LDS reads): M0 = LDS destination of
+    // lane 0, 16 bytes per lane; lanes past the end of the tile — the next ring buffer is live — or of the panel are
+    // switched off through EXEC (all of them for a chunk or a tile that does not exist).
+    constexpr int CH = (int)((24u * K * TL_LMAX * 8u / 1024u + TL_NW - 1) / TL_NW); // chunks per wave and tile (tiles of <= 24 K rows)
     auto stage_chunk = [&](uint32_t t, uint32_t buf, uint32_t i) {
-        const uint32_t off = min(wave + i * TL_NW, n_chunks - 1u) * 1024u;
+        const uint32_t off = (wave + i * TL_NW) * 1024u;
         const uint64_t src0 = (uint64_t)t * tile_bytes;
-        const uint64_t left = x_bytes - src0; // bytes of the panel from this tile on
-        const uint32_t last16 = (left < tile_bytes ? (uint32_t)left : tile_bytes) - 16u;
-        char *dst = lds + buf * buf_stride;
-        uint32_t l16 = lane * 16u;
-        asm volatile("" : "+v"(l16)); // recomputed per chunk: the per-chunk offsets must not stay in registers across the loop
-        // Hand-issued (M0 = LDS destination of lane 0, 16 bytes per lane): with the builtin anywhere in the block of the
-        // position pipeline the compiler stops counting LDS reads and drains them all (lgkmcnt(0)) at every use.
-        const uint32_t m0v = (uint32_t)(uintptr_t)(lds_ptr_t)(dst + off);
-        const uint32_t voff32 = min(off + l16, last16);
+        const uint64_t left = x_bytes > src0 ? x_bytes - src0 : 0ull; // bytes of the panel from this tile on
+        const uint32_t limit = left < tile_bytes ? (uint32_t)left : tile_bytes;
+        const uint32_t m0v = lds0 + buf * tile_bytes + off;
+        uint32_t voff = off + lane * 16u;
         const char *sbase = Xb + src0;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff32), "s"(sbase) : "memory");
+        uint64_t saved;
+        asm volatile("s_mov_b64 %0, exec\n\t"
+                     "v_cmpx_gt_u32_e32 vcc, %1, %2\n\t"
+                     "s_mov_b32 m0, %3\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %2, %4\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(saved)
+                     : "s"(limit), "v"(voff), "s"(m0v), "s"(sbase)
+                     : "memory", "vcc");
     };
     const uint32_t lcol16 = (lane * 2u < l ? lane : 0u) * 16u;
+    const lds_cptr_t ring = (lds_cptr_t)(lds + lcol16);
+    uint32_t rowbytes_v = rowbytes;
+    asm volatile("" : "+v"(rowbytes_v)); // a vector register: v_mad_u32_u24 takes one scalar operand
+    // record rows are bytes; a lane loads the aligned dword that holds the four row bytes of its quad
+    const uint32_t *prow32 = reinterpret_cast<const uint32_t *>(ta.prow);
 
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint32_t part = item % n_parts, wgg = item / n_parts;
-        const uint32_t t0 = part * tiles_per_part, t1 = min(ta.n_tiles, t0 + tiles_per_part);
+        const uint32_t t0 = part * tpp, t1 = min(nt, t0 + tpp);
         const uint64_t group_raw = (uint64_t)wgg * TL_NW + wave;
         const bool live = group_raw < ta.n_groups;
         const uint64_t group = live ? group_raw : ta.n_groups - 1; // idle waves shadow the last group (they still stage tiles and meet the barriers)
-        __syncthreads(); // everyone is done with the buffers of the previous item
-        if (t0 < t1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // everyone is done with the ring of the previous item
+        uint32_t bufn = t0 % nbuf; // ring buffer of the tile being staged
 #pragma unroll
-            for (int i = 0; i < CH; i++) stage_chunk(t0, 0, i);
-        }
+        for (int i = 0; i < CH; i++) stage_chunk(t0, bufn, i);
 
         d2 acc[S];
 #pragma unroll
         for (int sl = 0; sl < S; sl++) acc[sl] = (d2){0.0, 0.0};
 
-        const size_t vbase = (size_t)group * ta.n_tiles;
-        // record rows are bytes; a lane loads the aligned dword that holds its byte and extracts it when the set is worked
-        // (a byte load is zero-extended right behind the load, and that wait would also cover the tile's LDS-DMA)
-        const uint32_t *prow32 = reinterpret_cast<const uint32_t *>(ta.prow);
-        const uint32_t rsh = (lane & 3u) * 8u;
+        const size_t vbase = (size_t)group * nt;
         uint32_t crow[NSET], nrow[NSET];
         double cw[NSET], nw[NSET];
 #pragma unroll
         for (int b = 0; b < NSET; b++) {
-            crow[b] = 0;
-            cw[b] = 0.0;
-            if (t0 < t1) {
-                crow[b] = prow32[((vbase + t0) * NSET + b) * 16u + (lane >> 2)];
-                cw[b] = ta.pw[((vbase + t0) * NSET + b) * 64u + lane];
-            }
+            crow[b] = prow32[((vbase + t0) * NSET + b) * 16u + (lane >> 2)];
+            cw[b] = ta.pw[((vbase + t0) * NSET + b) * 64u + lane];
         }
 
         for (uint32_t t = t0; t < t1; t++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's LDS-DMA chunks of tile t (the compiler does not see them)
-            __syncthreads(); // tile t is in buffer (t - t0) & 1; everyone is done with the other buffer
-            const lds_cptr_t tile = (lds_cptr_t)(lds + ((t - t0) & 1u) * buf_stride + lcol16);
-            const uint32_t tn = t + 1 < t1 ? t + 1 : t; // the last visit of an item re-loads itself: no branch in the loop
-            // the next tile's records: nothing in this visit waits for them
+            __syncthreads(); // tile t is in the ring; everyone is done with visit t - 1, so the buffer of tile t + 1 - B is free
+            bufn = bufn + 1u == nbuf ? 0u : bufn + 1u;
+            const uint32_t tr = t + 1 < t1 ? t + 1 : t; // the last visit of an item re-loads its own records: no branch in the loop
+            // the next visit's records: nothing in this visit waits for them
 #pragma unroll
             for (int b = 0; b < NSET; b++) {
-                nrow[b] = prow32[((vbase + tn) * NSET + b) * 16u + (lane >> 2)];
-                nw[b] = ta.pw[((vbase + tn) * NSET + b) * 64u + lane];
+                nrow[b] = prow32[((vbase + tr) * NSET + b) * 16u + (lane >> 2)];
+                nw[b] = ta.pw[((vbase + tr) * NSET + b) * 64u + lane];
             }
             // The visit's S K positions as one software pipeline over position g (set g / (SPS K), lane g % (SPS K)): per step
-            //   R(g)          three v_readlane: row offset and the weight's halves into SGPRs
+            //   R(g)          v_readlane: the weight's halves (and, every 4th position, the quad's row bytes) into SGPRs; row
+            //                 byte -> ring offset by scalar instructions
             //   A(g - 1)      LDS address of the row
             //   L(g - 2)      ds_read_b128 of the row
             //   F(g - 2 - W)  the two FMAs
             // so that no instruction of a step depends on another one of the same step (a wave issues in order and two waves
             // share a SIMD: dependent neighbours leave the vector unit idle), and the next tile's LDS-DMA chunks are issued a
             // few at a time between the steps instead of as one burst that queues on the texture path.
-            uint32_t voff[NSET], wlo[NSET], whi[NSET];
+            uint32_t wlo[NSET], whi[NSET];
 #pragma unroll
             for (int b = 0; b < NSET; b++) {
-                voff[b] = ((crow[b] >> rsh) & 255u) * rowbytes;
                 wlo[b] = (uint32_t)__double2loint(cw[b]);
                 whi[b] = (uint32_t)__double2hiint(cw[b]);
             }
@@ -325,6 +383,7 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
             constexpr int NPT = S * K;        // positions per visit
             constexpr int WR = TL_W + 3;      // weights live from R(g) to F(g)
             constexpr int DM = NPT / CH;      // steps between two LDS-DMA chunks
+            uint32_t rows4 = 0;
             uint32_t offs[2];
             lds_cptr_t addr[2];
             double wq[WR];
@@ -345,15 +404,19 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
                 }
                 if (i >= 1 && i - 1 < NPT) { // A(i - 1)
                     const int g = i - 1;
-                    addr[g % 2] = tile + offs[g % 2];
-                    asm volatile("" : "+v"(addr[g % 2])); // the address now, not in front of the read
+                    // ring + row byte * rowbytes in one vector instruction (the address now, not in front of the read)
+                    asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr[g % 2]) : "s"(offs[g % 2]), "v"(rowbytes_v), "v"(ring));
                 }
                 if (i < NPT) { // R(i)
                     const int b = i / PPS, p = i % PPS;
-                    offs[i % 2] = rdlane(voff[b], p);
+                    if (p % 4 == 0) {
+                        asm volatile("" : "+v"(crow[b])); // read the quad's row bytes here, not 64 steps early (they would fill the SGPR file)
+                        rows4 = rdlane(crow[b], p);
+                    }
+                    offs[i % 2] = (rows4 >> (8 * (p % 4))) & 255u;
                     wq[i % WR] = __hiloint2double((int)rdlane(whi[b], p), (int)rdlane(wlo[b], p));
                 }
-                if (i % DM == DM / 2 && i / DM < CH) stage_chunk(tn, (t + 1 - t0) & 1u, i / DM);
+                if (i % DM == DM / 2 && i / DM < CH) stage_chunk(t + 1, bufn, i / DM);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -375,36 +438,37 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
 }
 
 template <int K, int S>
-__global__ __launch_bounds__(64 * TL_NW, 2) void spmm_tile_kernel(
-    TileArgs ta, const double *__restrict__ X, uint32_t ldx, uint32_t l, double *__restrict__ parts, uint32_t ldo, uint64_t part_stride,
-    uint32_t n_parts, uint32_t tiles_per_part, uint32_t n_items) {
-    spmm_tile_body<K, S>(ta, X, ldx, l, parts, ldo, part_stride, n_parts, tiles_per_part, n_items);
+__global__ __launch_bounds__(64 * TL_NW, 2) void spmm_tile_kernel(TileArgs ta, const double *__restrict__ X, uint32_t ldx, uint32_t l,
+                                                                  double *__restrict__ parts, uint32_t ldo, uint64_t part_stride,
+                                                                  uint32_t n_items) {
+    spmm_tile_body<K, S>(ta, X, ldx, l, parts, ldo, part_stride, n_items);
 }
+// <= 168 VGPRs: 2 tile waves + 2 gather waves of 88 per SIMD
 template <int K, int S>
 __global__ __launch_bounds__(64 * TL_NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void spmm_tile_kernel_r168(
     TileArgs ta, const double *__restrict__ X, uint32_t ldx, uint32_t l, double *__restrict__ parts, uint32_t ldo, uint64_t part_stride,
-    uint32_t n_parts, uint32_t tiles_per_part, uint32_t n_items) {
-    spmm_tile_body<K, S>(ta, X, ldx, l, parts, ldo, part_stride, n_parts, tiles_per_part, n_items);
+    uint32_t n_items) {
+    spmm_tile_body<K, S>(ta, X, ldx, l, parts, ldo, part_stride, n_items);
 }
 
 // out[o, :] = sum over parts (in order) + overflow sum + LowRankOffset term  (sqz/src/low_rank_offset.rs:76-80)
 __global__ __launch_bounds__(256) void tile_finish_kernel(const double *__restrict__ parts, uint32_t n_parts, uint64_t part_stride,
-                                                          const double *__restrict__ ovout, uint64_t n_outer, uint32_t l, uint32_t ldo,
-                                                          double *__restrict__ out, const double *__restrict__ off_a, uint32_t rank,
+                                                          const double *__restrict__ ovout, uint64_t n_outer, uint32_t l, uint32_t ldp,
+                                                          uint32_t ldo, double *__restrict__ out, const double *__restrict__ off_a, uint32_t rank,
                                                           const double *__restrict__ off_w, uint32_t ldw) {
     const uint32_t hp = (l + 1u) / 2u; // column pairs
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_outer * hp) return;
     const uint64_t o = e / hp;
     const uint32_t c = (uint32_t)(e % hp) * 2u;
-    d2 s = *reinterpret_cast<const d2 *>(parts + o * ldo + c);
+    d2 s = *reinterpret_cast<const d2 *>(parts + o * ldp + c);
     for (uint32_t p = 1; p < n_parts; p++) {
-        const d2 t = *reinterpret_cast<const d2 *>(parts + (size_t)p * part_stride + o * ldo + c);
+        const d2 t = *reinterpret_cast<const d2 *>(parts + (size_t)p * part_stride + o * ldp + c);
         s.x += t.x;
         s.y += t.y;
     }
     if (ovout) {
-        const d2 t = *reinterpret_cast<const d2 *>(ovout + o * ldo + c);
+        const d2 t = *reinterpret_cast<const d2 *>(ovout + o * ldp + c);
         s.x += t.x;
         s.y += t.y;
     }
@@ -418,51 +482,78 @@ __global__ __launch_bounds__(256) void tile_finish_kernel(const double *__restri
 
 template <int K, int S>
 void launch_tile_kernel(Storage &st, const TileArgs &ta, const double *X, uint32_t ldx, uint32_t l, double *parts, uint32_t ldo,
-                        uint64_t part_stride, uint32_t n_parts, uint32_t tpp, uint32_t n_items, uint32_t grid) {
-    const size_t shmem = (size_t)2 * ((TL_T * ldx * 8 + 1023u) / 1024u) * 1024u;
+                        uint64_t part_stride, uint32_t n_items, uint32_t grid) {
+    const size_t shmem = (size_t)ta.sh.B * ta.sh.T * ldx * 8;
     if constexpr (S <= 28) {
         SCANRS_HIP(hipFuncSetAttribute((const void *)spmm_tile_kernel_r168<K, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL((spmm_tile_kernel_r168<K, S>), dim3(grid), dim3(64 * TL_NW), shmem, st.stream, ta, X, ldx, l, parts, ldo, part_stride,
-                           n_parts, tpp, n_items);
+                           n_items);
     } else {
         SCANRS_HIP(hipFuncSetAttribute((const void *)spmm_tile_kernel<K, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
         hipLaunchKernelGGL((spmm_tile_kernel<K, S>), dim3(grid), dim3(64 * TL_NW), shmem, st.stream, ta, X, ldx, l, parts, ldo, part_stride,
-                           n_parts, tpp, n_items);
+                           n_items);
     }
 }
 
 } // namespace
 
-bool spmm_tiles_ok(const SparseCopy &cp, uint32_t ldx, uint32_t l) {
-    return l >= 16 && l <= TL_LMAX && ldx <= TL_LMAX && (ldx & 1u) == 0 && cp.n_outer > 0 && cp.n_inner > 0 && cp.nnz > 0;
+bool spmm_tiles_ok(const Storage &st, const SparseCopy &cp, uint32_t ldx, uint32_t l) {
+    return l >= 16 && l <= TL_LMAX && (ldx & 1u) == 0 && cp.n_outer > 0 && cp.n_inner > 0 && cp.nnz > 0 &&
+           (size_t)st.tile_b * st.tile_t * even_up(l) * 8 <= TL_LDS;
 }
-bool tile_shape_ok(uint32_t K, uint32_t S) { return (K == 4 && (S == 32 || S == 28)) || (K == 3 && S == 32) || (K == 2 && S == 32); }
+
+// Auto path (spmm_path 0): the hybrid product serves a large matrix once its layout under this map exists — built when a
+// solver announces many products (Storage::tile_hint) or when the same map comes by a second time, and only if the device
+// has room for it (about 18 bytes per nonzero per orientation).
+bool spmm_tiles_auto(Storage &st, SparseCopy &cp, const DevMap &map) {
+    if (!st.tile_auto || cp.nnz < std::max<uint64_t>(st.blocked_min_nnz, 1ull << 24)) return false;
+    if (cp.tiles && cp.tiles->structure_matches(st)) return true; // the weights follow the map in one streaming pass
+    bool seen = cp.tsig_n == map.n;
+    for (int i = 0; seen && i < map.n; i++) seen = cp.tsig_id[i] == map.ops[i].id && cp.tsig_outer[i] == map.ops[i].a_outer;
+    cp.tsig_n = map.n;
+    for (int i = 0; i < map.n; i++) {
+        cp.tsig_id[i] = map.ops[i].id;
+        cp.tsig_outer[i] = map.ops[i].a_outer;
+    }
+    if (!seen && st.tile_hint <= 0) return false;
+    // room: records (9 B per position) + overflow + the build's temporaries + the partial-sum buffers, and 8 GB for the solver
+    const double nt = (double)((cp.n_inner + st.tile_t - 1) / st.tile_t);
+    const double need = 13.0 * 64.0 * (double)((cp.n_outer + st.tile_s - 1) / st.tile_s) * nt * ((st.tile_s + 64 / st.tile_k - 1) / (64 / st.tile_k)) +
+                        0.2 * 12.0 * (double)cp.nnz + 32.0 * (double)cp.n_outer * 64.0 + 2.0 * (double)cp.n_outer * 104.0 * 8.0 * 2.0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    const double have = (double)free_b + (cp.tiles ? cp.tiles->bytes() : 0.0); // a stale layout is released first
+    return have > need + 8.0 * (double)(1ull << 30);
+}
 
 void launch_gather2d_ov(Storage &st, hipStream_t s, SparseCopy &ov, const double *X, uint32_t ldx, uint32_t l, double *out, uint32_t ldo); // kernels.hip
 
 void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l, double *out,
                        uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw) {
     if ((ldx & 1u) || (ldo & 1u)) fail(SCANRS_ERR_ARGUMENT, "panel leading dimensions must be even");
-    const uint32_t K = st.tile_k, S = st.tile_s;
-    if (!cp.tiles || !cp.tiles->matches(map, K, S)) {
+    if (!cp.tiles || !cp.tiles->structure_matches(st)) {
         cp.tiles.reset(); // free the old layout before the new one is allocated
-        cp.tiles.reset(tile_layout_build(st, cp, map, K, S), tile_layout_free);
+        cp.tiles.reset(tile_layout_build(st, cp), tile_layout_free);
     }
     TileLayout &tl = *cp.tiles;
+    if (!tl.weights_match(map)) tile_layout_weights(st, tl, cp, map);
+    const TileShape &sh = tl.sh;
+    // the kernels want compact panel rows (a tile is one contiguous run of bytes): a block of a wider panel is copied first
+    const uint32_t ldc = even_up(l);
+    if (ldx != ldc) {
+        double *xc = st.scratch.get<double>("tile_xc", (size_t)cp.n_inner * ldc);
+        launch_copy_cols(st, X, ldx, xc, ldc, cp.n_inner, l);
+        X = xc;
+        ldx = ldc;
+    }
     int dev = 0, n_cu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t wgg = (uint32_t)((tl.n_groups + TL_NW - 1) / TL_NW);
-    // items = (workgroup of groups, part of the tile range), dealt round-robin to one persistent workgroup per CU: about 16
-    // rounds, the part count chosen so that the last round is nearly full
-    uint32_t parts = std::max<uint32_t>(1u, (uint32_t)(16ull * (uint32_t)n_cu / wgg));
-    parts = std::min<uint32_t>(parts, std::max<uint32_t>(1u, tl.n_tiles / 8u));
-    const uint32_t tpp = (tl.n_tiles + parts - 1) / parts;
-    parts = (tl.n_tiles + tpp - 1) / tpp;
-    const uint32_t n_items = wgg * parts;
+    const uint32_t n_items = wgg * sh.n_parts;
     const uint32_t grid = std::min<uint32_t>(n_items, (uint32_t)n_cu);
-    const uint64_t part_stride = cp.n_outer * (uint64_t)ldo;
-    double *pbuf = st.scratch.get<double>("tile_parts", (size_t)parts * part_stride);
+    const uint64_t part_stride = cp.n_outer * (uint64_t)ldc; // partial sums and the overflow sum in compact rows of ldc columns
+    double *pbuf = st.scratch.get<double>("tile_parts", (size_t)sh.n_parts * part_stride);
     double *ovout = nullptr;
     if (tl.ov.nnz) { // the overflow part through the texture path, beside the tile kernel
         ovout = st.scratch.get<double>("tile_ovout", (size_t)part_stride);
@@ -470,35 +561,37 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
             hipStream_t ovs = st.ov();
             SCANRS_HIP(hipEventRecord(st.ev_in, st.stream)); // the panel (and the scratch zero-fills) are ready
             SCANRS_HIP(hipStreamWaitEvent(ovs, st.ev_in, 0));
-            launch_gather2d_ov(st, ovs, tl.ov, X, ldx, l, ovout, ldo);
+            launch_gather2d_ov(st, ovs, tl.ov, X, ldx, l, ovout, ldc);
             SCANRS_HIP(hipEventRecord(st.ev_ov, ovs));
         } else {
-            launch_gather2d_ov(st, st.stream, tl.ov, X, ldx, l, ovout, ldo);
+            launch_gather2d_ov(st, st.stream, tl.ov, X, ldx, l, ovout, ldc);
         }
     }
-    TileArgs ta{tl.prow.p, tl.pw.p, tl.n_groups, cp.n_outer, cp.n_inner, tl.n_tiles};
+    TileArgs ta{tl.prow.p, tl.pw.p, tl.n_groups, cp.n_outer, cp.n_inner, sh};
     const double bytes = tl.bytes() + (double)cp.n_inner * l * 8.0 + (double)cp.n_outer * l * 8.0;
     const bool long_outer = cp.n_outer >= cp.n_inner;
     if (st.prof.on)
         st.prof.begin(st.stream, long_outer ? "spmm_tile_kernel/long-outer" : "spmm_tile_kernel/short-outer", bytes,
-                      (double)tl.n_groups * tl.n_tiles * S * K * 8.0 * l);
-#define SCANRS_TILE(KK, SS) launch_tile_kernel<KK, SS>(st, ta, X, ldx, l, pbuf, ldo, part_stride, parts, tpp, n_items, grid)
-    if (K == 4 && S == 32)
-        SCANRS_TILE(4, 32);
-    else if (K == 4 && S == 28)
-        SCANRS_TILE(4, 28);
-    else if (K == 3 && S == 32)
-        SCANRS_TILE(3, 32);
-    else if (K == 2 && S == 32)
+                      (double)tl.n_groups * sh.nt * sh.S * sh.K * 8.0 * l);
+#define SCANRS_TILE(KK, SS) launch_tile_kernel<KK, SS>(st, ta, X, ldx, l, pbuf, ldc, part_stride, n_items, grid)
+    if (sh.K == 2 && sh.S == 32)
         SCANRS_TILE(2, 32);
+    else if (sh.K == 2 && sh.S == 28)
+        SCANRS_TILE(2, 28);
+    else if (sh.K == 3 && sh.S == 32)
+        SCANRS_TILE(3, 32);
+    else if (sh.K == 4 && sh.S == 32)
+        SCANRS_TILE(4, 32);
+    else if (sh.K == 4 && sh.S == 28)
+        SCANRS_TILE(4, 28);
     else
-        fail(SCANRS_ERR_ARGUMENT, "unsupported tile shape K=%u S=%u", K, S);
+        fail(SCANRS_ERR_ARGUMENT, "unsupported tile shape K=%u S=%u", sh.K, sh.S);
 #undef SCANRS_TILE
     if (st.prof.on) st.prof.end(st.stream);
     if (ovout && st.tile_overlap) SCANRS_HIP(hipStreamWaitEvent(st.stream, st.ev_ov, 0));
     const uint64_t n = cp.n_outer * (uint64_t)((l + 1u) / 2u);
-    hipLaunchKernelGGL(tile_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, pbuf, parts, part_stride, ovout,
-                       cp.n_outer, l, ldo, out, off_a, rank, off_w, ldw);
+    hipLaunchKernelGGL(tile_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, pbuf, sh.n_parts, part_stride, ovout,
+                       cp.n_outer, l, ldc, ldo, out, off_a, rank, off_w, ldw);
     SCANRS_HIP(hipGetLastError());
 }
 

@@ -500,13 +500,13 @@ def test_blocked_kernel_matches_gather_and_oracle(sa, storage):
 
 
 @pytest.mark.parametrize("storage", [so.CSR, so.CSC])
-@pytest.mark.parametrize("tile_k,tile_s", [(4, 32), (3, 32), (2, 32), (4, 28)])
-def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_s):
-    """spmm path 3 (tiles.hip: the hybrid product — panel tiles staged in LDS over K fixed record positions per (outer vector,
-    tile) with materialized weights, and the L2-blocked gather over the nonzeros that overflow them, on two streams) against the
-    plain gather kernel and the oracle: shapes around the slot (32) / workgroup (256) / tile (96) edges, empty vectors, dense
-    spots that fill the overflow part, matrices with no overflow at all, with and without the rank-r offset, panel widths
-    16 .. 104 (other widths fall through to path 2)."""
+@pytest.mark.parametrize("tile_k,tile_s,tile_t,tile_b", [(2, 32, 48, 4), (2, 28, 48, 4), (2, 32, 24, 8), (3, 32, 64, 3), (4, 32, 96, 2), (4, 28, 40, 3)])
+def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_s, tile_t, tile_b):
+    """spmm path 3 (tiles.hip: the hybrid product — panel tiles staged through a ring of LDS buffers, K fixed record positions
+    per (outer vector, visit) dealt first come first served with materialized weights, and the L2-blocked gather over the
+    nonzeros no visit had room for, on two streams) against the plain gather kernel and the oracle: shapes around the slot
+    (32) / workgroup (256) / tile edges, empty vectors, dense spots that fill the overflow part, matrices with no overflow at
+    all, with and without the rank-r offset, panel widths 16 .. 104 (other widths fall through to path 2)."""
     rng = np.random.default_rng(31 + storage)
     for rows, cols, fill in ((1, 1, 1.0), (31, 95, 0.5), (32, 96, 0.3), (33, 97, 0.9), (257, 200, 0.05), (700, 1000, 0.03),
                              (97, 5000, 0.02), (2000, 193, 0.2), (300, 400, 0.004)):
@@ -516,7 +516,7 @@ def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_
         g1, o = pair(sa, dense, storage)
         g3, _ = pair(sa, dense, storage)
         g1.set_spmm_path(1)
-        g3.set_spmm_path(3).set_option("tile_k", tile_k).set_option("tile_s", tile_s)
+        g3.set_spmm_path(3).set_option("tile_k", tile_k).set_option("tile_s", tile_s).set_option("tile_t", tile_t).set_option("tile_b", tile_b)
         f = rng.random(cols) + 0.5
         fr = rng.random(rows) + 0.5
         for gm in (g1, g3):
@@ -957,50 +957,6 @@ def test_default_seed_panel_is_the_sequential_stream(sa):
         for x, y in zip(a, e):
             assert np.array_equal(x, y)
 
-
-
-@pytest.mark.parametrize("knobs", [{"SCANRS_PERSIST_SLACK": "1", "SCANRS_PERSIST_TILE_KB": "64"},
-                                   {"SCANRS_PERSIST_SLACK": "0", "SCANRS_PERSIST_TILE_KB": "64"},
-                                   {"SCANRS_PERSIST_SLACK": "3", "SCANRS_PERSIST_TILE_KB": "200"},
-                                   {"SCANRS_PERSIST_SLACK": "1", "SCANRS_PERSIST_TILE_KB": "1536"}])
-def test_persistent_gather_matches_the_multi_launch_form(sa, monkeypatch, knobs):
-    """SCANRS_SPMM_PERSIST=1: one launch per product on the copy with few, long outer vectors — every wave owns a fixed
-    set of vectors and keeps their sums in registers across the L2 steps; the steps in flight are held together by
-    counters that carry no data. Nonzeros of a vector are added in the same order as by the per-step launches, so the
-    two forms agree bit for bit; both agree with the oracle (map with an inner-indexed scale, rank-1 offset)."""
-    rng = np.random.default_rng(78)
-    dense = random_counts(rng, 70, 9000, 0.03, 30)
-    dense[3, :] = rng.integers(1, 9, size=9000)
-    dense[40, :] = 0
-    f = rng.random(9000) + 0.5
-    u, v = rng.standard_normal((70, 1)), rng.standard_normal((1, 9000))
-
-    def build(persist, storage):
-        monkeypatch.setenv("SCANRS_SPMM_PERSIST", "1" if persist else "0")
-        monkeypatch.setenv("SCANRS_HOT_SEGMENT", "0")  # the multi-launch form then adds a vector's nonzeros in one wave too
-        for k_, v_ in knobs.items():
-            monkeypatch.setenv(k_, v_)  # read when a handle is created
-        g, o = pair(sa, dense + 0, storage)
-        g.set_spmm_path(2)
-        g.compose_scale_axis(1, f).apply(sa.FN_LOG2_1P)
-        o = o.compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=1, a=f)).apply(so.OP_LOG2_1P)
-        g.set_offset(u, v)
-        return g, so.LowRankOffset(o, u, v)
-
-    for storage in (so.CSR, so.CSC):
-        gp, lo = build(True, storage)
-        gm, _ = build(False, storage)
-        gp.profile_enable(True)
-        for l in (6, 100, 128, 200):
-            q = rng.standard_normal((9000, l))     # out rows = 70: the copy with 70 outer vectors of 9000 -> persistent form
-            a = gp.dot(q)
-            assert np.array_equal(a, gm.dot(q))
-            assert np.array_equal(a, gp.dot(q))
-            assert_close(a, lo.dot(q), rtol=1e-10, atol=1e-8)
-            ql = rng.standard_normal((l, 70))      # the other orientation stays on the multi-launch form
-            assert np.array_equal(gp.rdot(ql), gm.rdot(ql))
-        names = set(gp.profile_get())
-        assert any("persist" in n for n in names), names
 
 
 def test_materialized_map_values_are_bit_identical_and_never_stale(sa, monkeypatch):

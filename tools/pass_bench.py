@@ -1,6 +1,6 @@
 """Time of one sparse pass (b-wide product) in both orientations under the CellRanger map (scale, log2, centre / scale),
-for a list of product configurations: `path[:tile_k:tile_s]`, e.g. `0 3:4:32 3:3:32` (0 = default, 2 = L2-blocked gather,
-3 = hybrid LDS tiles + gather). usage: pass_bench.py [cells] [l] config..."""
+for a list of product configurations: `path[:tile_k:tile_s:tile_t:tile_b:overlap]`, e.g. `0 3:2:32:48:4` (0 = default,
+2 = L2-blocked gather, 3 = hybrid LDS tiles + gather). usage: pass_bench.py [cells] [l] config..."""
 import os
 import sys
 import time
@@ -28,14 +28,8 @@ for cfg in configs:
     parts = [int(x) for x in cfg.split(":")]
     m = sa.AdaptiveMat.from_device(genes, cells, sa.CSC, ip.data_ptr(), ix.data_ptr(), vv.data_ptr())
     m.set_spmm_path(parts[0])
-    if len(parts) > 1:
-        m.set_option("tile_k", parts[1])
-    if len(parts) > 2:
-        m.set_option("tile_s", parts[2])
-    if len(parts) > 3:
-        m.set_option("tile_overlap", parts[3])
-    if len(parts) > 4:
-        m.set_option("tile_ablate", parts[4])
+    for key, val in zip(("tile_k", "tile_s", "tile_t", "tile_b", "tile_overlap"), parts[1:]):
+        m.set_option(key, val)
     sa.normalize(m, sa.Normalization.CellRanger)
 
     def t(fn, reps=5):
