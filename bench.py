@@ -12,9 +12,10 @@ range-partitioned over the ranks by nonzeros (scanrs_plan_shards; strong scaling
 library (RCCL over xGMI, `scanrs_comm_*`), torch.distributed (gloo) is only the control plane (id broadcast, barriers,
 max over ranks). Rank 0 prints ONE JSON line.
 
-`value` is the device-resident rate (U and V left in HBM, reachable through scanrs_pca_result_device);
-`config.host_delivered_cells_per_s` is the rate of a step that also copies U and V to host arrays, as the reference's
-run_pca signature returns them. Also reported: roofline — HBM roofline of the dominant kernel, algorithmic bytes per
+`value` is what a caller of `run_pca` gets: the rate of steps that return U, sigma and V as host arrays, as the reference's
+signature does (scan-rs/src/dim_red/mod.rs:47); `config.device_resident_cells_per_s` is the rate with U and V left in HBM
+(scanrs_pca_result_device) for device-side consumers, `config.first_call_s` the cold create -> normalize -> run_pca on a
+fresh handle (the transposed copy and the tile layouts of the hybrid product are built there). Also reported: roofline — HBM roofline of the dominant kernel, algorithmic bytes per
 launch / average launch duration measured with HIP events on the library's stream; cpu_baseline — the CPU oracle
 (port of the reference's serial schedule) on 1 core and on all cores, bounded samples, rank 0 at N = 1 only.
 """
@@ -29,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-PMC_PROFILE = "r02d_pmc_traffic.json"  # committed PMC passes (separate --pmc runs) the `traffic` field is read from
+PMC_PROFILE = "r03_pmc_traffic.json"  # committed PMC passes (separate --pmc runs) the `traffic` field is read from
 
 
 def parse():
@@ -45,7 +46,7 @@ def parse():
     ap.add_argument("--cpu-cells", type=int, default=16000, help="cells of the 1-core CPU-baseline sample")
     ap.add_argument("--cpu-cells-all", type=int, default=100000, help="cells of the all-core CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-delivery", action="store_true", help="skip the extra step that copies U and V to the host")
+    ap.add_argument("--no-host-delivery", action="store_true", help="leave U and V in HBM in every step (value is then the device-resident rate)")
     ap.add_argument("--f32-panels", action="store_true",
                     help="opt-in fast mode: gathered panels rounded to f32, f64 sums (NOT the headline configuration)")
     ap.add_argument("--spmm-path", type=int, default=0, help="0 auto, 1 plain gather, 2 L2-blocked gather")
@@ -60,6 +61,31 @@ def parse():
     ap.add_argument("--sqz-bench", action="store_true",
                     help="instead: the reference's only benchmark (sqz/benches/my_benchmark.rs): u32 CSR / CSC 1000 x 10000 times 10000 x 16")
     return ap.parse_args()
+
+
+class Watchdog:
+    """Every rank: if no stage marker is set for `limit` seconds, print where every stage started and leave with a non-zero
+    code (os._exit: the main thread may be stuck inside a collective) — a hung multi-rank run ends with a reason, not a kill."""
+
+    def __init__(self, rank, limit):
+        import threading
+
+        self.rank, self.limit, self.stages, self.done = rank, limit, [("start", time.time())], False
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def stage(self, name):
+        self.stages.append((name, time.time()))
+
+    def _run(self):
+        while not self.done:
+            time.sleep(2.0)
+            name, t = self.stages[-1]
+            if time.time() - t > self.limit and not self.done:
+                t0 = self.stages[0][1]
+                trail = "; ".join(f"{n} @ {tt - t0:.1f}s" for n, tt in self.stages[-12:])
+                sys.stderr.write(f"[bench rank {self.rank}] WATCHDOG: stage '{name}' has run for more than {self.limit:.0f} s — {trail}\n")
+                sys.stderr.flush()
+                os._exit(3)
 
 
 def self_launch(args):
@@ -145,7 +171,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
 
-    def dbg(msg):  # SCANRS_BENCH_DEBUG=1: stage markers on stderr (where does a multi-rank run stop?)
+    wd = Watchdog(rank, float(os.environ.get("SCANRS_BENCH_WATCHDOG_S", "600")))
+
+    def dbg(msg):  # stage markers: kept for the watchdog, printed with SCANRS_BENCH_DEBUG=1 (where does a multi-rank run stop?)
+        wd.stage(msg)
         if os.environ.get("SCANRS_BENCH_DEBUG"):
             print(f"[bench rank {rank}] {msg} t={time.time():.3f}", file=sys.stderr, flush=True)
 
@@ -157,6 +186,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    free_at_start = torch.cuda.mem_get_info(dev)[0]
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -184,7 +214,20 @@ def main():
     lo, hi = shard_bounds(args.cells, world)[rank]
     t0 = time.time()
     dbg("datagen")
-    indptr, indices, values = synth_counts_torch(args.cells, args.genes, args.density, args.seed, dev, lo, hi)
+    def generate(lo_, hi_):
+        # ranks that share one GPU (test mode) take turns: four processes generating at once on one device were measured
+        # ~170x slower than one after the other (172 s instead of ~1 s for 50 k cells each; round 2's "hung" runs were this)
+        if shared_gpu and dist is not None:
+            out = None
+            for r in range(world):
+                if r == rank:
+                    out = synth_counts_torch(args.cells, args.genes, args.density, args.seed, dev, lo_, hi_)
+                    torch.cuda.synchronize()
+                dist.barrier()
+            return out
+        return synth_counts_torch(args.cells, args.genes, args.density, args.seed, dev, lo_, hi_)
+
+    indptr, indices, values = generate(lo, hi)
     dbg("datagen done")
     if world > 1:
         # scanrs_plan_shards on the global per-cell counts (every rank holds the counts of its equal-count range)
@@ -201,11 +244,14 @@ def main():
         np.cumsum(allc, out=gip[1:])
         bounds = sa.plan_shards(gip, world)
         nlo, nhi = int(bounds[rank]), int(bounds[rank + 1])
-        if (nlo, nhi) != (lo, hi):
+        moved = torch.tensor([int((nlo, nhi) != (lo, hi))])
+        dist.all_reduce(moved, op=dist.ReduceOp.MAX)  # every rank takes the same branch (generate() has barriers in test mode)
+        if int(moved.item()):
             del indptr, indices, values
             torch.cuda.empty_cache()
             lo, hi = nlo, nhi
-            indptr, indices, values = synth_counts_torch(args.cells, args.genes, args.density, args.seed, dev, lo, hi)
+            dbg("datagen for the balanced partition")
+            indptr, indices, values = generate(lo, hi)
     torch.cuda.synchronize()
     t_gen = time.time() - t0
     nnz_local = int(indptr[-1].item())
@@ -281,42 +327,54 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    # first pass also builds the transposed (gene-major) copy: data layout preparation, part of setup
-    step()
+    # First call on the fresh handle, as Cell Ranger makes it (one PCA per matrix, tools/src/bin/cmd.rs:61-70): handle
+    # creation (device-to-device copy of the triplet here), the transposed (gene-major) copy, the tile layouts of the hybrid
+    # product, normalize, PCA, U and V delivered to host arrays.
+    dbg("first call")
+    step(download=not args.no_host_delivery)
     barrier()
     t_setup = time.time() - t0
-    for _ in range(max(0, args.warmup - 1)):
-        step()
+    torch.cuda.empty_cache()
+    mem_after_first = max(0, free_at_start - torch.cuda.mem_get_info(dev)[0])  # everything the handle keeps: both copies, layouts, scratch
+    for i in range(max(0, args.warmup - 1)):
+        dbg(f"warmup {i + 1}")
+        step(download=not args.no_host_delivery)
     barrier()
-    # Timed region: exactly K steps between barriers. The per-launch HIP events that feed the roofline leg put
-    # a marker packet before and after every launch of a step, which costs a few percent of wall
-    # time, so by default they are recorded in a second pass of K steps right after the timed one
-    # (same inputs, same launches); --events-in-timed-region records them inside the timed steps instead.
+    # Timed region: exactly K steps between barriers, each returning host arrays like run_pca. The per-launch HIP events
+    # that feed the roofline leg put a marker packet before and after every launch of a step, which costs a few percent of
+    # wall time, so by default they are recorded in a second pass of K steps right after the timed one (same inputs, same
+    # launches, results left in HBM: that pass is also the device-resident rate); --events-in-timed-region records them
+    # inside the timed steps instead.
     mat.profile_reset()
     mat.profile_enable(bool(args.events_in_timed_region))
+    dbg("timed steps")
     barrier()
     t0 = time.perf_counter()
     sig = None
     for _ in range(args.steps):
-        _, sig, _ = step()
+        _, sig, _ = step(download=not args.no_host_delivery)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed_local = elapsed
-    events_elapsed = elapsed
-    if not args.events_in_timed_region:
-        mat.profile_enable(True)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        events_elapsed = time.perf_counter() - t0
+    events_elapsed = None
+    dbg("device-resident steps")
+    mat.profile_enable(not args.events_in_timed_region)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    events_elapsed = time.perf_counter() - t0
     mat.profile_enable(False)
+    dbg("reductions over ranks")
     rank_ms = [elapsed_local / args.steps * 1e3]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        t = torch.tensor([events_elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        events_elapsed = float(t.item())
         nn = torch.tensor([nnz_local], dtype=torch.int64)
         gl = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(gl, nn)
@@ -338,17 +396,6 @@ def main():
     if dist is not None:
         dist.all_reduce(vnorm)
     v_col_norm_err = float((vnorm - 1.0).abs().max().item())
-
-    host_ms = None
-    if not args.no_host_delivery:
-        barrier()
-        t0 = time.perf_counter()
-        step(download=True)
-        barrier()
-        th = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-        if dist is not None:
-            dist.all_reduce(th, op=dist.ReduceOp.MAX)
-        host_ms = float(th.item()) * 1e3
 
     knn_ms = None
     if args.also_knn and world == 1:
@@ -391,7 +438,10 @@ def main():
     # ---- roofline of the dominant kernel -------------------------------------------------------------------
     roof = None
     if prof:
-        kern = {k: v for k, v in prof.items() if not k.startswith("allreduce")}
+        # the dominant kernel of the critical path: the overflow gather of the hybrid product ("_ov") and the dense kernels the
+        # solver queues on its second stream run BESIDE the sparse passes (their event durations are stretched by the sharing)
+        side = ("spmm_gather2d_ov", "gemm_tiled", "gram_tiled", "gemm_skinny", "allreduce")
+        kern = {k: v for k, v in prof.items() if not k.startswith(side)} or {k: v for k, v in prof.items() if not k.startswith("allreduce")}
         dom = max(kern.items(), key=lambda kv: kv[1]["total_ms"])
         name, st = dom
         achieved = st["algorithmic_bytes"] / (st["total_ms"] * 1e-3) / 1e9 if st["total_ms"] > 0 else 0.0
@@ -427,6 +477,7 @@ def main():
             "kernel_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
             "launches_per_step_all": {k: round(v["launches"] / args.steps, 1) for k, v in sorted(prof.items())},
             "events_pass_ms_per_step": round(events_elapsed / args.steps * 1e3, 2),
+            "beside_the_critical_path": [k for k in sorted(prof) if k.startswith(side)],
         }
 
     # ---- CPU baseline: the oracle (the reference's serial schedule) on bounded samples: 1 core, then all cores -------
@@ -500,10 +551,15 @@ def main():
                 "nnz": nnz_global,
                 "parallelism": f"cells range-partitioned by nonzeros over {world} GPU(s)" + (", one sum all-reduce per contracting product" if world > 1 else ""),
                 "transport": transport,
-                "result_delivery": "value: U, V left in HBM (scanrs_pca_result_device); host_delivered_*: the same step with U, V copied to host arrays",
+                "result_delivery": ("value: every step returns U, sigma, V as host arrays (run_pca's contract); device_resident_*: the same steps with U, V "
+                                    "left in HBM (scanrs_pca_result_device)") if not args.no_host_delivery else "--no-host-delivery: U, V left in HBM in every step",
+                "device_resident_cells_per_s": round(args.cells * args.steps / events_elapsed, 1),
+                "device_resident_ms_per_step": round(events_elapsed / args.steps * 1e3, 2),
                 "v_col_norm_err_device_result": v_col_norm_err,
-                "setup_s": round(t_setup, 2),
-                "setup_includes": "upload, first normalize + PCA, and building the transposed (gene-major) copy of the matrix: both orientations stay in HBM (2 x 8 B per nonzero + bounds tables)",
+                "first_call_s": round(t_setup, 3),
+                "first_call_cells_per_s": round(args.cells / t_setup, 1),
+                "first_call_includes": "handle creation from device-resident arrays, the transposed (gene-major) copy, the tile layouts of the hybrid product (both orientations), normalize, PCA, host delivery",
+                "resident_bytes_per_nonzero": round(mem_after_first / max(1, nnz_local), 1) if mem_after_first else None,
                 "datagen_s": round(t_gen, 2),
                 "sigma_top3": [round(float(x), 6) for x in (sig[:3] if sig is not None else [])],
                 "per_rank_ms_per_step": [round(x, 2) for x in rank_ms],
@@ -513,9 +569,6 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
-        if host_ms is not None:
-            out["config"]["host_delivered_cells_per_s"] = round(args.cells / (host_ms * 1e-3), 1)
-            out["config"]["host_delivered_ms_per_step"] = round(host_ms, 2)
         if knn_ms is not None:
             out["config"][f"knn{args.also_knn}_device_scores_ms"] = round(knn_ms, 1)
         if randsvd_ms is not None:
@@ -524,6 +577,7 @@ def main():
             out["config"]["irlba_tol1e-4_ms"] = round(irlba_ms, 1)
             out["config"]["irlba_matrix_products"] = irlba_mprod
         print(json.dumps(out))
+    wd.done = True
     del mat
     if comm is not None:
         comm.close()

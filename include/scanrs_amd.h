@@ -315,7 +315,7 @@ int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uin
 int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
 /* Tuning options of a handle (shared by its views); defaults are the measured optimum on MI355X.
  *   "tile_k" (2)        hybrid product: record positions per (outer vector, visit): 2, 3 or 4
- *   "tile_s" (32)       hybrid product: outer vectors per wave (32; 28 with tile_k 2 or 4)
+ *   "tile_s" (28)       hybrid product: outer vectors per wave (28 or 32 with tile_k 2 or 4; 28 leaves registers for two gather waves per SIMD beside the tile kernel)
  *   "tile_t" (48)       hybrid product: panel rows per tile (<= 24 tile_k)
  *   "tile_b" (4)        hybrid product: tile buffers in the LDS ring (tile_t * tile_b <= 192); a nonzero may wait tile_b - 2 visits
  *   "tile_auto" (1)     path 0 may use the hybrid product for matrices of 2^24+ nonzeros (layout built when svd_bk / svd_rand

@@ -13,6 +13,7 @@
 
 #include <condition_variable>
 #include <mutex>
+#include <string>
 #include <thread>
 
 #include "common.hpp"
@@ -26,6 +27,8 @@ struct NcclUniqueId {
 };
 struct Rccl {
     void *h = nullptr;
+    std::string err; // why loading failed (captured right behind the failing call: dlerror() clears itself when read)
+    bool reused = false;
     int (*GetUniqueId)(NcclUniqueId *) = nullptr;
     int (*CommInitRank)(void **, int, NcclUniqueId, int) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
@@ -36,19 +39,39 @@ Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (r.h) break;
+        // An RCCL image the host program has already mapped (torch ships and links its own librccl.so.1) is reused: one
+        // RCCL per process. Only when there is none is the system's loaded — locally, so that it cannot interpose anybody.
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            r.h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+            if (r.h) {
+                r.reused = true;
+                break;
+            }
+        }
+        if (!r.h) {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (r.h) break;
+                if (const char *e = dlerror()) r.err = e;
+            }
         }
         if (!r.h) return;
-        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
-        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
-        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.h, "ncclCommDestroy");
-        r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
-        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+        struct {
+            void **slot;
+            const char *name;
+        } syms[] = {{(void **)&r.GetUniqueId, "ncclGetUniqueId"}, {(void **)&r.CommInitRank, "ncclCommInitRank"},
+                    {(void **)&r.CommDestroy, "ncclCommDestroy"}, {(void **)&r.AllReduce, "ncclAllReduce"},
+                    {(void **)&r.GetErrorString, "ncclGetErrorString"}};
+        for (auto &sy : syms) {
+            *sy.slot = dlsym(r.h, sy.name);
+            if (!*sy.slot && r.err.empty()) {
+                const char *e = dlerror();
+                r.err = e ? e : (std::string("missing symbol ") + sy.name);
+            }
+        }
     });
     if (!r.h || !r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce)
-        fail(SCANRS_ERR_DEVICE, "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+        fail(SCANRS_ERR_DEVICE, "RCCL (librccl.so.1) could not be loaded: %s", r.err.empty() ? "missing symbols" : r.err.c_str());
     return r;
 }
 void nccl_check(int rc, const char *what) {
@@ -74,6 +97,12 @@ struct LocalGroup {
         std::lock_guard<std::mutex> lk(mu);
         aborted = true;
         cv.notify_all();
+    }
+    // before a new operation, with no shard thread running: an earlier failure or cancellation aborted THAT operation only
+    void reset() {
+        std::lock_guard<std::mutex> lk(mu);
+        aborted = false;
+        arrived = 0;
     }
     void barrier() {
         std::unique_lock<std::mutex> lk(mu);
@@ -134,6 +163,7 @@ scanrs_comm *comm_make_local(const std::shared_ptr<LocalGroup> &g, uint32_t rank
     return c;
 }
 std::shared_ptr<LocalGroup> local_group_make(uint32_t world) { return std::make_shared<LocalGroup>(world); }
+void local_group_reset(LocalGroup &g) { g.reset(); }
 
 } // namespace scanrs
 

@@ -222,7 +222,7 @@ struct Storage {
         uint64_t rows_u = 0, rows_v = 0;
     } pca_dev;
     int spmm_path = 0;                    // 0 auto, 1 plain gather, 2 L2-blocked gather, 3 hybrid: LDS-staged tiles + gather of the overflow (tiles.hip)
-    uint32_t tile_k = 2, tile_s = 32;     // hybrid product: record positions per (outer vector, visit), outer vectors per wave
+    uint32_t tile_k = 2, tile_s = 28;     // hybrid product: record positions per (outer vector, visit), outer vectors per wave
     uint32_t tile_t = 48, tile_b = 4;     // ... panel rows per tile (<= 24 tile_k) and tile buffers in the LDS ring (tile_t * tile_b <= 192)
     int tile_auto = 1;                    // auto path may use the hybrid product (0: only spmm_path 3 does)
     int tile_hint = 0;                    // > 0 while a solver that repeats the same products is running (svd_bk, svd_rand)
@@ -381,6 +381,7 @@ struct LocalGroup;
 void comm_allreduce(Storage &st, scanrs_comm *c, void *d, uint64_t count, int dtype); // dtype 0 = f64, 1 = u64; on st.stream
 void comm_abort(scanrs_comm *c);
 std::shared_ptr<LocalGroup> local_group_make(uint32_t world);
+void local_group_reset(LocalGroup &g);
 scanrs_comm *comm_make_local(const std::shared_ptr<LocalGroup> &g, uint32_t rank);
 void allreduce_f64(Storage &st, double *d, uint64_t count);
 void allreduce_u64(Storage &st, unsigned long long *d, uint64_t count);

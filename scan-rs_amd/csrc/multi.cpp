@@ -35,6 +35,8 @@ int fan_out(scanrs_multi *mm, F &&f) {
     const size_t n = mm->shards.size();
     std::vector<ShardStatus> st(n);
     std::vector<std::thread> th;
+    // a failed or cancelled earlier operation aborted its own barriers only: the handle stays usable (no shard thread runs here)
+    if (mm->group) local_group_reset(*mm->group);
     for (size_t i = 0; i < n; i++) {
         th.emplace_back([&, i] {
             if (hipSetDevice(mm->devices[i]) != hipSuccess) {

@@ -568,7 +568,8 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
         }
     }
     TileArgs ta{tl.prow.p, tl.pw.p, tl.n_groups, cp.n_outer, cp.n_inner, sh};
-    const double bytes = tl.bytes() + (double)cp.n_inner * l * 8.0 + (double)cp.n_outer * l * 8.0;
+    // algorithmic bytes of the nonzeros this kernel works: 8 B each + indptr + the two panels
+    const double bytes = (double)(cp.nnz - tl.ov.nnz) * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_inner * l * 8.0 + (double)cp.n_outer * l * 8.0;
     const bool long_outer = cp.n_outer >= cp.n_inner;
     if (st.prof.on)
         st.prof.begin(st.stream, long_outer ? "spmm_tile_kernel/long-outer" : "spmm_tile_kernel/short-outer", bytes,

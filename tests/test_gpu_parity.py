@@ -455,6 +455,24 @@ def test_pca_errors_and_cancellation(sa):
     assert np.array_equal(s, s2) and np.array_equal(u, u2)
 
 
+def test_multi_handle_survives_a_cancelled_pca(sa):
+    """a cancelled (or failed) scanrs_multi_pca_bk aborted the group's barriers for good; the group is
+    reset at the start of every operation, so the handle is reusable exactly like a single-GPU handle."""
+    m = _synth(2500, 500, 0.06, 12)
+    mm = sa.MultiMat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data, 2, devices=[0, 0])
+    mm.normalize(sa.Normalization.CellRanger)
+    u, s, v = mm.run_pca_bk(6)
+    snoop = sa.AtomicSnoop()
+    snoop.cancel()
+    with pytest.raises(sa.CancellationError):
+        mm.run_pca_bk(6, snoop=snoop)
+    with pytest.raises(sa.ScanrsError):
+        mm.run_pca_bk(100000)  # invalid k on every shard
+    u2, s2, v2 = mm.run_pca_bk(6)
+    assert np.array_equal(s, s2) and np.array_equal(u, u2) and np.array_equal(v, v2)
+    mm.close()
+
+
 def test_pca_is_deterministic(sa):
     m = _synth(1200, 300, 0.08, 9)
     g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
