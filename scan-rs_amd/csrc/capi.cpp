@@ -276,6 +276,7 @@ static std::shared_ptr<DevBuf<double>> upload_vec(Storage &st, const double *h, 
 
 static void create_common(uint64_t rows, uint64_t cols, int storage, const uint64_t *indptr, const uint32_t *indices,
                           const uint32_t *values, bool device_src, scanrs_mat **out, bool sort_first = false) {
+    Tick tick("create: upload + validate");
     if (!out) fail(SCANRS_ERR_ARGUMENT, "null output handle");
     *out = nullptr;
     need_device();

@@ -389,7 +389,7 @@ int scanrs_h5_get_differential_expression(const char *path, const char *key, dou
         if (out) {
             if (cap < di.dims[0] * di.dims[1]) fail(SCANRS_ERR_ARGUMENT, "output too small for the %llu x %llu table", (unsigned long long)di.dims[0], (unsigned long long)di.dims[1]);
             const std::vector<double> v = f.read<double>(d);
-            memcpy(out, v.data(), v.size() * 8);
+            if (!v.empty()) memcpy(out, v.data(), v.size() * 8);
         }
     });
 }
@@ -407,7 +407,7 @@ int scanrs_h5_read_f64(const char *path, const char *dataset, double *out, uint6
         if (out) {
             const std::vector<double> v = f.read<double>(d);
             if (cap < v.size()) fail(SCANRS_ERR_ARGUMENT, "output holds %llu values, dataset has %zu", (unsigned long long)cap, v.size());
-            memcpy(out, v.data(), v.size() * 8);
+            if (!v.empty()) memcpy(out, v.data(), v.size() * 8);
         }
     });
 }

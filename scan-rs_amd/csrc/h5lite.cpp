@@ -106,6 +106,17 @@ uint64_t File::rd(const uint8_t *p, unsigned n) const {
 
 bool File::undefined(uint64_t a) const { return O_ == 8 ? a == UINT64_MAX : a == 0xFFFFFFFFull; }
 
+uint64_t File::checked_mul(uint64_t a, uint64_t b, const char *what) const {
+    uint64_t r;
+    if (__builtin_mul_overflow(a, b, &r)) H5FAIL("%s: %s overflows 64 bits (corrupt shape)", path_.c_str(), what);
+    return r;
+}
+
+void File::visit_node(uint64_t node) const {
+    if (visited_.size() > size_ / 24 + 64) H5FAIL("%s: more B-tree nodes than the file can hold", path_.c_str());
+    if (!visited_.insert(node).second) H5FAIL("%s: B-tree node %llu is reachable twice (cycle)", path_.c_str(), (unsigned long long)node);
+}
+
 // ---- object headers -----------------------------------------------------------------------------------------------
 std::vector<File::Msg> File::messages(Object obj) const {
     std::vector<Msg> out;
@@ -115,11 +126,19 @@ std::vector<File::Msg> File::messages(Object obj) const {
         uint64_t off, len;
     };
     std::vector<Block> blocks;
+    // a continuation that points at a block already queued is a loop; a header cannot hold more messages than the file has
+    // room for (4 bytes is the smallest message header)
+    auto push_block = [&](uint64_t off, uint64_t len) {
+        for (const Block &b : blocks)
+            if (b.off == off) H5FAIL("%s: object header continuation loop", path_.c_str());
+        if (blocks.size() > 4096) H5FAIL("%s: object header with too many continuation blocks", path_.c_str());
+        blocks.push_back({off, len});
+    };
+    const uint64_t max_msgs = size_ / 4 + 16;
     if (p[0] == 1) { // version 1: 16-byte prefix, 8-byte message headers, 8-byte aligned bodies
         const unsigned n_msgs = (unsigned)rd(p + 2, 2);
-        blocks.push_back({addr + 16, rd(p + 8, 4)});
+        push_block(addr + 16, rd(p + 8, 4));
         for (size_t b = 0; b < blocks.size(); b++) {
-            if (b > 4096) H5FAIL("%s: object header continuation loop", path_.c_str());
             uint64_t pos = blocks[b].off;
             const uint64_t end = blocks[b].off + blocks[b].len;
             at(blocks[b].off, blocks[b].len);
@@ -131,7 +150,7 @@ std::vector<File::Msg> File::messages(Object obj) const {
                 pos += 8 + m.size;
                 if (m.type == MSG_CONTINUATION) {
                     if (m.size < O_ + L_) H5FAIL("%s: short continuation message", path_.c_str());
-                    blocks.push_back({base_addr_ + rdO(m.data), rdL(m.data + O_)});
+                    push_block(base_addr_ + rdO(m.data), rdL(m.data + O_));
                 }
                 out.push_back(m);
             }
@@ -146,9 +165,8 @@ std::vector<File::Msg> File::messages(Object obj) const {
         const uint64_t chunk0 = rd(at(pos, nsz), nsz);
         pos += nsz;
         const unsigned hdr = 4 + ((flags & 0x04) ? 2 : 0);
-        blocks.push_back({pos, chunk0});
+        push_block(pos, chunk0);
         for (size_t b = 0; b < blocks.size(); b++) {
-            if (b > 4096) H5FAIL("%s: object header continuation loop", path_.c_str());
             uint64_t q = blocks[b].off;
             const uint64_t end = blocks[b].off + blocks[b].len;
             at(blocks[b].off, blocks[b].len);
@@ -162,8 +180,9 @@ std::vector<File::Msg> File::messages(Object obj) const {
                     if (m.size < O_ + L_) H5FAIL("%s: short continuation message", path_.c_str());
                     const uint64_t coff = base_addr_ + rdO(m.data), clen = rdL(m.data + O_);
                     if (clen < 8 || memcmp(at(coff, 4), "OCHK", 4) != 0) H5FAIL("%s: bad object header continuation block", path_.c_str());
-                    blocks.push_back({coff + 4, clen - 8}); // signature in front, checksum behind
+                    push_block(coff + 4, clen - 8); // signature in front, checksum behind
                 }
+                if (out.size() >= max_msgs) H5FAIL("%s: object header with more messages than the file can hold", path_.c_str());
                 out.push_back(m);
             }
         }
@@ -185,6 +204,7 @@ const File::Msg *File::find(const std::vector<Msg> &m, uint16_t type) const {
 // ---- groups -------------------------------------------------------------------------------------------------------
 void File::group_btree(uint64_t node, uint64_t heap_data, uint64_t heap_size, std::vector<std::pair<std::string, Object>> &out, int depth) const {
     if (depth > MAX_DEPTH) H5FAIL("%s: group B-tree too deep", path_.c_str());
+    visit_node(node); // a node reachable twice is a cycle (or a DAG that would be walked exponentially often)
     const uint8_t *p = at(base_addr_ + node, 8 + 2 * O_);
     if (memcmp(p, "TREE", 4) == 0) {
         if (p[4] != 0) H5FAIL("%s: group B-tree node has type %u", path_.c_str(), p[4]);
@@ -225,6 +245,7 @@ void File::links(Object group, std::vector<std::pair<std::string, Object>> &out)
         if (memcmp(h, "HEAP", 4) != 0) H5FAIL("%s: bad local heap signature", path_.c_str());
         const uint64_t hsize = rdL(h + 8), hdata = base_addr_ + rdO(h + 8 + 2 * L_);
         at(hdata, hsize);
+        visited_.clear();
         group_btree(btree, hdata, hsize, out, 0);
         return;
     }
@@ -370,6 +391,8 @@ DatasetInfo File::info(Object dataset) const {
 
 void File::chunk_btree(uint64_t node, unsigned rank, std::vector<Chunk> &out, int depth) const {
     if (depth > MAX_DEPTH) H5FAIL("%s: chunk B-tree too deep", path_.c_str());
+    visit_node(node);
+    if (out.size() > size_ / 8 + 64) H5FAIL("%s: more chunks than the file can hold", path_.c_str());
     const uint8_t *p = at(base_addr_ + node, 8 + 2 * O_);
     if (memcmp(p, "TREE", 4) != 0 || p[4] != 1) H5FAIL("%s: bad chunk B-tree node", path_.c_str());
     const unsigned level = p[5], n = (unsigned)rd(p + 6, 2);
@@ -403,22 +426,30 @@ void File::parse_layout(const std::vector<Msg> &m, const DatasetInfo &di, Layout
         if (fm->size < 2) H5FAIL("%s: short filter pipeline message", path_.c_str());
         const unsigned fver = f[0], nf = f[1];
         f += fver == 1 ? 8 : 2;
+        if (fver != 1 && fver != 2) H5FAIL("%s: filter pipeline version %u is not supported", path_.c_str(), fver);
+        if (f > fe) H5FAIL("%s: short filter pipeline message", path_.c_str());
+        auto need = [&](uint64_t n) { // every field is checked against the end of the message before it is read
+            if ((uint64_t)(fe - f) < n) H5FAIL("%s: short filter pipeline message", path_.c_str());
+        };
         for (unsigned i = 0; i < nf; i++) {
-            if (f + 8 > fe && fver == 1) H5FAIL("%s: short filter pipeline message", path_.c_str());
             Filter fl;
+            need(2);
             fl.id = (uint16_t)rd(f, 2);
             f += 2;
             unsigned name_len = 0;
             if (fver == 1 || fl.id >= 256) {
+                need(2);
                 name_len = (unsigned)rd(f, 2);
                 f += 2;
             }
+            need(4);
             f += 2; // flags
             const unsigned ncd = (unsigned)rd(f, 2);
             f += 2;
             if (fver == 1) name_len = (name_len + 7) & ~7u;
+            need(name_len);
             f += name_len;
-            if (f + 4ull * ncd > fe) H5FAIL("%s: short filter pipeline message", path_.c_str());
+            need(4ull * ncd + ((fver == 1 && (ncd & 1)) ? 4 : 0));
             for (unsigned c = 0; c < ncd; c++) fl.cd.push_back((uint32_t)rd(f + 4ull * c, 4));
             f += 4ull * ncd;
             if (fver == 1 && (ncd & 1)) f += 4;
@@ -444,7 +475,10 @@ void File::parse_layout(const std::vector<Msg> &m, const DatasetInfo &di, Layout
         const uint64_t btree = rdO(d + 3);
         for (unsigned i = 0; i < rank; i++) lay.chunk_dims.push_back(rd(d + 3 + O_ + 4ull * i, 4));
         if (rd(d + 3 + O_ + 4ull * rank, 4) != elem) H5FAIL("%s: chunk element size does not match the datatype", path_.c_str());
-        if (!undefined(btree)) chunk_btree(btree, rank, lay.chunks, 0);
+        if (!undefined(btree)) {
+            visited_.clear();
+            chunk_btree(btree, rank, lay.chunks, 0);
+        }
     } else if (lay.cls == 2 && ver == 4) {
         const uint8_t cflags = d[2];
         const unsigned nd = d[3], enc = d[4];
@@ -456,14 +490,18 @@ void File::parse_layout(const std::vector<Msg> &m, const DatasetInfo &di, Layout
         const unsigned index_type = *q++;
         if ((cflags & 0x01) && !lay.filters.empty()) H5FAIL("%s: unfiltered partial edge chunks are not supported", path_.c_str());
         uint64_t chunk_bytes = elem;
-        for (uint64_t c : lay.chunk_dims) chunk_bytes *= c;
+        for (uint64_t c : lay.chunk_dims) chunk_bytes = checked_mul(chunk_bytes, c, "chunk size");
+        if (chunk_bytes > 0xFFFFFFFFull) H5FAIL("%s: chunks of 4 GiB or more are not supported", path_.c_str());
         std::vector<uint64_t> grid(rank);
         uint64_t n_chunks = 1;
         for (unsigned i = 0; i < rank; i++) {
             if (lay.chunk_dims[i] == 0) H5FAIL("%s: zero chunk dimension", path_.c_str());
-            grid[i] = (di.dims[i] + lay.chunk_dims[i] - 1) / lay.chunk_dims[i];
-            n_chunks *= grid[i];
+            grid[i] = di.dims[i] / lay.chunk_dims[i] + (di.dims[i] % lay.chunk_dims[i] ? 1 : 0);
+            n_chunks = checked_mul(n_chunks, grid[i], "chunk grid");
         }
+        // every chunk of the grid costs at least one index entry (>= 8 bytes) in the file: a grid the file has no room for is a
+        // corrupt shape, not a dataset (the walks below are linear in n_chunks)
+        if (index_type != 1 && n_chunks > size_ / 8 + 64) H5FAIL("%s: chunk grid of %llu chunks cannot be indexed by a %llu-byte file", path_.c_str(), (unsigned long long)n_chunks, (unsigned long long)size_);
         auto offset_of = [&](uint64_t linear) {
             std::vector<uint64_t> off(rank);
             for (int i = (int)rank - 1; i >= 0; i--) {
@@ -508,6 +546,7 @@ void File::parse_layout(const std::vector<Msg> &m, const DatasetInfo &di, Layout
                 const uint8_t *h = at(base_addr_ + hdr, 8 + L_ + O_ + 4);
                 if (memcmp(h, "FAHD", 4) != 0) H5FAIL("%s: bad fixed array header", path_.c_str());
                 const unsigned client = h[5], esz = h[6], page_bits = h[7];
+                if (page_bits > 31) H5FAIL("%s: bad fixed array page size", path_.c_str());
                 const uint64_t nel = rdL(h + 8), dblk = rdO(h + 8 + L_);
                 if (nel < n_chunks) H5FAIL("%s: fixed array smaller than the chunk grid", path_.c_str());
                 if ((client == 0 && esz != O_) || (client == 1 && (esz < O_ + 5 || esz > O_ + 12))) H5FAIL("%s: bad fixed array entry size", path_.c_str());
@@ -783,8 +822,9 @@ std::vector<uint8_t> File::read_raw(Object dataset, uint64_t start, uint64_t end
     if (end > d0) end = d0;
     if (start > end) H5FAIL("%s: slice start %llu is past the end %llu of the dataset", path_.c_str(), (unsigned long long)start, (unsigned long long)end);
     uint64_t row_elems = 1; // elements per index of the first dimension
-    for (unsigned i = 1; i < rank; i++) row_elems *= di.dims[i];
-    const uint64_t row_bytes = row_elems * elem;
+    for (unsigned i = 1; i < rank; i++) row_elems = checked_mul(row_elems, di.dims[i], "dataset shape");
+    const uint64_t row_bytes = checked_mul(row_elems, elem, "dataset shape");
+    if (di.n_elements() == UINT64_MAX) H5FAIL("%s: dataset shape overflows 64 bits (corrupt shape)", path_.c_str());
     if (row_bytes && (end - start) > (UINT64_MAX / 2) / row_bytes) H5FAIL("%s: dataset too large", path_.c_str());
     // deflate expands at most ~1032:1, so nothing a file describes can be larger than this (a corrupt shape would
     // otherwise turn into a huge zero-filled allocation)
@@ -793,7 +833,7 @@ std::vector<uint8_t> File::read_raw(Object dataset, uint64_t start, uint64_t end
     if (out.empty()) return out;
     Layout lay;
     parse_layout(m, di, lay);
-    const uint64_t total = di.n_elements() * elem;
+    const uint64_t total = checked_mul(di.n_elements(), elem, "dataset size");
     if (lay.cls == 0) {
         if (lay.compact_size < total) H5FAIL("%s: compact dataset shorter than its dataspace", path_.c_str());
         memcpy(out.data(), lay.compact + start * row_bytes, out.size());
@@ -805,21 +845,36 @@ std::vector<uint8_t> File::read_raw(Object dataset, uint64_t start, uint64_t end
         uint64_t chunk_elems = 1;
         for (uint64_t c : lay.chunk_dims) {
             if (c == 0) H5FAIL("%s: zero chunk dimension", path_.c_str());
-            chunk_elems *= c;
+            chunk_elems = checked_mul(chunk_elems, c, "chunk size");
         }
-        // the chunks that intersect the slice; each lands in its own region of `out`, so they can be inflated side by side
+        const uint64_t chunk_size_bytes = checked_mul(chunk_elems, elem, "chunk size");
+        if (chunk_size_bytes > 0xFFFFFFFFull) H5FAIL("%s: chunks of 4 GiB or more are not supported", path_.c_str());
+        // the chunks that intersect the slice; each lands in its own region of `out`, so they can be inflated side by side.
+        // A chunk's offset comes from the file (B-tree key / index position): it must sit on the chunk grid inside the
+        // dataspace — the copy below trusts it.
         std::vector<const Chunk *> todo;
         for (const Chunk &c : lay.chunks) {
-            if (c.offset[0] >= end || c.offset[0] + lay.chunk_dims[0] <= start) continue;
+            if (c.offset.size() != rank) H5FAIL("%s: chunk with the wrong number of coordinates", path_.c_str());
             bool inside = true;
-            for (unsigned i = 0; i < rank; i++) inside = inside && c.offset[i] < di.dims[i];
-            if (inside) todo.push_back(&c);
+            for (unsigned i = 0; i < rank; i++) {
+                if (c.offset[i] % lay.chunk_dims[i]) H5FAIL("%s: chunk offset off the chunk grid", path_.c_str());
+                inside = inside && c.offset[i] < di.dims[i];
+            }
+            if (!inside) continue;
+            if (c.offset[0] >= end || lay.chunk_dims[0] > UINT64_MAX - c.offset[0] || c.offset[0] + lay.chunk_dims[0] <= start) continue;
+            todo.push_back(&c);
         }
         auto place = [&](const Chunk &c, std::vector<uint64_t> &idx) {
             const uint8_t *src = at(base_addr_ + c.addr, c.size);
             std::vector<uint8_t> buf(src, src + c.size);
-            unfilter(buf, lay.filters, c.filter_mask, chunk_elems * elem + 8);
-            if (buf.size() < chunk_elems * elem) H5FAIL("%s: chunk shorter than its declared shape", path_.c_str());
+            unfilter(buf, lay.filters, c.filter_mask, chunk_size_bytes + 8);
+            if (buf.size() < chunk_size_bytes) H5FAIL("%s: chunk shorter than its declared shape", path_.c_str());
+            // every copy is checked against both buffers (defence in depth behind the offset validation above)
+            auto copy = [&](uint64_t dst_byte, uint64_t src_byte, uint64_t n) {
+                if (dst_byte > out.size() || n > out.size() - dst_byte || src_byte > buf.size() || n > buf.size() - src_byte)
+                    H5FAIL("%s: chunk does not fit its dataset (corrupt chunk index)", path_.c_str());
+                memcpy(out.data() + dst_byte, buf.data() + src_byte, (size_t)n);
+            };
             // copy the runs along the last dimension; idx walks the other dimensions of the chunk
             const uint64_t last = rank - 1;
             const uint64_t run = std::min(lay.chunk_dims[last], di.dims[last] - c.offset[last]);
@@ -837,9 +892,9 @@ std::vector<uint8_t> File::read_raw(Object dataset, uint64_t start, uint64_t end
                     const uint64_t g0 = rank == 1 ? c.offset[0] : c.offset[0] + idx[0];
                     if (rank == 1) { // the run itself crosses the slice
                         const uint64_t lo = std::max(start, c.offset[0]), hi = std::min(end, c.offset[0] + run);
-                        if (lo < hi) memcpy(out.data() + (lo - start) * elem, buf.data() + (lo - c.offset[0]) * elem, (size_t)((hi - lo) * elem));
+                        if (lo < hi) copy((lo - start) * elem, (lo - c.offset[0]) * elem, (hi - lo) * elem);
                     } else if (g0 >= start && g0 < end) {
-                        memcpy(out.data() + (dst_elem - start * row_elems) * elem, buf.data() + src_elem * elem, (size_t)(run * elem));
+                        copy((dst_elem - start * row_elems) * elem, src_elem * elem, run * elem);
                     }
                 }
                 int k = (int)rank - 2; // odometer over dimensions 0 .. rank-2

@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <unordered_set>
 #include <vector>
 
 namespace scanrs {
@@ -35,10 +36,12 @@ struct DatasetInfo {
     std::vector<uint64_t> max_dims; // UINT64_MAX: unlimited
     bool null_space = false;
     TypeInfo type;
+    // UINT64_MAX when the product of the extents does not fit 64 bits (a corrupt shape; every caller bounds it)
     uint64_t n_elements() const {
         if (null_space) return 0;
         uint64_t n = 1;
-        for (uint64_t d : dims) n *= d;
+        for (uint64_t d : dims)
+            if (__builtin_mul_overflow(n, d, &n)) return UINT64_MAX;
         return n;
     }
 };
@@ -101,6 +104,10 @@ class File {
     void links(Object group, std::vector<std::pair<std::string, Object>> &out) const;
     void group_btree(uint64_t node, uint64_t heap_data, uint64_t heap_size, std::vector<std::pair<std::string, Object>> &out, int depth) const;
     void chunk_btree(uint64_t node, unsigned rank, std::vector<Chunk> &out, int depth) const;
+    // B-tree walks: every node may be entered once (a node that is its own descendant, or a DAG, would otherwise be walked
+    // exponentially often), and there cannot be more nodes than the file has room for
+    void visit_node(uint64_t node) const;
+    uint64_t checked_mul(uint64_t a, uint64_t b, const char *what) const;
     void parse_layout(const std::vector<Msg> &m, const DatasetInfo &di, Layout &lay) const;
     void unfilter(std::vector<uint8_t> &buf, const std::vector<Filter> &filters, uint32_t mask, uint64_t limit) const;
 
@@ -111,6 +118,7 @@ class File {
     unsigned O_ = 8, L_ = 8;
     uint64_t base_addr_ = 0;
     Object root_ = 0;
+    mutable std::unordered_set<uint64_t> visited_; // nodes of the B-tree walk in progress (cleared per walk)
 };
 
 } // namespace h5

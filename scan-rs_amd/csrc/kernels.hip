@@ -2157,6 +2157,7 @@ void sort_outer_vectors(Storage &st, SparseCopy &cp) {
 }
 
 void build_transposed_copy(Storage &st, const SparseCopy &src, SparseCopy &dst) {
+    Tick tick("transposed copy build");
     dst.n_outer = src.n_inner;
     dst.n_inner = src.n_outer;
     dst.nnz = src.nnz;

@@ -216,6 +216,15 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
     const uint64_t n_rec = tl->n_groups * sh.nt * sh.nset * 64u;
     if (n_rec == 0) return tl.release();
     const uint64_t n_seg = cp.n_outer * sh.n_parts;
+    auto lap = [&](const char *what) { // SCANRS_TRACE: where a build spends its time (forces a sync per phase)
+        static thread_local std::chrono::steady_clock::time_point t_prev;
+        if (!trace_on()) return;
+        (void)hipStreamSynchronize(s);
+        const auto t_now = std::chrono::steady_clock::now();
+        if (what) fprintf(stderr, "[scanrs trace]   layout: %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t_now - t_prev).count());
+        t_prev = t_now;
+    };
+    lap(nullptr);
     DevBuf<unsigned long long> ovc(n_seg + 1), ovo(n_seg + 1);
     SCANRS_HIP(hipMemsetAsync(ovc.p + n_seg, 0, 8, s));
     const dim3 grid((unsigned)((n_seg + 255) / 256));
@@ -228,11 +237,14 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
     unsigned long long n_ov = 0;
     SCANRS_HIP(hipMemcpyAsync(&n_ov, ovo.p + n_seg, 8, hipMemcpyDeviceToHost, s));
     SCANRS_HIP(hipStreamSynchronize(s));
+    lap("count + scan");
     tl->prow.alloc(n_rec);
     tl->pcnt.alloc(n_rec);
     tl->pw.alloc(n_rec);
+    lap("hipMalloc of records");
     hipLaunchKernelGGL(tile_init_rows_kernel, dim3((unsigned)((n_rec / 4 + 255) / 256)), dim3(256), 0, s, tl->prow.p, n_rec, sh);
     SCANRS_HIP(hipMemsetAsync(tl->pcnt.p, 0, n_rec * 4, s));
+    lap("init rows + counts");
     SparseCopy &ov = tl->ov;
     ov.n_outer = cp.n_outer;
     ov.n_inner = cp.n_inner;
@@ -245,8 +257,10 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
     hipLaunchKernelGGL((tile_assign_kernel<true>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, cp.n_outer, sh,
                        (unsigned long long *)nullptr, ovo.p, tl->prow.p, tl->pcnt.p, ov.indices.p, ov.values.p);
     SCANRS_HIP(hipGetLastError());
+    lap("fill");
     if (n_ov) ensure_bounds_public(st, ov);
     SCANRS_HIP(hipStreamSynchronize(s)); // the temporaries are released on return
+    lap("overflow bounds");
     if (trace_on())
         fprintf(stderr, "[scanrs trace] tile layout: %llu outer x %llu inner, T %u x B %u, K %u, S %u, %llu groups x %u tiles in %u parts, nnz %llu, overflow %llu (%.1f %%), positions per nonzero %.2f, %.2f GB\n",
                 (unsigned long long)cp.n_outer, (unsigned long long)cp.n_inner, sh.T, sh.B, sh.K, sh.S, (unsigned long long)tl->n_groups, sh.nt,
@@ -264,6 +278,7 @@ static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &c
                            cp.n_outer, tl.sh, map);
     if (tl.ov.nnz) materialize_map_values(st, tl.ov, map, tl.ov.fvals.p);
     SCANRS_HIP(hipGetLastError());
+    if (trace_on()) (void)hipStreamSynchronize(st.stream);
     tl.sig_n = map.n;
     for (int i = 0; i < map.n; i++) {
         tl.sig_id[i] = map.ops[i].id;

@@ -98,6 +98,60 @@ def synth_counts_fast(n_cells: int, n_genes: int, density: float, seed: int = 0,
     return m
 
 
+def _par_chunk(args):
+    """cells [c0, c1) of `synth_counts_par`: its own generator (seed, chunk id), Poisson-process form of the model"""
+    seed, ci, c0, c1, n_genes, cum_flat, total, big, n_clusters = args
+    rng = np.random.default_rng([seed, ci])
+    cl = rng.integers(0, n_clusters, size=c1 - c0)
+    depth = np.exp(rng.normal(0.0, 0.3, size=c1 - c0))
+    n_ev = rng.poisson(depth * total[cl])
+    starts = np.concatenate(([0], np.cumsum(n_ev + 1)))
+    e = rng.standard_exponential(int(starts[-1]))
+    cs = np.cumsum(e)
+    seg_base = np.concatenate(([0.0], cs[starts[1:-1] - 1]))
+    seg_total = cs[starts[1:] - 1] - seg_base
+    keep = np.ones(e.shape[0], dtype=bool)
+    keep[starts[1:] - 1] = False
+    cell = np.repeat(np.arange(c1 - c0), n_ev)
+    u = (cs[keep] - seg_base[cell]) / seg_total[cell] * total[cl][cell]
+    gene = np.searchsorted(cum_flat, u + big * cl[cell], side="right") - cl[cell] * n_genes
+    np.clip(gene, 0, n_genes - 1, out=gene)
+    first = np.ones(gene.shape[0], dtype=bool)
+    first[1:] = (gene[1:] != gene[:-1]) | (cell[1:] != cell[:-1])
+    counts = np.bincount(cell[first], minlength=c1 - c0).astype(np.int64)
+    return counts, gene[first].astype(np.uint32), rng.geometric(0.6, size=int(first.sum())).astype(np.uint32)
+
+
+def synth_counts_par(n_cells: int, n_genes: int, density: float, seed: int = 0, n_clusters: int = 20, chunk: int = 8192, workers: int = 0):
+    """The model of `synth_counts_fast` with one generator per chunk of `chunk` cells (seed sequence [seed, chunk id]), so the
+    chunks can be drawn by a pool of processes: the million-cell fixture input (10^9 nonzeros) in well under a minute on a
+    many-core host instead of five. Returns (indptr uint64[n_cells + 1], indices uint32[nnz], values uint32[nnz]), cell-major,
+    indices ascending per cell. The result does not depend on `workers`."""
+    import multiprocessing as mp
+    import os
+
+    rng = np.random.default_rng(seed)
+    rates = _profiles(rng, n_clusters, n_genes)
+    scale = density / rates.mean()
+    cum = np.cumsum(rates * scale, axis=1)
+    total = cum[:, -1].copy()
+    big = float(np.ceil(total.max())) + 1.0
+    cum_flat = (cum + big * np.arange(n_clusters)[:, None]).ravel()
+    jobs = [(seed, ci, c0, min(n_cells, c0 + chunk), n_genes, cum_flat, total, big, n_clusters)
+            for ci, c0 in enumerate(range(0, n_cells, chunk))]
+    workers = workers or min(len(jobs), max(1, (os.cpu_count() or 1) - 1), 64)
+    if workers > 1 and len(jobs) > 1:
+        with mp.get_context("fork").Pool(workers) as pool:
+            parts = pool.map(_par_chunk, jobs, chunksize=1)
+    else:
+        parts = [_par_chunk(j) for j in jobs]
+    indptr = np.zeros(n_cells + 1, dtype=np.uint64)
+    np.cumsum(np.concatenate([p[0] for p in parts]), out=indptr[1:])
+    indices = np.concatenate([p[1] for p in parts])
+    values = np.concatenate([p[2] for p in parts])
+    return indptr, indices, values
+
+
 def synth_counts_torch(n_cells: int, n_genes: int, density: float, seed: int, device, cell_begin: int = 0,
                        cell_end: int | None = None, n_clusters: int = 20, chunk: int = 4096):
     """Device-side generator: returns (indptr int64[n_local+1], indices int32[nnz], values int32[nnz])

@@ -3,6 +3,7 @@
 `-m gpu` suite can hold the HIP path to it without the oracle's minutes of CPU time on the GPU box.
 
     python tests/golden/make_config_fixtures.py            # ~3 min of one host core, ~6 GB of host memory
+    python tests/golden/make_config_fixtures.py config3    # configs[2], 1M cells: ~1 h of one host core, ~30 GB of host memory
 
 Inputs are reproducible on the GPU box: `scanrs_amd.synth.synth_counts_fast(100_000, 33_000, 0.03, 0)` (numpy Generator,
 PCG64) and the start panel `scanrs_oracle.omega_panel((100, 33_000), 0)` restated inside the product as
@@ -57,5 +58,39 @@ def main():
     print(f"wrote {out} ({os.path.getsize(out) / 1e3:.0f} kB)")
 
 
+def main_config3():
+    """configs[2]: 1 M cells x 33 k genes @ 3 % -> tests/golden/config3_1M.npz. Input from `synth_counts_par` (one numpy
+    generator per chunk of 8192 cells: the GPU box regenerates the 10^9 nonzeros with a process pool in well under a minute).
+    The oracle runs its serial loops (the reference's own accumulation order); only LAPACK is threaded."""
+    from scanrs_amd.synth import synth_counts_par
+
+    cells = 1_000_000
+    t0 = time.time()
+    ip, ix, vv = synth_counts_par(cells, GENES, DENSITY, SEED)
+    print(f"matrix: nnz {int(ip[-1])} ({time.time() - t0:.1f} s)", flush=True)
+    omega = so.omega_panel((2 * K, GENES), 0)
+    so.build()
+    o = so.AdaptiveMat(GENES, cells, so.CSC, ip, ix, vv)
+    t0 = time.time()
+    u, s, v = so.BkSvd().run_pca(so.normalize(o, "cellranger"), K, omega=omega)
+    print(f"oracle: {time.time() - t0:.1f} s", flush=True)
+    u, v = sign_normalise(u), v * np.sign(u[np.argmax(np.abs(u), axis=0), np.arange(K)])
+    gi = np.linspace(0, GENES - 1, N_SUB).astype(np.int64)
+    ci = np.linspace(0, cells - 1, N_SUB).astype(np.int64)
+    out = os.path.join(ROOT, "tests", "golden", "config3_1M.npz")
+    np.savez_compressed(
+        out,
+        cells=cells, genes=GENES, density=DENSITY, k=K, seed=SEED,
+        nnz=np.int64(ip[-1]), sum_indices=np.int64(ix.astype(np.int64).sum()), sum_values=np.int64(vv.astype(np.int64).sum()),
+        indptr_probe=ip[:: cells // 100].astype(np.int64),
+        sigma=s, gene_rows=gi, cell_rows=ci, u_sub=u[gi], v_sub=v[ci],
+        u_colsum=u.sum(axis=0), v_colsum=v.sum(axis=0), u_colabs=np.abs(u).sum(axis=0), v_colabs=np.abs(v).sum(axis=0),
+    )
+    print(f"wrote {out} ({os.path.getsize(out) / 1e3:.0f} kB)")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "config3":
+        main_config3()
+    else:
+        main()
