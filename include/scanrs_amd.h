@@ -326,8 +326,20 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *                       rounds of waves, 2 always longest first
  *   "hot_segment" (512) nonzeros per step from which a vector gets a whole workgroup (0 = never)
  *   "materialize" (1)   keep the values of the map prefix per nonzero on the copy with few, long outer vectors
- * Unknown keys return SCANRS_ERR_ARGUMENT. */
+ *   "slice_walk" (1)    Ix1 products / moments on the copy with few, long vectors stage the inner-indexed arrays in LDS slices
+ *   "spmv_lds" (1)      Ix1 products on the copy with many short vectors stage the vector in LDS parts
+ *   "overlap" (1)       small dense work of the solvers runs on a second stream beside the sparse passes
+ *   "d2h_threads" (4)   host threads that empty the pinned ring of a large result download
+ *   "reuse_cmax" (1e5)  svd_bk: coefficient bound above which a projection column is recomputed directly
+ * Unknown keys return SCANRS_ERR_ARGUMENT. The only environment variables the library reads are the diagnostics
+ * SCANRS_TRACE and SCANRS_TRACE_EIG (phase timings on stderr). */
 int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value);
+/* Process-wide options of the entry points that take no handle:
+ *   "h5_threads" (8)               threads that inflate the chunks of a large filtered HDF5 read
+ *   "eig_threads" (4)              host team of the Rayleigh-Ritz eigensolver for matrices of 768+ rows (1, 2 or 4)
+ *   "knn_exhaustive" (0)           1: never use the bf16-MFMA filter of scanrs_knn*
+ *   "knn_filter_min_points" (32768), "knn_ratio" (4), "knn_stats" (0)   tuning / statistics of that filter */
+int scanrs_set_global_option(const char *key, double value);
 /* Arithmetic of the large sparse products: 0 (default) = f64 throughout, the reference's arithmetic; 1 = opt-in fast
  * mode: the dense panel is rounded to f32 before it is gathered (half the on-chip bytes per nonzero), products and
  * sums stay f64. Singular values / loadings then agree with the f64 path to ~1e-7 relative, not to rounding. */

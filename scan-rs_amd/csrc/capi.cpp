@@ -140,8 +140,7 @@ Storage::~Storage() {
     }
 }
 hipStream_t Storage::aux() {
-    static const bool no_overlap = getenv("SCANRS_NO_OVERLAP") && atoi(getenv("SCANRS_NO_OVERLAP")) != 0; // experiment knob
-    if (no_overlap) return stream;
+    if (!overlap) return stream;
     if (!aux_stream) SCANRS_HIP(hipStreamCreate(&aux_stream));
     return aux_stream;
 }
@@ -291,13 +290,6 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
     // stream that produced a device-resident input) stay ordered with the kernels launched here
     SCANRS_HIP(hipStreamCreate(&st->stream));
     st->scratch.stream = st->stream;
-    if (const char *e = getenv("SCANRS_L2_TILE_KB")) { // tuning knob for the L2-blocked gather (default 3584)
-        const long kb = atol(e);
-        if (kb >= 64) st->l2_tile_bytes = (size_t)kb << 10;
-    }
-    if (const char *e = getenv("SCANRS_SPMM_ORDER")) st->spmm_order = atoi(e);
-    if (const char *e = getenv("SCANRS_MATERIALIZE")) st->materialize = atoi(e);
-    if (const char *e = getenv("SCANRS_HOT_SEGMENT")) st->hot_segment = (uint32_t)std::max(0, atoi(e));
     SparseCopy &cp = st->primary;
     cp.n_outer = storage == SCANRS_CSR ? rows : cols;
     cp.n_inner = storage == SCANRS_CSR ? cols : rows;
@@ -1130,6 +1122,27 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path) {
         m->st->spmm_path = path;
     });
 }
+int scanrs_set_global_option(const char *key, double value) {
+    return guard([&] {
+        if (!key) fail(SCANRS_ERR_ARGUMENT, "null key");
+        GlobalOptions &go = global_options();
+        const std::string k(key);
+        if (k == "h5_threads")
+            go.h5_threads = (int)std::max(1.0, value);
+        else if (k == "eig_threads")
+            go.eig_threads = (int)std::max(1.0, value);
+        else if (k == "knn_exhaustive")
+            go.knn_exhaustive = value != 0.0;
+        else if (k == "knn_filter_min_points")
+            go.knn_filter_min_points = (unsigned long long)std::max(0.0, value);
+        else if (k == "knn_ratio")
+            go.knn_ratio = (unsigned long long)std::max(2.0, value);
+        else if (k == "knn_stats")
+            go.knn_stats = value != 0.0;
+        else
+            fail(SCANRS_ERR_ARGUMENT, "unknown global option '%s'", key);
+    });
+}
 int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
     return guard([&] {
         if (!m || !key) fail(SCANRS_ERR_ARGUMENT, "null handle or key");
@@ -1156,6 +1169,17 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.materialize = value != 0.0;
         } else if (k == "hot_segment") {
             st.hot_segment = (uint32_t)std::max(0.0, value);
+        } else if (k == "slice_walk") {
+            st.slice_walk = value != 0.0;
+        } else if (k == "spmv_lds") {
+            st.spmv_lds = value != 0.0;
+        } else if (k == "overlap") {
+            st.overlap = value != 0.0;
+        } else if (k == "d2h_threads") {
+            st.d2h_threads = (unsigned)std::max(1.0, value);
+        } else if (k == "reuse_cmax") {
+            if (!(value > 0.0)) fail(SCANRS_ERR_ARGUMENT, "reuse_cmax must be positive");
+            st.reuse_cmax = value;
         } else {
             fail(SCANRS_ERR_ARGUMENT, "unknown option '%s'", key);
         }

@@ -232,6 +232,11 @@ struct Storage {
     int spmm_order = 1;                   // L2-blocked gather: launch outer vectors longest first: 0 never, 1 auto, 2 always (SCANRS_SPMM_ORDER)
     uint32_t hot_segment = 512;           // ... and give a workgroup to vectors with >= this many nonzeros per step (0 = never)
     uint64_t blocked_min_nnz = 1ull << 22; // auto: matrices below this stay on the plain gather kernel
+    int slice_walk = 1;                   // Ix1 products / moments on the short-outer copy stage the inner-indexed arrays in LDS slices
+    int spmv_lds = 1;                     // Ix1 products on the long-outer copy stage the vector in LDS parts
+    int overlap = 1;                      // small dense work of the solvers on a second stream beside the sparse passes
+    unsigned d2h_threads = 4;             // host threads that empty the pinned ring of a large result download
+    double reuse_cmax = 1e5;              // svd_bk: coefficient bound above which a projection column is recomputed directly
     int materialize = 1;                  // keep the map prefix's values per nonzero on the short-outer copy (SCANRS_MATERIALIZE=0: off)
     ~Storage();
     // the copy whose outer dimension is the base matrix's rows (true) or cols (false)

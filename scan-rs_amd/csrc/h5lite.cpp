@@ -20,6 +20,10 @@
 #include "common_err.hpp"
 
 namespace scanrs {
+GlobalOptions &global_options() { // lives with the host-only code so that the sanitizer builds of the readers link without the HIP part
+    static GlobalOptions go;
+    return go;
+}
 namespace h5 {
 
 namespace {
@@ -909,10 +913,7 @@ std::vector<uint8_t> File::read_raw(Object dataset, uint64_t start, uint64_t end
         // core is the whole load time, so large reads deal the chunks over a few threads (libhdf5 reads them one by one)
         unsigned n_thr = 1;
         if (!lay.filters.empty() && todo.size() >= 16 && out.size() >= (64u << 20)) {
-            static const unsigned cap = [] {
-                const char *e_ = getenv("SCANRS_H5_THREADS");
-                return e_ ? (unsigned)std::max(1, atoi(e_)) : 8u;
-            }();
+            const unsigned cap = (unsigned)std::max(1, global_options().h5_threads);
             n_thr = std::max(1u, std::min({cap, std::thread::hardware_concurrency(), (unsigned)(todo.size() / 4)}));
         }
         if (n_thr == 1) {

@@ -374,11 +374,7 @@ bool sym_eig_topk(const double *a_in, int n, int k, double *w, double *z) {
     // per step; thread 0 keeps the serial parts (column update, reflector, finishing p'). If the barriers turn out slow
     // (an oversubscribed or CPU-throttled host: the others are not running), the team is dismissed and thread 0 goes on alone.
     constexpr int VS = 4;
-    static const int T_env = [] {
-        const char *e_ = getenv("SCANRS_EIG_THREADS");
-        const int t_ = e_ ? atoi(e_) : 4;
-        return t_ >= 4 ? 4 : (t_ >= 2 ? 2 : 1);
-    }();
+    const int T_env = global_options().eig_threads >= 4 ? 4 : (global_options().eig_threads >= 2 ? 2 : 1);
     // measured on the MI355X host (256 cores): n = 1000: 48.6 -> 31 ms with 4 threads; n = 500: 6.1 -> 7.8 ms (the 2 MB matrix
     // lives in one core's L2 and the three barriers per step cost more than the split saves) -> team from n = 768 on
     int T = (n >= 768 && std::thread::hardware_concurrency() >= 8) ? T_env : 1;

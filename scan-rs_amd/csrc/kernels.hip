@@ -1539,10 +1539,7 @@ static bool slice_walk_chain(const DevMap &map, int from, bool &lazy_scale) {
     }
     return true;
 }
-static bool slice_walk_enabled() { // read per call (tests flip it)
-    const char *e = getenv("SCANRS_SLICE_WALK");
-    return !(e && atoi(e) == 0);
-}
+
 // MODE 1: out_a = sums, out_b = sums of squares (may be null), fout optional.  MODE 0: out_a[row * ld_a] = product (+ offset)
 template <int MODE>
 static void launch_slice_walk(Storage &st, SparseCopy &cp, const DevMap &map, const double *fvals, int fstart, bool lazy_scale,
@@ -1727,7 +1724,7 @@ void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const doubl
     if (l <= 2 && l > 0 && cp.n_outer > 0) {
         if ((ldx & 1u) || (ldo & 1u)) fail(SCANRS_ERR_ARGUMENT, "panel leading dimensions must be even");
         const bool long_outer = cp.n_outer >= cp.n_inner;
-        if (st.spmm_path != 1 && slice_walk_enabled() && l == 1 && !long_outer && cp.nnz >= st.blocked_min_nnz && cp.n_inner >= (1ull << 19)) {
+        if (st.spmm_path != 1 && st.slice_walk && l == 1 && !long_outer && cp.nnz >= st.blocked_min_nnz && cp.n_inner >= (1ull << 19)) {
             // few long vectors against an inner-indexed vector far beyond L2: slices of it (and of the barcode scale, unless
             // the mapped values are materialized) staged in LDS
             const int fstart = fvals_prefix_len(map);
@@ -1767,8 +1764,7 @@ void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const doubl
             SCANRS_HIP(hipGetLastError());
             return;
         }
-        static const bool lds_ok = !(getenv("SCANRS_SPMV_LDS") && atoi(getenv("SCANRS_SPMV_LDS")) == 0);
-        if (lds_ok && l == 1 && st.spmm_path != 1 && cp.nnz >= st.blocked_min_nnz && cp.n_outer >= (1ull << 16) && cp.n_inner >= 8192 &&
+        if (st.spmv_lds && l == 1 && st.spmm_path != 1 && cp.nnz >= st.blocked_min_nnz && cp.n_outer >= (1ull << 16) && cp.n_inner >= 8192 &&
             cp.n_inner <= 8u * 18432u) {
             // vector of 64 KB .. 1.1 MB against many outer vectors: LDS-staged parts
             const uint32_t nb = ensure_bounds(st, cp);
@@ -1824,7 +1820,7 @@ void launch_row_reduce(Storage &st, SparseCopy &cp, const DevMap &map, int mode,
         for (int i = 0; i < map.n; i++)
             inner_indexed = inner_indexed || (map.ops[i].a && !map.ops[i].a_outer) || (map.ops[i].b && !map.ops[i].b_outer);
         bool lazy = false;
-        if (inner_indexed && slice_walk_enabled() && cp.n_outer < cp.n_inner && slice_walk_chain(map, 0, lazy) && lazy) {
+        if (inner_indexed && st.slice_walk && cp.n_outer < cp.n_inner && slice_walk_chain(map, 0, lazy) && lazy) {
             // the barcode scale staged in LDS slice by slice instead of gathered from L2 (see slice_walk_kernel)
             double *fout = mode == 2 && fvals_wanted(st, cp, map, map.n) ? fvals_claim(st, cp, map, map.n) : nullptr;
             launch_slice_walk<1>(st, cp, map, nullptr, 0, true, nullptr, 0, out_sum, 1, mode == 2 ? out_sumsq : nullptr, fout, nullptr, 0,

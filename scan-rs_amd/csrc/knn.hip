@@ -428,17 +428,16 @@ __global__ void kf_scatter_result_kernel(const uint32_t *__restrict__ res, const
 
 bool knn_filtered(const double *dq, uint32_t ldq, uint64_t n_q, const double *dp, uint32_t ldp, uint64_t n_p, uint32_t d, uint32_t k,
                   int skip, uint32_t *dout) {
-    const bool off = getenv("SCANRS_KNN_EXHAUSTIVE") && atoi(getenv("SCANRS_KNN_EXHAUSTIVE")) != 0; // read per call (tests flip it)
-    uint64_t min_points = 32768;
-    if (const char *e = getenv("SCANRS_KNN_FILTER_MIN_POINTS")) min_points = (uint64_t)atoll(e);
+    const GlobalOptions &go = global_options(); // scanrs_set_global_option (read per call: tests flip them)
+    const bool off = go.knn_exhaustive != 0;
+    const uint64_t min_points = go.knn_filter_min_points;
     if (off || d > KF_DMAX || n_p < min_points || k > 64 || n_q < 256) return false;
     hipStream_t s = 0;
     // nested strided subsets S_0 < S_1 < ... < all points: S_0 (at most KF_CAP points) is ranked exactly for every query, which gives
     // an upper bound tau of the k-th distance; every further subset is `ratio` times denser and goes through the filter with the
     // previous tau, which lets about k * ratio * (volume inflation of the margin) pairs per query through.
-    uint64_t ratio = 4; // 1M x 50, k = 15: 487 ms at 4, 553 at 8, 606 at 16 (fewer passes, but longer candidate lists and the first overflows)
-    if (const char *e = getenv("SCANRS_KNN_RATIO")) ratio = std::max<uint64_t>(2, (uint64_t)atoll(e));
-    const bool stats = getenv("SCANRS_KNN_STATS") != nullptr;
+    const uint64_t ratio = std::max<uint64_t>(2, go.knn_ratio); // default 4: 1M x 50, k = 15: 487 ms at 4, 553 at 8, 606 at 16 (fewer passes, but longer candidate lists and the first overflows)
+    const bool stats = go.knn_stats != 0;
     std::vector<uint64_t> strides;
     uint64_t st0 = 1;
     while ((n_p + st0 - 1) / st0 > KF_CAP) st0 *= 2;

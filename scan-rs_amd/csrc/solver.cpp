@@ -223,11 +223,7 @@ static void download_panel_staged(Ctx &c, const double *d, uint32_t ld, uint64_t
     const uint64_t slot_rows = std::max<uint64_t>(1, SLOT / row_bytes);
     const size_t n_chunks = (size_t)((rows + slot_rows - 1) / slot_rows);
     char *stage = (char *)c.st.pinned((size_t)NS * slot_rows * row_bytes);
-    static const unsigned T_env = [] {
-        const char *e = getenv("SCANRS_D2H_THREADS");
-        return e ? (unsigned)std::max(1, atoi(e)) : 4u;
-    }();
-    const unsigned T = std::max(1u, std::min(T_env, std::thread::hardware_concurrency()));
+    const unsigned T = std::max(1u, std::min(c.st.d2h_threads, std::thread::hardware_concurrency()));
     hipEvent_t ev[NS];
     for (auto &e : ev) SCANRS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     std::atomic<size_t> ready{0};
@@ -732,8 +728,7 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
     // T' = (op(A) K) C amplifies the rounding of op(A) K by |C|. Columns of Q whose coefficient column stays
     // small (<= 1e5: error <= ~1e-11) take the cheap dense route; the others — directions in which the Krylov
     // blocks are numerically dependent — are recomputed directly as a (narrow) sparse product op(A) Q[:, bad].
-    double cmax_limit = 1e5;
-    if (const char *e = getenv("SCANRS_REUSE_CMAX")) cmax_limit = atof(e);
+    const double cmax_limit = c.st.reuse_cmax;
     std::vector<uint32_t> bad;
     if (reuse) {
         std::vector<double> colmax(q, 0.0);

@@ -599,13 +599,10 @@ def test_blocked_kernel_many_steps_and_determinism(sa):
         assert_close(g.rdot(ql), o.rdot(ql), rtol=1e-10, atol=1e-8)
 
 
-@pytest.mark.parametrize("knobs", [{"SCANRS_HOT_SEGMENT": "8"}, {"SCANRS_HOT_SEGMENT": "1", "SCANRS_SPMM_ORDER": "2"},
-                                   {"SCANRS_SPMM_ORDER": "0"}, {"SCANRS_HOT_SEGMENT": "0"}])
-def test_blocked_kernel_hot_vectors_and_launch_order(sa, monkeypatch, knobs):
+@pytest.mark.parametrize("knobs", [{"hot_segment": 8}, {"hot_segment": 1, "spmm_order": 2}, {"spmm_order": 0}, {"hot_segment": 0}])
+def test_blocked_kernel_hot_vectors_and_launch_order(sa, knobs):
     """Launch order (longest vector first) and the workgroup-per-hot-vector split change scheduling and the
     association of the partial sums, never the result beyond rounding; both stay bitwise repeatable."""
-    for k_, v_ in knobs.items():
-        monkeypatch.setenv(k_, v_)  # read when a handle is created
     rng = np.random.default_rng(77)
     dense = random_counts(rng, 50, 5000, 0.02, 30)
     dense[3, :] = rng.integers(1, 9, size=5000)          # hot vectors: every step has a long segment
@@ -615,6 +612,8 @@ def test_blocked_kernel_hot_vectors_and_launch_order(sa, monkeypatch, knobs):
     for storage in (so.CSR, so.CSC):
         g, o = pair(sa, dense + 0, storage)
         g.set_spmm_path(2)
+        for k_, v_ in knobs.items():
+            g.set_option(k_, v_)  # scanrs_mat_set_option
         f = rng.random(5000) + 0.5
         g.compose_scale_axis(1, f).apply(sa.FN_LOG2_1P)
         o = o.compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=1, a=f)).apply(so.OP_LOG2_1P)
@@ -977,9 +976,9 @@ def test_default_seed_panel_is_the_sequential_stream(sa):
 
 
 
-def test_materialized_map_values_are_bit_identical_and_never_stale(sa, monkeypatch):
+def test_materialized_map_values_are_bit_identical_and_never_stale(sa):
     """On the copy with few, long outer vectors the first links of the normalisation chain (per-barcode scale, log) are
-    evaluated once per nonzero and kept (SCANRS_MATERIALIZE, default on): the moments pass of normalize() leaves them,
+    evaluated once per nonzero and kept (option "materialize", default on): the moments pass of normalize() leaves them,
     the products read them. Same arithmetic in the same order, so products and PCA agree bit for bit with the lazy
     evaluation; values are keyed by link identity, so re-normalizing, another view or a different size factor never
     sees the previous values."""
@@ -996,8 +995,9 @@ def test_materialized_map_values_are_bit_identical_and_never_stale(sa, monkeypat
     sf = rng.integers(500, 5000, size=cells).astype(np.uint32)
 
     def run(materialize):
-        monkeypatch.setenv("SCANRS_MATERIALIZE", "1" if materialize else "0")
         m = sa.AdaptiveMat.from_scipy(a)
+        m.set_option("materialize", 1 if materialize else 0)
+        m.set_option("tile_auto", 0)  # the gather kernels are the subject here (the hybrid product keeps its own weights)
         m.profile_enable(True)
         out = {}
         sa.normalize(m, sa.Normalization.CellRanger)
@@ -1026,16 +1026,14 @@ def test_materialized_map_values_are_bit_identical_and_never_stale(sa, monkeypat
     assert "materialize_map_values" in names_mat, names_mat
 
 
-@pytest.mark.parametrize("knobs", [{"SCANRS_SLICE_WALK": "1", "SCANRS_MATERIALIZE": "1"}, {"SCANRS_SLICE_WALK": "1", "SCANRS_MATERIALIZE": "0"},
-                                   {"SCANRS_SLICE_WALK": "0", "SCANRS_MATERIALIZE": "1"}, {"SCANRS_SLICE_WALK": "0", "SCANRS_MATERIALIZE": "0"}])
-def test_slice_walk_moments_and_spmv_match_the_oracle(sa, monkeypatch, knobs):
+@pytest.mark.parametrize("knobs", [{"slice_walk": 1, "materialize": 1}, {"slice_walk": 1, "materialize": 0},
+                                   {"slice_walk": 0, "materialize": 1}, {"slice_walk": 0, "materialize": 0}])
+def test_slice_walk_moments_and_spmv_match_the_oracle(sa, knobs):
     """The walk of a few long vectors against barcode-indexed arrays staged slice by slice in LDS (slice_walk_kernel):
     moments of the mapped values and Ix1 products, with the mapped values lazy or materialized, against the oracle and
-    against the L2-blocked kernels it replaces (SCANRS_SLICE_WALK=0); repeatable bit for bit."""
+    against the L2-blocked kernels it replaces (option "slice_walk" 0); repeatable bit for bit."""
     import scipy.sparse as sp
 
-    for k_, v_ in knobs.items():
-        monkeypatch.setenv(k_, v_)
     rng = np.random.default_rng(21)
     rows, cols, nnz = 40, 600_000, 6_500_000
     r = rng.integers(0, rows, size=nnz)
@@ -1047,6 +1045,8 @@ def test_slice_walk_moments_and_spmv_match_the_oracle(sa, monkeypatch, knobs):
     assert m.nnz > (1 << 22)  # above the blocked kernels' threshold
     f = rng.random(cols) + 0.5
     g = sa.AdaptiveMat.from_csmat(rows, cols, sa.CSR, m.indptr, m.indices, m.data)
+    for k_, v_ in knobs.items():
+        g.set_option(k_, v_)
     g.profile_enable(True)
     g.compose_scale_axis(1, f).apply(sa.FN_LOG2_1P)
     o = so.AdaptiveMat(rows, cols, so.CSR, m.indptr, m.indices, m.data)
@@ -1067,4 +1067,4 @@ def test_slice_walk_moments_and_spmv_match_the_oracle(sa, monkeypatch, knobs):
     m2, v2 = g.mean_var_axis(1)
     assert np.array_equal(m2, mean) and np.array_equal(v2, var)
     names = set(g.profile_get())
-    assert any(n.startswith("slice_walk") for n in names) == (knobs["SCANRS_SLICE_WALK"] == "1"), names
+    assert any(n.startswith("slice_walk") for n in names) == (knobs["slice_walk"] == 1), names

@@ -303,6 +303,7 @@ def test_sym_eig_topk_does_not_depend_on_the_thread_count():
 
     code = (
         "import numpy as np, scanrs_amd as sa, sys\n"
+        "sa.set_global_option('eig_threads', int(sys.argv[1]))\n"
         "rng = np.random.default_rng(4)\n"
         "b = rng.standard_normal((800, 800)); a = b @ b.T\n"
         "w, z = sa.host_sym_eig_topk(a, 40)\n"
@@ -310,8 +311,8 @@ def test_sym_eig_topk_does_not_depend_on_the_thread_count():
     )
     outs = []
     for t in ("1", "2", "4"):
-        env = dict(os.environ, SCANRS_EIG_THREADS=t, PYTHONPATH=ROOT)
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        env = dict(os.environ, PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, "-c", code, t], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout)
     assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 1000

@@ -90,12 +90,14 @@ def test_knn_larger_set_all_dimension_kernels_and_duplicates():
 
 
 def _knn_both_ways(sa, fn, monkeypatch):
-    """run `fn` with the matrix-core filter allowed and with the exhaustive kernel forced; the env switch is read per call"""
-    monkeypatch.delenv("SCANRS_KNN_EXHAUSTIVE", raising=False)
+    """run `fn` with the matrix-core filter allowed and with the exhaustive kernel forced (global option, read per call)"""
+    sa.set_global_option("knn_exhaustive", 0)
     a = fn()
-    monkeypatch.setenv("SCANRS_KNN_EXHAUSTIVE", "1")
-    b = fn()
-    monkeypatch.delenv("SCANRS_KNN_EXHAUSTIVE", raising=False)
+    sa.set_global_option("knn_exhaustive", 1)
+    try:
+        b = fn()
+    finally:
+        sa.set_global_option("knn_exhaustive", 0)
     return a, b
 
 
@@ -150,6 +152,9 @@ def test_knn_device_on_pca_scores(monkeypatch):
     s2, res = sa.BkSvd().run_pca_device(g, 9)
     assert res.ld_v == 10 and res.k == 9
     a = sa.knn_device(res.d_v, m.shape[0], res.ld_v, res.k, 15)
-    monkeypatch.setenv("SCANRS_KNN_EXHAUSTIVE", "1")
-    b = sa.knn(v, 15)
+    sa.set_global_option("knn_exhaustive", 1)
+    try:
+        b = sa.knn(v, 15)
+    finally:
+        sa.set_global_option("knn_exhaustive", 0)
     assert np.array_equal(a, b)

@@ -1,5 +1,5 @@
 """Throughput of the exact kNN (scan_rs::nn::knn) on synthetic PCA scores: n x d, k neighbours; the matrix-core filter path
-(bf16 MFMA filter + exact f64 rerank) against the exhaustive f64 kernel (SCANRS_KNN_EXHAUSTIVE=1), results compared."""
+(bf16 MFMA filter + exact f64 rerank) against the exhaustive f64 kernel (global option "knn_exhaustive"), results compared."""
 import os
 import sys
 import time
@@ -19,7 +19,7 @@ v = (centres[rng.integers(0, 20, size=n)] + rng.standard_normal((n, d))) * np.li
 sa.knn(v[:1000], k)
 res = {}
 for mode in (["filter", "exhaustive"] if also_exhaustive else ["filter"]):
-    os.environ["SCANRS_KNN_EXHAUSTIVE"] = "1" if mode == "exhaustive" else "0"
+    sa.set_global_option("knn_exhaustive", 1 if mode == "exhaustive" else 0)
     t0 = time.perf_counter()
     out = sa.knn(v, k)
     dt = time.perf_counter() - t0
