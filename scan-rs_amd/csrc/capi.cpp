@@ -233,6 +233,12 @@ static SparseCopy &copy_outer_view_rows(scanrs_mat *m, bool view_rows) {
     return m->st->copy_with_outer_rows(view_rows != m->transposed);
 }
 
+// does the product V * X (transpose: V^T * X) of this handle currently run through the hybrid tile product?
+bool mat_tiles_ready(scanrs_mat *m, bool transpose) {
+    SparseCopy &cp = copy_outer_view_rows(m, !transpose);
+    return cp.tiles != nullptr && (m->st->spmm_path == 3 || (m->st->spmm_path == 0 && m->st->tile_auto && m->st->panel_precision == 0));
+}
+
 void mat_apply(scanrs_mat *m, bool transpose, const double *dX, uint32_t ldx, uint32_t l, double *dOut, uint32_t ldo) {
     Storage &st = *m->st;
     const bool outer_is_view_row = !transpose;

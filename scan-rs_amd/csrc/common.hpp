@@ -370,6 +370,7 @@ void omega_fill(uint64_t seed, uint64_t count, double *out);
 // operator-level helpers shared by capi.cpp and solver.cpp
 // out[rows_v x l] = V * X  (transpose: out[cols_v x l] = V^T * X), offsets and shard reduction included.
 void mat_apply(scanrs_mat *m, bool transpose, const double *dX, uint32_t ldx, uint32_t l, double *dOut, uint32_t ldo);
+bool mat_tiles_ready(scanrs_mat *m, bool transpose);
 void sort_outer_vectors(Storage &st, SparseCopy &cp);
 void launch_scale_rows(Storage &st, const double *X, uint32_t ldx, uint64_t rows, uint32_t l, const double *a, double *Xs);
 // knn.hip

@@ -59,7 +59,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void tile_assign_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
                                                           const uint32_t *__restrict__ values, uint64_t n_outer, TileShape sh,
                                                           unsigned long long *__restrict__ ovc, const unsigned long long *__restrict__ ov_off,
-                                                          uint8_t *__restrict__ prow, uint32_t *__restrict__ pcnt,
+                                                          uint8_t *__restrict__ prow, uint8_t *__restrict__ pcnt,
                                                           uint32_t *__restrict__ ov_indices, uint32_t *__restrict__ ov_values) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_outer * sh.n_parts) return;
@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void tile_assign_kernel(const uint64_t *__rest
             v++;
             cap = sh.K;
         }
-        if (v > tau + sh.B - 2u || v >= t1) { // tile tau has left the ring (or the part is over): overflow
+        // tile tau has left the ring (or the part is over), or the count does not fit the position's byte: overflow part
+        if (v > tau + sh.B - 2u || v >= t1 || values[p] > 255u) {
             if (FILL) {
                 ov_indices[op] = idx;
                 ov_values[op] = values[p];
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void tile_assign_kernel(const uint64_t *__rest
         if (FILL) {
             const uint64_t rec = ((g * sh.nt + v) * sh.nset + b) * 64u + (uint64_t)q * sh.K + (sh.K - cap);
             prow[rec] = (uint8_t)((tau % sh.B) * sh.T + (idx - tau * sh.T));
-            pcnt[rec] = values[p];
+            pcnt[rec] = (uint8_t)values[p];
         }
         cap--;
     }
@@ -124,8 +125,9 @@ __global__ void tile_init_rows_kernel(uint8_t *__restrict__ prow, uint64_t n_rec
     reinterpret_cast<uint32_t *>(prow)[e] = code * 0x01010101u;
 }
 
-// pw[rec] = the map chain at the record's (count, outer, inner); unused positions (count 0) get weight 0
-__global__ __launch_bounds__(256) void tile_weights_kernel(const uint8_t *__restrict__ prow, const uint32_t *__restrict__ pcnt,
+// pw[rec] = the map chain at the record's (count, outer, inner); unused positions (count 0) get weight 0.
+// One thread per record; nset * 64 is a power of two and (group, visit) pairs fit 32 bits (checked by the builder).
+__global__ __launch_bounds__(256) void tile_weights_kernel(const uint8_t *__restrict__ prow, const uint8_t *__restrict__ pcnt,
                                                            double *__restrict__ pw, uint64_t n_rec, uint64_t n_outer, TileShape sh, DevMap map) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_rec) return;
@@ -133,14 +135,13 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint8_t *__rest
     double w = 0.0;
     if (cnt) {
         const uint32_t lane = (uint32_t)(e & 63u);
-        const uint64_t sv = e >> 6;
-        const uint32_t b = (uint32_t)(sv % sh.nset);
-        const uint64_t gv = sv / sh.nset;
-        const uint32_t v = (uint32_t)(gv % sh.nt);
-        const uint64_t g = gv / sh.nt;
-        const uint64_t o = g * sh.S + (uint64_t)b * sh.sps + lane / sh.K;
+        const uint32_t sv = (uint32_t)(e >> 6);
+        const uint32_t b = sh.nset == 1 ? 0u : (sv & (sh.nset - 1u));
+        const uint32_t gv = sh.nset == 1 ? sv : sv / sh.nset;
+        const uint32_t g = gv / sh.nt, v = gv - g * sh.nt;
+        const uint64_t o = (uint64_t)g * sh.S + b * sh.sps + lane / sh.K;
         const uint32_t code = prow[e];
-        const uint32_t bufi = code / sh.T, r = code % sh.T;
+        const uint32_t bufi = code / sh.T, r = code - bufi * sh.T;
         const uint32_t d = (v % sh.B + sh.B - bufi) % sh.B; // visits the nonzero waited
         const uint32_t inner = (v - d) * sh.T + r;
         w = eval_map(map, cnt, (uint32_t)o, inner);
@@ -161,14 +162,14 @@ struct TileLayout {
     TileShape sh{};
     uint64_t n_groups = 0;
     DevBuf<uint8_t> prow;  // [group][visit][set][64]: ring row of the position
-    DevBuf<uint32_t> pcnt; // same index: the raw count (0 = unused position)
+    DevBuf<uint8_t> pcnt;  // same index: the raw count (0 = unused position; counts above 255 live in the overflow part)
     DevBuf<double> pw;     // same index: the weight under the map `sig_*`
     SparseCopy ov;         // the overflow part: indptr / indices / values (counts) / fvals (weights)
     // identity of the map the weights were evaluated under (MapOp ids are never reused); -1: none yet
     int sig_n = -1;
     uint32_t sig_id[MAX_OPS] = {};
     int sig_outer[MAX_OPS] = {};
-    double bytes() const { return (double)prow.n + (double)pcnt.n * 4.0 + (double)pw.n * 8.0 + (double)ov.nnz * 16.0; }
+    double bytes() const { return (double)prow.n + (double)pcnt.n + (double)pw.n * 8.0 + (double)ov.nnz * 16.0; }
     bool structure_matches(const Storage &st) const { return sh.K == st.tile_k && sh.S == st.tile_s && sh.T == st.tile_t && sh.B == st.tile_b; }
     bool weights_match(const DevMap &map) const {
         if (sig_n != map.n) return false;
@@ -215,6 +216,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
     hipStream_t s = st.stream;
     const uint64_t n_rec = tl->n_groups * sh.nt * sh.nset * 64u;
     if (n_rec == 0) return tl.release();
+    if (tl->n_groups * sh.nt > 0xFFFFFFFFull || (sh.nset & (sh.nset - 1u))) fail(SCANRS_ERR_SHAPE, "matrix too large for the tile layout's 32-bit visit index");
     const uint64_t n_seg = cp.n_outer * sh.n_parts;
     auto lap = [&](const char *what) { // SCANRS_TRACE: where a build spends its time (forces a sync per phase)
         static thread_local std::chrono::steady_clock::time_point t_prev;
@@ -229,7 +231,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
     SCANRS_HIP(hipMemsetAsync(ovc.p + n_seg, 0, 8, s));
     const dim3 grid((unsigned)((n_seg + 255) / 256));
     hipLaunchKernelGGL((tile_assign_kernel<false>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, cp.n_outer, sh, ovc.p,
-                       (const unsigned long long *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+                       (const unsigned long long *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     size_t tmp_bytes = 0;
     SCANRS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, ovc.p, ovo.p, 0ull, (size_t)n_seg + 1, rocprim::plus<unsigned long long>(), s));
     DevBuf<char> tmp(std::max<size_t>(tmp_bytes, 16));
@@ -243,7 +245,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
     tl->pw.alloc(n_rec);
     lap("hipMalloc of records");
     hipLaunchKernelGGL(tile_init_rows_kernel, dim3((unsigned)((n_rec / 4 + 255) / 256)), dim3(256), 0, s, tl->prow.p, n_rec, sh);
-    SCANRS_HIP(hipMemsetAsync(tl->pcnt.p, 0, n_rec * 4, s));
+    SCANRS_HIP(hipMemsetAsync(tl->pcnt.p, 0, n_rec, s));
     lap("init rows + counts");
     SparseCopy &ov = tl->ov;
     ov.n_outer = cp.n_outer;
@@ -519,9 +521,10 @@ bool spmm_tiles_ok(const Storage &st, const SparseCopy &cp, uint32_t ldx, uint32
 
 // Auto path (spmm_path 0): the hybrid product serves a large matrix once its layout under this map exists — built when a
 // solver announces many products (Storage::tile_hint) or when the same map comes by a second time, and only if the device
-// has room for it (about 18 bytes per nonzero per orientation).
+// has room for it (about 16 bytes per nonzero per orientation).
 bool spmm_tiles_auto(Storage &st, SparseCopy &cp, const DevMap &map) {
     if (!st.tile_auto || cp.nnz < std::max<uint64_t>(st.blocked_min_nnz, 1ull << 24)) return false;
+    if (((cp.n_outer + st.tile_s - 1) / st.tile_s) * ((cp.n_inner + st.tile_t - 1) / st.tile_t) > 0xFFFFFFFFull) return false; // 32-bit visit index
     if (cp.tiles && cp.tiles->structure_matches(st)) return true; // the weights follow the map in one streaming pass
     bool seen = cp.tsig_n == map.n;
     for (int i = 0; seen && i < map.n; i++) seen = cp.tsig_id[i] == map.ops[i].id && cp.tsig_outer[i] == map.ops[i].a_outer;
@@ -533,7 +536,7 @@ bool spmm_tiles_auto(Storage &st, SparseCopy &cp, const DevMap &map) {
     if (!seen && st.tile_hint <= 0) return false;
     // room: records (9 B per position) + overflow + the build's temporaries + the partial-sum buffers, and 8 GB for the solver
     const double nt = (double)((cp.n_inner + st.tile_t - 1) / st.tile_t);
-    const double need = 13.0 * 64.0 * (double)((cp.n_outer + st.tile_s - 1) / st.tile_s) * nt * ((st.tile_s + 64 / st.tile_k - 1) / (64 / st.tile_k)) +
+    const double need = 10.0 * 64.0 * (double)((cp.n_outer + st.tile_s - 1) / st.tile_s) * nt * ((st.tile_s + 64 / st.tile_k - 1) / (64 / st.tile_k)) +
                         0.2 * 12.0 * (double)cp.nnz + 32.0 * (double)cp.n_outer * 64.0 + 2.0 * (double)cp.n_outer * 104.0 * 8.0 * 2.0;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
