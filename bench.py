@@ -58,6 +58,7 @@ def parse():
                     help="N=1 only: serve the exchange steps through RCCL (world 1) anyway, to price the transport itself")
     ap.add_argument("--events-in-timed-region", action="store_true",
                     help="record the per-launch HIP events inside the K timed steps instead of in a second pass of K steps")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="scanrs_mat_set_option on the handle (experiments)")
     ap.add_argument("--sqz-bench", action="store_true",
                     help="instead: the reference's only benchmark (sqz/benches/my_benchmark.rs): u32 CSR / CSC 1000 x 10000 times 10000 x 16")
     return ap.parse_args()
@@ -311,6 +312,9 @@ def main():
         mat.set_panel_precision(1)
     if args.spmm_path:
         mat.set_spmm_path(args.spmm_path)
+    for kv in args.opt:
+        key, val = kv.split("=")
+        mat.set_option(key, float(val))
     bk = sa.BkSvd()  # k_multiplier 2.0, n_iter 5: the solver scan-rs-cmd uses (tools/src/bin/cmd.rs:70)
 
     def step(download=False):
@@ -449,7 +453,7 @@ def main():
         try:  # HBM bytes per launch from the committed PMC passes (profiles/, separate --pmc runs), headline workload only
             with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as f:
                 pj = json.load(f)
-            pm = pj["kernels"].get(name)
+            pm = pj["kernels"].get(name) or pj["kernels"].get(name.split("/")[0])  # the tile kernel is one class in the trace (both orientations)
             if pm and args.cells == 1_000_000 and args.genes == 33_000 and world == 1:
                 traffic = round(pm["hbm_bytes_per_launch_corrected"])
                 traffic_src = f"profiles/{PMC_PROFILE} (committed rocprofv3 --pmc passes of this command, commit {pj.get('commit', '?')}; NOT measured in this run)"

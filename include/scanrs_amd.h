@@ -315,7 +315,11 @@ int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uin
 int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
 /* Tuning options of a handle (shared by its views); defaults are the measured optimum on MI355X.
  *   "tile_k" (2)        hybrid product: record positions per (outer vector, visit): 2, 3 or 4
- *   "tile_s" (28)       hybrid product: outer vectors per wave (28 or 32 with tile_k 2 or 4; 28 leaves registers for two gather waves per SIMD beside the tile kernel)
+ *   "tile_s" (32)       hybrid product: outer vectors per wave (32, or 28 with tile_k 2 or 4: 28 leaves registers for two gather
+ *                       waves per SIMD beside the tile kernel instead of one)
+ *   "ov_tile_kb" (0)    hybrid product: panel slice per step of the overflow gather (0 = l2_tile_kb)
+ *   "tile_ku" (1)       hybrid product, tile_k 2: 1 = one of the two positions takes only count-1 nonzeros, whose rows are added
+ *                       without a weight (maps whose value at count 1 is an outer factor times an inner factor); 0 = none
  *   "tile_t" (48)       hybrid product: panel rows per tile (<= 24 tile_k)
  *   "tile_b" (4)        hybrid product: tile buffers in the LDS ring (tile_t * tile_b <= 192); a nonzero may wait tile_b - 2 visits
  *   "tile_auto" (1)     path 0 may use the hybrid product for matrices of 2^24+ nonzeros (layout built when svd_bk / svd_rand

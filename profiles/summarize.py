@@ -23,9 +23,13 @@ def one(pattern):
 
 
 def classify(name, grid):
+    if "spmm_tile_kernel" in name:  # the persistent tile kernel of the hybrid product (both orientations: one grid of 256 workgroups)
+        return "spmm_tile_kernel"
+    if "spmm_gather_ov_kernel" in name:  # the gather over the overflow part, beside the tile kernel (4 vectors per wave)
+        return "spmm_gather2d_ov/long-outer" if grid > 2_500_000 else "spmm_gather2d_ov/short-outer"
     if "spmm_gather2d_kernel" in name:
         return "spmm_gather2d_kernel<1>/long-outer" if grid > 10_000_000 else "spmm_gather2d_kernel<1>/short-outer"
-    for k in ("gram_tiled_kernel", "gemm_tiled_kernel", "slice_walk_kernel<1>", "slice_walk_kernel<0>", "row_reduce2d_kernel<2>", "row_reduce_kernel<2>", "row_reduce_kernel<0>",
+    for k in ("tile_weights_kernel", "tile_finish_kernel", "tile_assign_kernel", "gram_tiled_kernel", "gemm_tiled_kernel", "slice_walk_kernel<1>", "slice_walk_kernel<0>", "row_reduce2d_kernel<2>", "row_reduce_kernel<2>", "row_reduce_kernel<0>",
               "weighted_colsum_partial_kernel", "spmv2d_kernel", "spmv_lds_kernel", "gram_kernel", "gemm_nn_kernel"):
         if k in name:
             return k
@@ -75,7 +79,7 @@ def main():
         "commit": commit, "kernels": tr}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
     # ---- on-chip counters ----------------------------------------------------------------------------------------------
     cc = {}
-    for sub in ("tcc", "sq", "tcp"):
+    for sub in ("tcc", "sq", "tcp", "lds"):
         for key, cs in counters(f"{raw}/{sub}").items():
             for cn, (s, n) in cs.items():
                 cc.setdefault(key, {})[cn] = {"avg_per_launch": s / n, "launches": n}
@@ -88,6 +92,8 @@ def main():
             for c in ("SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"):
                 if g(c) is not None:
                     d[c + "/SQ_WAVE_CYCLES"] = g(c) / g("SQ_WAVE_CYCLES")
+        if g("SQ_LDS_IDX_ACTIVE") and g("SQ_LDS_BANK_CONFLICT") is not None:
+            d["lds_bank_conflict_cycles/lds_active_cycles"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
         if g("SQ_INSTS_VALU") and g("SQ_INSTS_VMEM_RD"):
             d["valu_insts_per_vmem_read"] = g("SQ_INSTS_VALU") / g("SQ_INSTS_VMEM_RD")
         v["derived"] = d

@@ -1158,10 +1158,14 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.tile_k = (uint32_t)value;
         } else if (k == "tile_s") {
             st.tile_s = (uint32_t)value;
+        } else if (k == "tile_ku") {
+            st.tile_ku = (uint32_t)value;
         } else if (k == "tile_t") {
             st.tile_t = (uint32_t)value;
         } else if (k == "tile_b") {
             st.tile_b = (uint32_t)value;
+        } else if (k == "ov_tile_kb") {
+            st.ov_tile_bytes = (size_t)std::max(0.0, value) << 10;
         } else if (k == "tile_auto") {
             st.tile_auto = value != 0.0;
         } else if (k == "tile_overlap") {

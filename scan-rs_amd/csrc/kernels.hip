@@ -188,19 +188,17 @@ __global__ void build_bounds_kernel(const uint64_t *__restrict__ indptr, const u
 // MAT: the first `fstart` links of the map were evaluated once per nonzero into `fvals` (materialized prefix, see
 // ensure_fvals); the kernel reads that f64 instead of the u32 count and applies only the remaining links, which index
 // their arrays by the outer position (wave-uniform) — no scattered gather of a scale per nonzero.
-// HOT = false: no vector ever gets a workgroup (n_hot must be 0) and the kernel declares no LDS at all — the form that runs
-// beside the persistent tile kernel of tiles.hip, whose two tile buffers leave 6 KB of a CU's LDS.
-template <int NACC, bool MAT, bool HOT = true>
+template <int NACC, bool MAT>
 __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
     const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices, const uint32_t *__restrict__ values,
     const uint32_t *__restrict__ bounds, uint32_t nb, uint32_t b0, uint32_t b1, int first, int last, uint64_t n_outer,
     const uint32_t *__restrict__ order, uint32_t n_hot, DevMap map, const double *__restrict__ X, uint32_t ldx, uint32_t l,
     double *out, uint32_t ldo, const double *__restrict__ off_a, uint32_t rank, const double *__restrict__ off_w, uint32_t ldw,
     const double *__restrict__ fvals, int fstart) {
-    __shared__ d2 part[HOT ? 3 : 1][HOT ? NACC : 1][HOT ? 64 : 1];
+    __shared__ d2 part[3][NACC][64];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const bool hot = HOT && blockIdx.x < n_hot; // block-uniform
+    const bool hot = blockIdx.x < n_hot; // block-uniform
     const uint64_t slot = hot ? (uint64_t)blockIdx.x : (uint64_t)n_hot + ((uint64_t)blockIdx.x - n_hot) * 4u + wave;
     if (slot >= n_outer) return; // never taken by a hot block
     const uint64_t row64 = order ? (uint64_t)order[slot] : slot;
@@ -283,7 +281,7 @@ __global__ __launch_bounds__(256) void spmm_gather2d_kernel(
             }
         }
     }
-    if (HOT && hot) { // block-uniform: all four waves of a hot block reach the barrier
+    if (hot) { // block-uniform: all four waves of a hot block reach the barrier
         if (wave > 0) {
 #pragma unroll
             for (int a = 0; a < NACC; a++) part[wave - 1][a][lane] = acc[a];
@@ -1613,6 +1611,94 @@ static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const
     SCANRS_HIP(hipGetLastError());
 }
 
+// The overflow part of a tile layout beside the persistent tile kernel (tiles.hip): two gather waves per SIMD, a few
+// nonzeros per (vector, step) — the pass is bound by the chain of dependent loads of a task (bounds -> indices / weights ->
+// panel rows), not by the texture path. One wave therefore works NV consecutive vectors as ONE task: their bounds in one
+// load, their nonzeros (usually fewer than 64 together) in one load of indices and one of weights, the row gathers of all of
+// them back to back; the accumulators of the NV vectors are compile-time registers (the gather loop is unrolled over the
+// vectors, its bounds are scalars). Weights are materialized (fvals), no map, no offset; sums carried through `out`.
+template <int NV>
+__global__ __launch_bounds__(256) void spmm_gather_ov_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                             const double *__restrict__ fvals, const uint32_t *__restrict__ bounds, uint32_t nb,
+                                                             uint32_t b0, uint32_t b1, int first, uint64_t n_outer, const double *__restrict__ X,
+                                                             uint32_t ldx, uint32_t l, double *out, uint32_t ldo) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t task = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint64_t row0 = task * NV;
+    if (row0 >= n_outer) return;
+    uint32_t len_l = 0, blo = 0, bhi = 0;
+    if (lane < (uint32_t)NV && row0 + lane < n_outer) {
+        const uint32_t *bd = bounds + (row0 + lane) * (nb + 1);
+        const uint32_t o0 = bd[b0];
+        len_l = bd[b1] - o0;
+        const uint64_t base = indptr[row0 + lane] + o0;
+        blo = (uint32_t)base;
+        bhi = (uint32_t)(base >> 32);
+    }
+    uint32_t start[NV + 1];
+    uint64_t base[NV];
+    start[0] = 0;
+#pragma unroll
+    for (int r = 0; r < NV; r++) {
+        start[r + 1] = start[r] + rdlane(len_l, r);
+        base[r] = ((uint64_t)rdlane(bhi, r) << 32) | rdlane(blo, r);
+    }
+    const uint32_t total = start[NV];
+    if (total == 0 && !first) return;
+    const bool act = lane * 2u < l;
+    const uint32_t lcol = act ? lane * 2u : 0u;
+    d2 acc[NV];
+#pragma unroll
+    for (int r = 0; r < NV; r++) {
+        acc[r] = (d2){0.0, 0.0};
+        if (!first && act && row0 + r < n_outer && start[r + 1] > start[r]) acc[r] = *reinterpret_cast<const d2 *>(out + (row0 + r) * ldo + lcol);
+    }
+    for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
+        const uint32_t p = c0 + lane;
+        uint32_t idx = 0;
+        double f = 0.0;
+        if (p < total) {
+            uint64_t a = base[0] + p;
+#pragma unroll
+            for (int r = 1; r < NV; r++)
+                if (p >= start[r]) a = base[r] + (p - start[r]);
+            idx = indices[a];
+            f = fvals[a];
+        }
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < NV; r++) {
+                const uint32_t lo = max(start[r], c0) - c0, hi = min(start[r + 1], c0 + 64u);
+                if (hi <= c0 + lo) continue; // scalar: nothing of vector r in this chunk
+                const uint32_t n = hi - c0;
+                uint32_t j = lo;
+                for (; j + 8u <= n; j += 8u) {
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; u++) {
+                        const uint32_t g = rdlane(idx, j + u);
+                        const double fv = bcast<double>(f, j + u);
+                        const d2 x = *reinterpret_cast<const d2 *>(X + (size_t)g * ldx + lcol);
+                        acc[r].x = fma(fv, x.x, acc[r].x);
+                        acc[r].y = fma(fv, x.y, acc[r].y);
+                    }
+                }
+                for (; j < n; j++) {
+                    const uint32_t g = rdlane(idx, j);
+                    const double fv = bcast<double>(f, j);
+                    const d2 x = *reinterpret_cast<const d2 *>(X + (size_t)g * ldx + lcol);
+                    acc[r].x = fma(fv, x.x, acc[r].x);
+                    acc[r].y = fma(fv, x.y, acc[r].y);
+                }
+            }
+        }
+    }
+    if (act) {
+#pragma unroll
+        for (int r = 0; r < NV; r++)
+            if (row0 + r < n_outer && (first || start[r + 1] > start[r])) *reinterpret_cast<d2 *>(out + (row0 + r) * ldo + lcol) = acc[r];
+    }
+}
+
 uint32_t ensure_bounds_public(Storage &st, SparseCopy &cp) { return ensure_bounds(st, cp); }
 
 // fout[p] = the whole chain of `map` at nonzero p of `cp` (tiles.hip: weights of the overflow part)
@@ -1635,19 +1721,20 @@ void materialize_map_values(Storage &st, SparseCopy &cp, const DevMap &map, doub
 void launch_gather2d_ov(Storage &st, hipStream_t s, SparseCopy &ov, const double *X, uint32_t ldx, uint32_t l, double *out,
                         uint32_t ldo) {
     const uint32_t nb = (uint32_t)((ov.n_inner + (1ull << BT_SHIFT) - 1) >> BT_SHIFT); // bounds were built with the layout
-    uint32_t m = (uint32_t)(st.l2_tile_bytes / ((size_t)(1u << BT_SHIFT) * l * 8));
+    // panel slice per step: the L2 slice of the blocked gather unless ov_tile_bytes says otherwise (one step over the whole panel
+    // finishes this gather sooner but its Infinity-Cache / HBM row reads slow the tile kernel's staging down: measured worse)
+    const size_t ovb = st.ov_tile_bytes ? st.ov_tile_bytes : st.l2_tile_bytes;
+    uint32_t m = (uint32_t)(ovb / ((size_t)(1u << BT_SHIFT) * l * 8));
     if (m < 1u) m = 1u;
     const uint32_t steps = (nb + m - 1u) / m;
-    const dim3 grid((unsigned)((ov.n_outer + 3) / 4)), block(256);
-    DevMap none;
-    memset(&none, 0, sizeof(none));
+    constexpr int NV = 4; // vectors per wave
+    const dim3 grid((unsigned)((ov.n_outer + 4u * NV - 1) / (4u * NV))), block(256);
     const double bytes = ((double)ov.nnz * 12.0 + (double)(ov.n_outer + 1) * 8.0 + (double)ov.n_inner * l * 8.0 + (double)ov.n_outer * l * 8.0) / steps;
     for (uint32_t sidx = 0; sidx < steps; sidx++) {
         const uint32_t b0 = sidx * m, b1 = std::min(nb, b0 + m);
         if (st.prof.on) st.prof.begin(s, ov.n_outer >= ov.n_inner ? "spmm_gather2d_ov/long-outer" : "spmm_gather2d_ov/short-outer", bytes, (double)ov.nnz * 8.0 * l / steps);
-        hipLaunchKernelGGL((spmm_gather2d_kernel<1, true, false>), grid, block, 0, s, ov.indptr.p, ov.indices.p, (const uint32_t *)nullptr,
-                           ov.bounds.p, nb, b0, b1, sidx == 0 ? 1 : 0, sidx + 1 == steps ? 1 : 0, ov.n_outer, (const uint32_t *)nullptr, 0u, none,
-                           X, ldx, l, out, ldo, (const double *)nullptr, 0u, (const double *)nullptr, 0u, ov.fvals.p, 0);
+        hipLaunchKernelGGL((spmm_gather_ov_kernel<NV>), grid, block, 0, s, ov.indptr.p, ov.indices.p, ov.fvals.p, ov.bounds.p, nb, b0, b1,
+                           sidx == 0 ? 1 : 0, ov.n_outer, X, ldx, l, out, ldo);
         if (st.prof.on) st.prof.end(s);
     }
     SCANRS_HIP(hipGetLastError());

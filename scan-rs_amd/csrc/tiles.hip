@@ -45,7 +45,7 @@ typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef __attribute__((address_space(3))) const char *lds_cptr_t;
 
 struct TileShape {
-    uint32_t T, B, K, S, sps, nset, nt, n_parts, tpp;
+    uint32_t T, B, K, KU, S, sps, nset, nt, n_parts, tpp; // KU of the K positions of a (slot, visit) pair are "unit" positions
 };
 
 // ---- builder -------------------------------------------------------------------------------------------------------
@@ -80,55 +80,92 @@ __global__ __launch_bounds__(256) void tile_assign_kernel(const uint64_t *__rest
     const uint64_t g = o / sh.S;
     const uint32_t sl = (uint32_t)(o % sh.S), b = sl / sh.sps, q = sl % sh.sps;
     const uint64_t idx_end = (uint64_t)t1 * sh.T;
-    uint32_t v = t0, cap = sh.K;
+    // Two first-come-first-served queues: the KU unit positions of a visit take only nonzeros of count 1 (whose weight is the
+    // product of a per-outer and a per-inner factor: the kernel adds their panel rows without a weight), the K - KU general
+    // positions take anything. A count-1 nonzero goes where it is served first (unit queue on a tie).
+    const uint32_t KG = sh.K - sh.KU;
+    uint32_t vu = t0, cu = sh.KU, vg = t0, cg = KG;
     unsigned long long n_ov = 0;
     unsigned long long op = FILL ? ov_off[e] : 0ull;
     for (uint64_t p = lo; p < end; p++) {
         const uint32_t idx = indices[p];
         if ((uint64_t)idx >= idx_end) break;
-        const uint32_t tau = idx / sh.T;
-        if (tau > v) {
-            v = tau;
-            cap = sh.K;
+        const uint32_t tau = idx / sh.T, cnt = values[p];
+        const uint32_t last = min(tau + sh.B - 2u, t1 - 1u); // last visit with tile tau in the ring (and inside the part)
+        // where each queue would serve it
+        uint32_t au = vu, bu = cu, ag = vg, bg = cg;
+        if (tau > au) {
+            au = tau;
+            bu = sh.KU;
         }
-        if (cap == 0) {
-            v++;
-            cap = sh.K;
+        if (bu == 0) {
+            au++;
+            bu = sh.KU;
         }
-        // tile tau has left the ring (or the part is over), or the count does not fit the position's byte: overflow part
-        if (v > tau + sh.B - 2u || v >= t1 || values[p] > 255u) {
+        if (tau > ag) {
+            ag = tau;
+            bg = KG;
+        }
+        if (bg == 0) {
+            ag++;
+            bg = KG;
+        }
+        const bool can_u = sh.KU > 0 && cnt == 1u && au <= last;
+        const bool can_g = KG > 0 && cnt <= 255u && ag <= last;
+        if (!can_u && !can_g) { // no visit has room while tile tau is in the ring (or the count does not fit a byte): overflow part
             if (FILL) {
                 ov_indices[op] = idx;
-                ov_values[op] = values[p];
+                ov_values[op] = cnt;
                 op++;
             } else {
                 n_ov++;
             }
             continue;
         }
-        if (FILL) {
-            const uint64_t rec = ((g * sh.nt + v) * sh.nset + b) * 64u + (uint64_t)q * sh.K + (sh.K - cap);
-            prow[rec] = (uint8_t)((tau % sh.B) * sh.T + (idx - tau * sh.T));
-            pcnt[rec] = (uint8_t)values[p];
+        const bool use_u = can_u && (!can_g || au <= ag);
+        uint32_t v, j;
+        if (use_u) {
+            v = au;
+            j = sh.KU - bu;
+            vu = au;
+            cu = bu - 1u;
+        } else {
+            v = ag;
+            j = sh.KU + (KG - bg);
+            vg = ag;
+            cg = bg - 1u;
         }
-        cap--;
+        if (FILL) {
+            const uint64_t rec = ((g * sh.nt + v) * sh.nset + b) * 64u + (uint64_t)q * sh.K + j;
+            prow[rec] = (uint8_t)((tau % sh.B) * sh.T + (idx - tau * sh.T));
+            pcnt[rec] = (uint8_t)cnt;
+        }
     }
     if (!FILL) ovc[e] = n_ov;
 }
 
-// an unused position reads a row that is certainly in the ring at its visit — row 0 of the visit's own tile — with weight 0
+// An unused general position reads a row that is certainly in the ring at its visit — row 0 of the visit's own tile — with
+// weight 0; an unused unit position (no weight) reads the row of zeros that the kernel keeps behind the ring (row B T).
 __global__ void tile_init_rows_kernel(uint8_t *__restrict__ prow, uint64_t n_rec, TileShape sh) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // one thread per 4 records
     if (e * 4u >= n_rec) return;
     const uint32_t v = (uint32_t)((e * 4u / (sh.nset * 64u)) % sh.nt);
-    const uint32_t code = (v % sh.B) * sh.T;
-    reinterpret_cast<uint32_t *>(prow)[e] = code * 0x01010101u;
+    const uint32_t own = (v % sh.B) * sh.T, zero = sh.B * sh.T;
+    uint32_t word = 0;
+    for (uint32_t i = 0; i < 4u; i++) {
+        const uint32_t lane = (uint32_t)((e * 4u + i) & 63u);
+        word |= ((lane % sh.K) < sh.KU ? zero : own) << (8u * i);
+    }
+    reinterpret_cast<uint32_t *>(prow)[e] = word;
 }
 
 // pw[rec] = the map chain at the record's (count, outer, inner); unused positions (count 0) get weight 0.
 // One thread per record; nset * 64 is a power of two and (group, visit) pairs fit 32 bits (checked by the builder).
+// Unit mode (uo / vi given): the stored weight is w / (uo[outer] * vi[inner]) — the kernel works on panel rows scaled by
+// vi and scales a vector's sum by uo at the end; the unit positions (count 1: quotient 1) are not read at all.
 __global__ __launch_bounds__(256) void tile_weights_kernel(const uint8_t *__restrict__ prow, const uint8_t *__restrict__ pcnt,
-                                                           double *__restrict__ pw, uint64_t n_rec, uint64_t n_outer, TileShape sh, DevMap map) {
+                                                           double *__restrict__ pw, uint64_t n_rec, uint64_t n_outer, TileShape sh, DevMap map,
+                                                           const double *__restrict__ uo, const double *__restrict__ vi) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_rec) return;
     const uint32_t cnt = pcnt[e];
@@ -145,8 +182,55 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint8_t *__rest
         const uint32_t d = (v % sh.B + sh.B - bufi) % sh.B; // visits the nonzero waited
         const uint32_t inner = (v - d) * sh.T + r;
         w = eval_map(map, cnt, (uint32_t)o, inner);
+        if (uo) {
+            const double d2 = uo[o] * vi[inner];
+            w = (d2 != 0.0 && isfinite(d2)) ? w / d2 : 0.0; // a zero unit weight means a zero weight for every count (log1p, square, scale)
+        }
     }
     pw[e] = w;
+}
+
+// The factor of the weight of a count-1 nonzero that depends on one side only (outer or inner position): the chain run on
+// x = 1 with the links of the other side left out; the side that owns the links in front of the nonlinear links also owns
+// those (nl_outer). uo[o] * vi[i] == f(1, o, i) up to rounding for the chains tile_map_separable() accepts.
+__global__ void tile_unit_factor_kernel(DevMap map, int side_outer, int nl_outer, uint64_t n, double *__restrict__ out) {
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    double x = 1.0;
+    const bool owns_nl = (side_outer != 0) == (nl_outer != 0);
+    for (int i = 0; i < map.n; i++) {
+        const DevOp &op = map.ops[i];
+        switch (op.kind) {
+        case OP_SCALE_AXIS:
+            if ((op.a_outer != 0) == (side_outer != 0)) x = op.a[idx] * x;
+            break;
+        case OP_LN_1P:
+            if (owns_nl) x = map_ln(x + 1.0);
+            break;
+        case OP_LOG2_1P:
+            if (owns_nl) x = map_log2(x + 1.0);
+            break;
+        case OP_LOG10_1P:
+            if (owns_nl) x = map_log10(x + 1.0);
+            break;
+        case OP_SQUARE:
+            if (owns_nl) x = x * x;
+            break;
+        default:
+            break;
+        }
+    }
+    out[idx] = x;
+}
+
+// Xc[r, 0:l] = vi[r] * X[r, 0:l] in compact rows of ldc columns (the panel the unit-mode kernel stages)
+__global__ void tile_scale_panel_kernel(const double *__restrict__ X, uint32_t ldx, uint64_t rows, uint32_t l, uint32_t ldc,
+                                        const double *__restrict__ vi, double *__restrict__ Xc) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * ldc) return;
+    const uint64_t r = e / ldc;
+    const uint32_t c = (uint32_t)(e - r * ldc);
+    Xc[e] = c < l ? vi[r] * X[r * ldx + c] : 0.0;
 }
 
 __global__ void tile_ovptr_kernel(const unsigned long long *__restrict__ ov_off, uint64_t n_outer, uint32_t n_parts,
@@ -165,12 +249,17 @@ struct TileLayout {
     DevBuf<uint8_t> pcnt;  // same index: the raw count (0 = unused position; counts above 255 live in the overflow part)
     DevBuf<double> pw;     // same index: the weight under the map `sig_*`
     SparseCopy ov;         // the overflow part: indptr / indices / values (counts) / fvals (weights)
+    // unit mode (sh.KU > 0 and a separable map): per-outer / per-inner factors of the weight of a count-1 nonzero
+    bool unit_mode = false;
+    DevBuf<double> uo, vi;
     // identity of the map the weights were evaluated under (MapOp ids are never reused); -1: none yet
     int sig_n = -1;
     uint32_t sig_id[MAX_OPS] = {};
     int sig_outer[MAX_OPS] = {};
     double bytes() const { return (double)prow.n + (double)pcnt.n + (double)pw.n * 8.0 + (double)ov.nnz * 16.0; }
-    bool structure_matches(const Storage &st) const { return sh.K == st.tile_k && sh.S == st.tile_s && sh.T == st.tile_t && sh.B == st.tile_b; }
+    bool structure_matches(const Storage &st) const {
+        return sh.K == st.tile_k && sh.S == st.tile_s && sh.T == st.tile_t && sh.B == st.tile_b && sh.KU == (st.tile_k == 2u && st.tile_ku ? 1u : 0u);
+    }
     bool weights_match(const DevMap &map) const {
         if (sig_n != map.n) return false;
         for (int i = 0; i < map.n; i++)
@@ -184,6 +273,7 @@ void tile_layout_free(TileLayout *t) { delete t; }
 uint32_t ensure_bounds_public(Storage &st, SparseCopy &cp); // kernels.hip
 void materialize_map_values(Storage &st, SparseCopy &cp, const DevMap &map, double *fout); // kernels.hip
 
+// unit positions exist for K = 2 only (one unit + one general position per visit)
 bool tile_shape_ok(uint32_t K, uint32_t S, uint32_t T, uint32_t B) {
     const bool ks = (K == 2 && (S == 32 || S == 28)) || (K == 3 && S == 32) || (K == 4 && (S == 32 || S == 28));
     return ks && B >= 2 && T >= 8 && T <= 24u * K && B * T <= 192;
@@ -196,6 +286,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
     auto tl = std::make_unique<TileLayout>();
     TileShape &sh = tl->sh;
     sh.K = st.tile_k;
+    sh.KU = st.tile_k == 2u && st.tile_ku ? 1u : 0u;
     sh.S = st.tile_s;
     sh.T = st.tile_t;
     sh.B = st.tile_b;
@@ -271,13 +362,36 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
     return tl.release();
 }
 
+// Is f(1, outer, inner) a product of an outer and an inner factor? Yes when the links in front of the first nonlinear link
+// (log, square) index one side only and no binomial residual link takes part; nl_outer = the side that owns them.
+static bool tile_map_separable(const DevMap &map, int &nl_outer) {
+    bool nonlinear = false, pre_outer = false, pre_inner = false;
+    for (int i = 0; i < map.n; i++) {
+        const int k = map.ops[i].kind;
+        if (k == OP_BINOM_DEV || k == OP_BINOM_PEARSON) return false;
+        if (k == OP_LN_1P || k == OP_LOG2_1P || k == OP_LOG10_1P || k == OP_SQUARE) nonlinear = true;
+        if (k == OP_SCALE_AXIS && !nonlinear) (map.ops[i].a_outer ? pre_outer : pre_inner) = true;
+    }
+    if (nonlinear && pre_outer && pre_inner) return false;
+    nl_outer = pre_inner ? 0 : 1;
+    return true;
+}
+
 // weights of every position and of the overflow part under `map`
 static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &cp, const DevMap &map) {
     Tick tick("tile layout weights");
     const uint64_t n_rec = tl.prow.n;
+    int nl_outer = 1;
+    tl.unit_mode = tl.sh.KU > 0 && tile_map_separable(map, nl_outer);
+    if (tl.unit_mode) {
+        if (tl.uo.n != cp.n_outer) tl.uo.alloc(std::max<uint64_t>(cp.n_outer, 1));
+        if (tl.vi.n != cp.n_inner) tl.vi.alloc(std::max<uint64_t>(cp.n_inner, 1));
+        hipLaunchKernelGGL(tile_unit_factor_kernel, dim3((unsigned)((cp.n_outer + 255) / 256)), dim3(256), 0, st.stream, map, 1, nl_outer, cp.n_outer, tl.uo.p);
+        hipLaunchKernelGGL(tile_unit_factor_kernel, dim3((unsigned)((cp.n_inner + 255) / 256)), dim3(256), 0, st.stream, map, 0, nl_outer, cp.n_inner, tl.vi.p);
+    }
     if (n_rec)
         hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st.stream, tl.prow.p, tl.pcnt.p, tl.pw.p, n_rec,
-                           cp.n_outer, tl.sh, map);
+                           cp.n_outer, tl.sh, map, tl.unit_mode ? tl.uo.p : (const double *)nullptr, tl.unit_mode ? tl.vi.p : (const double *)nullptr);
     if (tl.ov.nnz) materialize_map_values(st, tl.ov, map, tl.ov.fvals.p);
     SCANRS_HIP(hipGetLastError());
     if (trace_on()) (void)hipStreamSynchronize(st.stream);
@@ -294,12 +408,16 @@ namespace {
 struct TileArgs {
     const uint8_t *prow;
     const double *pw;
+    const double *uo; // unit mode: factor applied to a vector's sum at the end
     uint64_t n_groups, n_outer, n_inner;
     TileShape sh;
 };
 
 // parts[part][outer][:] = sum over the part's visits of weight * X[inner, :]
-template <int K, int S>
+// KU > 0 (unit mode): position j < KU of every (slot, visit) pair holds a count-1 nonzero or nothing: its row is ADDED (no
+// weight, no v_readlane of one: the panel staged here was scaled by the per-inner factor, the sums are scaled by the
+// per-outer factor at the end); an unused unit position reads a row of zeros kept behind the ring.
+template <int K, int S, int KU>
 __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double *__restrict__ X, uint32_t ldx, uint32_t l,
                                                double *__restrict__ parts, uint32_t ldo, uint64_t part_stride, uint32_t n_items) {
     constexpr int SPS = 64 / K;
@@ -308,10 +426,15 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t rowbytes = ldx * 8u;
     const uint32_t tile_bytes = ta.sh.T * rowbytes;
-    const uint32_t n_parts = ta.sh.n_parts, tpp = ta.sh.tpp, nt = ta.sh.nt, nbuf = ta.sh.B;
+    const uint32_t tpp = ta.sh.tpp, nt = ta.sh.nt, nbuf = ta.sh.B;
+    const uint32_t n_wgg = (uint32_t)((ta.n_groups + TL_NW - 1) / TL_NW);
     const char *Xb = reinterpret_cast<const char *>(X);
     const uint64_t x_bytes = ta.n_inner * (uint64_t)rowbytes;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
+    if (ta.sh.KU) { // the row of zeros behind the ring (unused unit positions); visible to everybody after the first barrier
+        const uint32_t zoff = nbuf * tile_bytes;
+        for (uint32_t i = threadIdx.x * 16u; i < rowbytes; i += blockDim.x * 16u) *reinterpret_cast<d2 *>(lds + zoff + i) = (d2){0.0, 0.0};
+    }
 
     // LDS-DMA staging of tile t into ring buffer `buf`: 1 KB per wave-instruction, chunk i of this wave. No branches (a join
     // makes the compiler wait for ALL outstanding LDS reads at the next use) and hand-issued for the same reason (with the
@@ -338,7 +461,19 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
                      : "s"(limit), "v"(voff), "s"(m0v), "s"(sbase)
                      : "memory", "vcc");
     };
-    const uint32_t lcol16 = (lane * 2u < l ? lane : 0u) * 16u;
+    // Lanes that own no column pair still take part in every ds_read_b128, which the LDS serves in four groups of 16 lanes
+    // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, {32-35,44-47,52-59}, {36-43,48-51,60-63}: MI355X_MICROARCH.md, LDS): an idle
+    // lane that re-read lane 0's bytes hit the banks of an active lane of ITS group at another address — a 2-way conflict in
+    // two of the four groups, 6 LDS cycles per row instead of 4 (measured: SQ_LDS_BANK_CONFLICT = 1/3 of SQ_LDS_IDX_ACTIVE at
+    // l = 100). It re-reads the first active lane of its own group instead: same address, broadcast, no extra cycle.
+    uint32_t src_lane = lane;
+    if (lane * 2u >= l) {
+        const uint32_t grp = lane < 32u ? (((lane >= 4u && lane < 12u) || (lane >= 16u && lane < 20u) || lane >= 28u) ? 1u : 0u)
+                                        : (((lane >= 36u && lane < 44u) || (lane >= 48u && lane < 52u) || lane >= 60u) ? 3u : 2u);
+        const uint32_t first = grp == 0u ? 0u : grp == 1u ? 4u : grp == 2u ? 32u : 36u;
+        src_lane = first * 2u < l ? first : 0u;
+    }
+    const uint32_t lcol16 = src_lane * 16u;
     const lds_cptr_t ring = (lds_cptr_t)(lds + lcol16);
     uint32_t rowbytes_v = rowbytes;
     asm volatile("" : "+v"(rowbytes_v)); // a vector register: v_mad_u32_u24 takes one scalar operand
@@ -346,7 +481,10 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
     const uint32_t *prow32 = reinterpret_cast<const uint32_t *>(ta.prow);
 
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const uint32_t part = item % n_parts, wgg = item / n_parts;
+        // part-major: the workgroups resident at one time walk the SAME range of tiles, so a tile comes from HBM once and from
+        // L2 / Infinity Cache for everybody else (with the parts interleaved every workgroup streamed its own range of the
+        // 800 MB panel of the gene-major product: 118 GB of staging reads per pass, 5 TB/s, and that bound the pass)
+        const uint32_t part = item / n_wgg, wgg = item - part * n_wgg;
         const uint32_t t0 = part * tpp, t1 = min(nt, t0 + tpp);
         const uint64_t group_raw = (uint64_t)wgg * TL_NW + wave;
         const bool live = group_raw < ta.n_groups;
@@ -399,7 +537,12 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
             constexpr int PPS = SPS * K;      // positions per full set
             constexpr int NPT = S * K;        // positions per visit
             constexpr int WR = TL_W + 3;      // weights live from R(g) to F(g)
-            constexpr int DM = NPT / CH;      // steps between two LDS-DMA chunks
+            // the next tile's LDS-DMA chunks go out in the first third of the visit, a few steps apart (all at once they queue on
+            // the texture path; spread over the whole visit the last ones are still in flight at the barrier: -1.5 ms per pass)
+#ifndef TL_DMA_EARLY
+#define TL_DMA_EARLY 1
+#endif
+            constexpr int DM = TL_DMA_EARLY ? (NPT / (3 * CH) > 1 ? NPT / (3 * CH) : 1) : NPT / CH;
             uint32_t rows4 = 0;
             uint32_t offs[2];
             lds_cptr_t addr[2];
@@ -410,8 +553,13 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
                 if (i >= 2 + TL_W) { // F(i - 2 - W)
                     const int g = i - 2 - TL_W;
                     const int sl = (g / PPS) * SPS + (g % PPS) / K;
-                    acc[sl].x = fma(wq[g % WR], x[g % TL_W].x, acc[sl].x);
-                    acc[sl].y = fma(wq[g % WR], x[g % TL_W].y, acc[sl].y);
+                    if ((g % PPS) % K < KU) { // unit position: the row as it is
+                        acc[sl].x += x[g % TL_W].x;
+                        acc[sl].y += x[g % TL_W].y;
+                    } else {
+                        acc[sl].x = fma(wq[g % WR], x[g % TL_W].x, acc[sl].x);
+                        acc[sl].y = fma(wq[g % WR], x[g % TL_W].y, acc[sl].y);
+                    }
                     // pin the FMAs here (pure arithmetic: without a use the compiler sinks them to the end of the kernel)
                     asm volatile("" : "+v"(acc[sl].x), "+v"(acc[sl].y));
                 }
@@ -431,9 +579,9 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
                         rows4 = rdlane(crow[b], p);
                     }
                     offs[i % 2] = (rows4 >> (8 * (p % 4))) & 255u;
-                    wq[i % WR] = __hiloint2double((int)rdlane(whi[b], p), (int)rdlane(wlo[b], p));
+                    if (p % K >= KU) wq[i % WR] = __hiloint2double((int)rdlane(whi[b], p), (int)rdlane(wlo[b], p));
                 }
-                if (i % DM == DM / 2 && i / DM < CH) stage_chunk(t + 1, bufn, i / DM);
+                if (i % DM == (TL_DMA_EARLY ? 0 : DM / 2) && i / DM < CH) stage_chunk(t + 1, bufn, i / DM);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -448,24 +596,32 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
 #pragma unroll
             for (int sl = 0; sl < S; sl++) {
                 const uint64_t o = group * S + sl;
-                if (o < ta.n_outer) *reinterpret_cast<d2 *>(dst + o * ldo + lane * 2u) = acc[sl];
+                if (o < ta.n_outer) {
+                    d2 r = acc[sl];
+                    if (KU > 0) { // the per-outer factor of the unit weight
+                        const double uf = ta.uo[o];
+                        r.x *= uf;
+                        r.y *= uf;
+                    }
+                    *reinterpret_cast<d2 *>(dst + o * ldo + lane * 2u) = r;
+                }
             }
         }
     }
 }
 
-template <int K, int S>
+template <int K, int S, int KU>
 __global__ __launch_bounds__(64 * TL_NW, 2) void spmm_tile_kernel(TileArgs ta, const double *__restrict__ X, uint32_t ldx, uint32_t l,
                                                                   double *__restrict__ parts, uint32_t ldo, uint64_t part_stride,
                                                                   uint32_t n_items) {
-    spmm_tile_body<K, S>(ta, X, ldx, l, parts, ldo, part_stride, n_items);
+    spmm_tile_body<K, S, KU>(ta, X, ldx, l, parts, ldo, part_stride, n_items);
 }
 // <= 168 VGPRs: 2 tile waves + 2 gather waves of 88 per SIMD
-template <int K, int S>
+template <int K, int S, int KU>
 __global__ __launch_bounds__(64 * TL_NW) __attribute__((amdgpu_waves_per_eu(3, 3))) void spmm_tile_kernel_r168(
     TileArgs ta, const double *__restrict__ X, uint32_t ldx, uint32_t l, double *__restrict__ parts, uint32_t ldo, uint64_t part_stride,
     uint32_t n_items) {
-    spmm_tile_body<K, S>(ta, X, ldx, l, parts, ldo, part_stride, n_items);
+    spmm_tile_body<K, S, KU>(ta, X, ldx, l, parts, ldo, part_stride, n_items);
 }
 
 // out[o, :] = sum over parts (in order) + overflow sum + LowRankOffset term  (sqz/src/low_rank_offset.rs:76-80)
@@ -497,17 +653,17 @@ __global__ __launch_bounds__(256) void tile_finish_kernel(const double *__restri
     *reinterpret_cast<d2 *>(out + o * ldo + c) = s;
 }
 
-template <int K, int S>
+template <int K, int S, int KU>
 void launch_tile_kernel(Storage &st, const TileArgs &ta, const double *X, uint32_t ldx, uint32_t l, double *parts, uint32_t ldo,
                         uint64_t part_stride, uint32_t n_items, uint32_t grid) {
-    const size_t shmem = (size_t)ta.sh.B * ta.sh.T * ldx * 8;
+    const size_t shmem = ((size_t)ta.sh.B * ta.sh.T + (ta.sh.KU ? 1u : 0u)) * ldx * 8; // the ring (+ the row of zeros)
     if constexpr (S <= 28) {
-        SCANRS_HIP(hipFuncSetAttribute((const void *)spmm_tile_kernel_r168<K, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL((spmm_tile_kernel_r168<K, S>), dim3(grid), dim3(64 * TL_NW), shmem, st.stream, ta, X, ldx, l, parts, ldo, part_stride,
+        SCANRS_HIP(hipFuncSetAttribute((const void *)spmm_tile_kernel_r168<K, S, KU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((spmm_tile_kernel_r168<K, S, KU>), dim3(grid), dim3(64 * TL_NW), shmem, st.stream, ta, X, ldx, l, parts, ldo, part_stride,
                            n_items);
     } else {
-        SCANRS_HIP(hipFuncSetAttribute((const void *)spmm_tile_kernel<K, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL((spmm_tile_kernel<K, S>), dim3(grid), dim3(64 * TL_NW), shmem, st.stream, ta, X, ldx, l, parts, ldo, part_stride,
+        SCANRS_HIP(hipFuncSetAttribute((const void *)spmm_tile_kernel<K, S, KU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((spmm_tile_kernel<K, S, KU>), dim3(grid), dim3(64 * TL_NW), shmem, st.stream, ta, X, ldx, l, parts, ldo, part_stride,
                            n_items);
     }
 }
@@ -516,7 +672,7 @@ void launch_tile_kernel(Storage &st, const TileArgs &ta, const double *X, uint32
 
 bool spmm_tiles_ok(const Storage &st, const SparseCopy &cp, uint32_t ldx, uint32_t l) {
     return l >= 16 && l <= TL_LMAX && (ldx & 1u) == 0 && cp.n_outer > 0 && cp.n_inner > 0 && cp.nnz > 0 &&
-           (size_t)st.tile_b * st.tile_t * even_up(l) * 8 <= TL_LDS;
+           ((size_t)st.tile_b * st.tile_t + 1u) * even_up(l) * 8 <= TL_LDS;
 }
 
 // Auto path (spmm_path 0): the hybrid product serves a large matrix once its layout under this map exists — built when a
@@ -558,11 +714,20 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     const TileShape &sh = tl.sh;
     // the kernels want compact panel rows (a tile is one contiguous run of bytes): a block of a wider panel is copied first
     const uint32_t ldc = even_up(l);
-    if (ldx != ldc) {
+    const double *Xov = X; // the overflow part works on the panel as it came
+    const uint32_t ldxov = ldx;
+    if (tl.unit_mode) { // unit mode: the tile kernel's panel carries the per-inner factor of the unit weight
+        double *xc = st.scratch.get<double>("tile_xc", (size_t)cp.n_inner * ldc);
+        const uint64_t n = cp.n_inner * (uint64_t)ldc;
+        hipLaunchKernelGGL(tile_scale_panel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, X, ldx, cp.n_inner, l, ldc, tl.vi.p, xc);
+        X = xc;
+        ldx = ldc;
+    } else if (ldx != ldc) {
         double *xc = st.scratch.get<double>("tile_xc", (size_t)cp.n_inner * ldc);
         launch_copy_cols(st, X, ldx, xc, ldc, cp.n_inner, l);
         X = xc;
         ldx = ldc;
+        Xov = xc;
     }
     int dev = 0, n_cu = 256;
     (void)hipGetDevice(&dev);
@@ -579,30 +744,31 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
             hipStream_t ovs = st.ov();
             SCANRS_HIP(hipEventRecord(st.ev_in, st.stream)); // the panel (and the scratch zero-fills) are ready
             SCANRS_HIP(hipStreamWaitEvent(ovs, st.ev_in, 0));
-            launch_gather2d_ov(st, ovs, tl.ov, X, ldx, l, ovout, ldc);
+            launch_gather2d_ov(st, ovs, tl.ov, Xov, Xov == X ? ldx : ldxov, l, ovout, ldc);
             SCANRS_HIP(hipEventRecord(st.ev_ov, ovs));
         } else {
-            launch_gather2d_ov(st, st.stream, tl.ov, X, ldx, l, ovout, ldc);
+            launch_gather2d_ov(st, st.stream, tl.ov, Xov, Xov == X ? ldx : ldxov, l, ovout, ldc);
         }
     }
-    TileArgs ta{tl.prow.p, tl.pw.p, tl.n_groups, cp.n_outer, cp.n_inner, sh};
+    TileArgs ta{tl.prow.p, tl.pw.p, tl.unit_mode ? tl.uo.p : nullptr, tl.n_groups, cp.n_outer, cp.n_inner, sh};
     // algorithmic bytes of the nonzeros this kernel works: 8 B each + indptr + the two panels
     const double bytes = (double)(cp.nnz - tl.ov.nnz) * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_inner * l * 8.0 + (double)cp.n_outer * l * 8.0;
     const bool long_outer = cp.n_outer >= cp.n_inner;
     if (st.prof.on)
         st.prof.begin(st.stream, long_outer ? "spmm_tile_kernel/long-outer" : "spmm_tile_kernel/short-outer", bytes,
                       (double)tl.n_groups * sh.nt * sh.S * sh.K * 8.0 * l);
-#define SCANRS_TILE(KK, SS) launch_tile_kernel<KK, SS>(st, ta, X, ldx, l, pbuf, ldc, part_stride, n_items, grid)
+#define SCANRS_TILE(KK, SS, UU) launch_tile_kernel<KK, SS, UU>(st, ta, X, ldx, l, pbuf, ldc, part_stride, n_items, grid)
+    const bool um = tl.unit_mode; // a layout with unit positions under a map that does not separate runs the weighted kernel
     if (sh.K == 2 && sh.S == 32)
-        SCANRS_TILE(2, 32);
+        um ? SCANRS_TILE(2, 32, 1) : SCANRS_TILE(2, 32, 0);
     else if (sh.K == 2 && sh.S == 28)
-        SCANRS_TILE(2, 28);
+        um ? SCANRS_TILE(2, 28, 1) : SCANRS_TILE(2, 28, 0);
     else if (sh.K == 3 && sh.S == 32)
-        SCANRS_TILE(3, 32);
+        SCANRS_TILE(3, 32, 0);
     else if (sh.K == 4 && sh.S == 32)
-        SCANRS_TILE(4, 32);
+        SCANRS_TILE(4, 32, 0);
     else if (sh.K == 4 && sh.S == 28)
-        SCANRS_TILE(4, 28);
+        SCANRS_TILE(4, 28, 0);
     else
         fail(SCANRS_ERR_ARGUMENT, "unsupported tile shape K=%u S=%u", sh.K, sh.S);
 #undef SCANRS_TILE

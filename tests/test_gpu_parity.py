@@ -518,8 +518,9 @@ def test_blocked_kernel_matches_gather_and_oracle(sa, storage):
 
 
 @pytest.mark.parametrize("storage", [so.CSR, so.CSC])
-@pytest.mark.parametrize("tile_k,tile_s,tile_t,tile_b", [(2, 32, 48, 4), (2, 28, 48, 4), (2, 32, 24, 8), (3, 32, 64, 3), (4, 32, 96, 2), (4, 28, 40, 3)])
-def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_s, tile_t, tile_b):
+@pytest.mark.parametrize("tile_k,tile_s,tile_t,tile_b,tile_ku", [(2, 28, 48, 4, 1), (2, 32, 48, 4, 1), (2, 28, 48, 4, 0), (2, 32, 24, 8, 1), (3, 32, 64, 3, 0),
+                                                                 (4, 32, 96, 2, 0), (4, 28, 40, 3, 0)])
+def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_s, tile_t, tile_b, tile_ku):
     """spmm path 3 (tiles.hip: the hybrid product — panel tiles staged through a ring of LDS buffers, K fixed record positions
     per (outer vector, visit) dealt first come first served with materialized weights, and the L2-blocked gather over the
     nonzeros no visit had room for, on two streams) against the plain gather kernel and the oracle: shapes around the slot
@@ -535,6 +536,7 @@ def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_
         g3, _ = pair(sa, dense, storage)
         g1.set_spmm_path(1)
         g3.set_spmm_path(3).set_option("tile_k", tile_k).set_option("tile_s", tile_s).set_option("tile_t", tile_t).set_option("tile_b", tile_b)
+        g3.set_option("tile_ku", tile_ku)
         f = rng.random(cols) + 0.5
         fr = rng.random(rows) + 0.5
         for gm in (g1, g3):
@@ -577,8 +579,26 @@ def test_lds_staged_product_whole_pca_and_remap(sa):
     for g in (ga, gb):
         g.reset_map()
         sa.log_normalize_with_size_factor(g, None, sa.FN_LN_1P)
-    q = np.random.default_rng(3).standard_normal((m.shape[0], 40))
+    rng = np.random.default_rng(3)
+    q = rng.standard_normal((m.shape[0], 40))
     assert_close(ga.dot(q), gb.dot(q), rtol=1e-11, atol=1e-10)
+    # maps whose count-1 weight is NOT (outer factor) x (inner factor) — scales on both sides in front of the logarithm, the
+    # binomial residuals — keep the unit positions of the layout but run the weighted kernel; raw counts (no map) separate
+    fr, fc = rng.random(m.shape[1]) + 0.5, rng.random(m.shape[0]) + 0.5
+    ql = rng.standard_normal((m.shape[1], 24))
+    for g in (ga, gb):
+        g.reset_map()
+        g.compose_scale_axis(0, fr).compose_scale_axis(1, fc).apply(sa.FN_LOG2_1P)
+    assert_close(ga.dot(q), gb.dot(q), rtol=1e-11, atol=1e-10)
+    assert_close(ga.t().dot(ql), gb.t().dot(ql), rtol=1e-11, atol=1e-10)
+    for g in (ga, gb):
+        g.reset_map()
+    assert_close(ga.dot(q), gb.dot(q), rtol=1e-11, atol=1e-10)
+    assert_close(ga.t().dot(ql), gb.t().dot(ql), rtol=1e-11, atol=1e-10)
+    for g in (ga, gb):
+        g.reset_map()
+        sa.normalize(g, sa.Normalization.BinomialDeviance)
+    assert_close(ga.dot(q), gb.dot(q), rtol=1e-10, atol=1e-9)
 
 
 def test_blocked_kernel_many_steps_and_determinism(sa):

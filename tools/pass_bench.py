@@ -28,7 +28,7 @@ for cfg in configs:
     parts = [int(x) for x in cfg.split(":")]
     m = sa.AdaptiveMat.from_device(genes, cells, sa.CSC, ip.data_ptr(), ix.data_ptr(), vv.data_ptr())
     m.set_spmm_path(parts[0])
-    for key, val in zip(("tile_k", "tile_s", "tile_t", "tile_b", "tile_overlap"), parts[1:]):
+    for key, val in zip(("tile_k", "tile_s", "tile_t", "tile_b", "tile_overlap", "tile_ku", "ov_tile_kb"), parts[1:]):
         m.set_option(key, val)
     sa.normalize(m, sa.Normalization.CellRanger)
 

@@ -4,7 +4,7 @@
 #   usage: tools/profile_round.sh TAG      (e.g. r02a)
 # Counters go in their own runs (rocprofv3 --pmc with --kernel-trace only), the program directly after `--`.
 set -u
-TAG=${1:-r02d}
+TAG=${1:-r03a}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -15,6 +15,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- p
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --kernel-trace --output-format csv -d $OUT/tcc -- python3 bench.py $ARGS > $OUT/tcc.json 2> $OUT/tcc.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/sq -- python3 bench.py $ARGS > $OUT/sq.json 2> $OUT/sq.err
 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum --kernel-trace --output-format csv -d $OUT/tcp -- python3 bench.py $ARGS > $OUT/tcp.json 2> $OUT/tcp.err
+rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/lds -- python3 bench.py $ARGS > $OUT/lds.json 2> $OUT/lds.err
 python3 profiles/summarize.py $TAG $OUT > $OUT/summary.log 2>&1
 tail -30 $OUT/summary.log
 ls -la $OUT
