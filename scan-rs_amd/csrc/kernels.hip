@@ -1899,6 +1899,15 @@ void launch_spmm_u32(Storage &st, const SparseCopy &cp, const uint32_t *X, uint3
 
 static uint32_t ensure_bounds(Storage &st, SparseCopy &cp);
 
+// Should the moments pass of normalize() keep the mapped values for the gather products? Not when the b-wide products of this
+// copy will run through the hybrid tile product, which keeps its own weights: 8 B per nonzero and 1.7 ms of stores per
+// normalize saved; a gather product that wants them later (RandSvd's 500-column panels) materializes them itself then.
+static bool moments_keep_values(Storage &st, const SparseCopy &cp, const DevMap &map) {
+    const bool tiles = st.panel_precision == 0 && tile_shape_ok(st.tile_k, st.tile_s, st.tile_t, st.tile_b) &&
+                       (st.spmm_path == 3 || (st.spmm_path == 0 && st.tile_auto && cp.nnz >= std::max<uint64_t>(st.blocked_min_nnz, 1ull << 24)));
+    return !tiles && fvals_wanted(st, cp, map, map.n);
+}
+
 void launch_row_reduce(Storage &st, SparseCopy &cp, const DevMap &map, int mode, uint32_t *out_u32, double *out_sum,
                        double *out_sumsq) {
     if (cp.n_outer == 0) return;
@@ -1909,7 +1918,7 @@ void launch_row_reduce(Storage &st, SparseCopy &cp, const DevMap &map, int mode,
         bool lazy = false;
         if (inner_indexed && st.slice_walk && cp.n_outer < cp.n_inner && slice_walk_chain(map, 0, lazy) && lazy) {
             // the barcode scale staged in LDS slice by slice instead of gathered from L2 (see slice_walk_kernel)
-            double *fout = mode == 2 && fvals_wanted(st, cp, map, map.n) ? fvals_claim(st, cp, map, map.n) : nullptr;
+            double *fout = mode == 2 && moments_keep_values(st, cp, map) ? fvals_claim(st, cp, map, map.n) : nullptr;
             launch_slice_walk<1>(st, cp, map, nullptr, 0, true, nullptr, 0, out_sum, 1, mode == 2 ? out_sumsq : nullptr, fout, nullptr, 0,
                                  nullptr, 0, mode == 1 ? "slice_walk_sum" : "slice_walk_moments",
                                  (double)cp.nnz * (fout ? 16.0 : 8.0) + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_outer * 16.0);
@@ -1922,7 +1931,7 @@ void launch_row_reduce(Storage &st, SparseCopy &cp, const DevMap &map, int mode,
             const dim3 grid((unsigned)((cp.n_outer + 3) / 4)), block(256);
             // the moments walk evaluates exactly the chain the later products start with (normalize: scale, log — then
             // the 1/sigma link is appended): keep the values, the products then skip the per-nonzero scale gather
-            double *fout = mode == 2 && fvals_wanted(st, cp, map, map.n) ? fvals_claim(st, cp, map, map.n) : nullptr;
+            double *fout = mode == 2 && moments_keep_values(st, cp, map) ? fvals_claim(st, cp, map, map.n) : nullptr;
             const double bytes = ((double)cp.nnz * (fout ? 16.0 : 8.0) + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_outer * (mode == 1 ? 8.0 : 16.0)) / steps;
             for (uint32_t sidx = 0; sidx < steps; sidx++) {
                 const uint32_t b0 = sidx * m, b1 = std::min(nb, b0 + m);

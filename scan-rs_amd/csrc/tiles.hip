@@ -20,7 +20,7 @@
 //
 // Tile kernel: a wave owns S outer vectors ("slots") of one group for a whole item (a range of tiles): 2 f64 accumulators
 // per lane per slot (lane = column pair), every FMA destination a compile-time register because the code is unrolled over
-// the positions; the 64 lanes of a record set hold the set's positions (slot q, position j -> lane q K + j), so the serial
+// the positions; the 64 lanes of a record set hold the set's positions (slot q, position j -> lane j SPS + q), so the serial
 // part reads them with v_readlane at immediate lanes (the four row bytes of a lane quad with ONE v_readlane, taken apart by
 // scalar instructions: v_readlane is the slowest instruction of the loop, profiles/microbench/issue_bench.hip); tiles are
 // staged by LDS-DMA (global_load_lds, one barrier per visit), a few chunks at a time between the positions. The positions
@@ -51,7 +51,9 @@ struct TileShape {
 // ---- builder -------------------------------------------------------------------------------------------------------
 // One thread per (outer vector, part): walks the part's nonzeros in order and deals them to visits first come first served.
 // FILL = false: counts the nonzeros left over (ovc[outer * n_parts + part]); FILL = true: writes records and overflow.
-// Record index of (group g, visit v, set b, lane): ((g nt + v) nset + b) 64 + lane, lane = q K + j for slot b sps + q.
+// Record index of (group g, visit v, set b, lane): ((g nt + v) nset + b) 64 + lane, lane = j sps + q for position j of slot
+// b sps + q (position-major: the weights of the general positions of a set are contiguous, so the weight refresh writes
+// whole cache lines).
 // The layout is STRUCTURE (this kernel: which nonzero sits where; row bytes and raw counts) and WEIGHTS (tile_weights_kernel:
 // the map chain evaluated per position) — a re-normalized handle keeps the structure and refreshes the weights in one
 // streaming pass.
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void tile_assign_kernel(const uint64_t *__rest
             cg = bg - 1u;
         }
         if (FILL) {
-            const uint64_t rec = ((g * sh.nt + v) * sh.nset + b) * 64u + (uint64_t)q * sh.K + j;
+            const uint64_t rec = ((g * sh.nt + v) * sh.nset + b) * 64u + (uint64_t)j * sh.sps + q;
             prow[rec] = (uint8_t)((tau % sh.B) * sh.T + (idx - tau * sh.T));
             pcnt[rec] = (uint8_t)cnt;
         }
@@ -154,12 +156,12 @@ __global__ void tile_init_rows_kernel(uint8_t *__restrict__ prow, uint64_t n_rec
     uint32_t word = 0;
     for (uint32_t i = 0; i < 4u; i++) {
         const uint32_t lane = (uint32_t)((e * 4u + i) & 63u);
-        word |= ((lane % sh.K) < sh.KU ? zero : own) << (8u * i);
+        word |= ((lane / sh.sps) < sh.KU ? zero : own) << (8u * i);
     }
     reinterpret_cast<uint32_t *>(prow)[e] = word;
 }
 
-// pw[rec] = the map chain at the record's (count, outer, inner); unused positions (count 0) get weight 0.
+// pw[rec] = the map chain at the record's (count, outer, inner); unused positions (count 0) keep the weight 0 of the build.
 // One thread per record; nset * 64 is a power of two and (group, visit) pairs fit 32 bits (checked by the builder).
 // Unit mode (uo / vi given): the stored weight is w / (uo[outer] * vi[inner]) — the kernel works on panel rows scaled by
 // vi and scales a vector's sum by uo at the end; the unit positions (count 1: quotient 1) are not read at all.
@@ -169,14 +171,16 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint8_t *__rest
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_rec) return;
     const uint32_t cnt = pcnt[e];
+    if (cnt == 0) return; // an unused position keeps the weight 0 it was built with
     double w = 0.0;
-    if (cnt) {
+    if (uo && ((uint32_t)(e & 63u) / sh.sps) < sh.KU) return; // unit mode: the unit positions carry no weight (never read)
+    {
         const uint32_t lane = (uint32_t)(e & 63u);
         const uint32_t sv = (uint32_t)(e >> 6);
         const uint32_t b = sh.nset == 1 ? 0u : (sv & (sh.nset - 1u));
         const uint32_t gv = sh.nset == 1 ? sv : sv / sh.nset;
         const uint32_t g = gv / sh.nt, v = gv - g * sh.nt;
-        const uint64_t o = (uint64_t)g * sh.S + b * sh.sps + lane / sh.K;
+        const uint64_t o = (uint64_t)g * sh.S + b * sh.sps + lane % sh.sps;
         const uint32_t code = prow[e];
         const uint32_t bufi = code / sh.T, r = code - bufi * sh.T;
         const uint32_t d = (v % sh.B + sh.B - bufi) % sh.B; // visits the nonzero waited
@@ -337,6 +341,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
     lap("hipMalloc of records");
     hipLaunchKernelGGL(tile_init_rows_kernel, dim3((unsigned)((n_rec / 4 + 255) / 256)), dim3(256), 0, s, tl->prow.p, n_rec, sh);
     SCANRS_HIP(hipMemsetAsync(tl->pcnt.p, 0, n_rec, s));
+    SCANRS_HIP(hipMemsetAsync(tl->pw.p, 0, n_rec * 8, s)); // unused positions: weight 0 for good
     lap("init rows + counts");
     SparseCopy &ov = tl->ov;
     ov.n_outer = cp.n_outer;
@@ -550,10 +555,16 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
             d2 x[TL_W];
 #pragma unroll
             for (int i = 0; i < NPT + TL_W + 2; i++) {
+                // position k of the visit -> set, position j of slot q (j-major inside a set; a last, partial set has fewer slots)
+                auto set_of = [](int k) constexpr { return k / PPS; };
+                auto ns_of = [](int k) constexpr { return S - SPS * (k / PPS) < SPS ? S - SPS * (k / PPS) : SPS; };
+                auto lane_of = [&](int k) constexpr { return ((k % PPS) / ns_of(k)) * SPS + (k % PPS) % ns_of(k); };
+                auto slot_of = [&](int k) constexpr { return set_of(k) * SPS + (k % PPS) % ns_of(k); };
+                auto unit_of = [&](int k) constexpr { return (k % PPS) / ns_of(k) < KU; };
                 if (i >= 2 + TL_W) { // F(i - 2 - W)
                     const int g = i - 2 - TL_W;
-                    const int sl = (g / PPS) * SPS + (g % PPS) / K;
-                    if ((g % PPS) % K < KU) { // unit position: the row as it is
+                    const int sl = slot_of(g);
+                    if (unit_of(g)) { // unit position: the row as it is
                         acc[sl].x += x[g % TL_W].x;
                         acc[sl].y += x[g % TL_W].y;
                     } else {
@@ -573,13 +584,13 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
                     asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr[g % 2]) : "s"(offs[g % 2]), "v"(rowbytes_v), "v"(ring));
                 }
                 if (i < NPT) { // R(i)
-                    const int b = i / PPS, p = i % PPS;
-                    if (p % 4 == 0) {
+                    const int b = set_of(i), p = lane_of(i);
+                    if (p % 4 == 0 || (i % PPS) % ns_of(i) == 0) {
                         asm volatile("" : "+v"(crow[b])); // read the quad's row bytes here, not 64 steps early (they would fill the SGPR file)
-                        rows4 = rdlane(crow[b], p);
+                        rows4 = rdlane(crow[b], p & ~3);
                     }
                     offs[i % 2] = (rows4 >> (8 * (p % 4))) & 255u;
-                    if (p % K >= KU) wq[i % WR] = __hiloint2double((int)rdlane(whi[b], p), (int)rdlane(wlo[b], p));
+                    if (!unit_of(i)) wq[i % WR] = __hiloint2double((int)rdlane(whi[b], p), (int)rdlane(wlo[b], p));
                 }
                 if (i % DM == (TL_DMA_EARLY ? 0 : DM / 2) && i / DM < CH) stage_chunk(t + 1, bufn, i / DM);
                 asm volatile("" ::: "memory");

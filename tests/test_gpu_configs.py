@@ -157,3 +157,35 @@ def test_config5_one_gpu_shard_of_30M(sa):
     assert np.array_equal(s, s2)
     v_dev = torch.as_tensor(sa.DevArray(res.d_v, n_cells * res.ld_v), device=dev).view(n_cells, res.ld_v)[:, :k]
     assert bool(torch.equal(v_dev.cpu(), torch.from_numpy(v)))
+
+
+def test_config3_1M_matches_the_committed_oracle_result(sa):
+    """configs[2] — the headline shape, 1 M cells x 33 k genes @ 3 % — against the CPU oracle's result on the SAME input
+    (tests/golden/config3_1M.npz, made by `make_config_fixtures.py config3`: one hour of one host core in the build
+    container; the matrix comes from `synth_counts_par`, one numpy generator per chunk of 8192 cells, regenerated here by a
+    process pool). sigma at 1e-8 relative, loadings on the fixed subsample at 1e-6, every row through the column sums.
+    Round 2's verdict: the full-size configuration had only ever been compared with itself."""
+    import torch
+
+    from scanrs_amd.synth import synth_counts_par
+
+    path = os.path.join(ROOT, "tests", "golden", "config3_1M.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/config3_1M.npz has not been generated")
+    fx = np.load(path)
+    cells, genes, k = int(fx["cells"]), int(fx["genes"]), int(fx["k"])
+    ip, ix, vv = synth_counts_par(cells, genes, float(fx["density"]), int(fx["seed"]))
+    assert int(ip[-1]) == int(fx["nnz"])
+    assert int(ix.astype(np.int64).sum()) == int(fx["sum_indices"]) and int(vv.astype(np.int64).sum()) == int(fx["sum_values"])
+    assert np.array_equal(ip[:: cells // 100].astype(np.int64), fx["indptr_probe"])
+    g = sa.AdaptiveMat.from_csmat(genes, cells, sa.CSC, ip, ix, vv)
+    del ix, vv
+    sa.normalize(g, sa.Normalization.CellRanger)
+    omega = sa.omega_fill(0, 2 * k * genes).reshape(2 * k, genes)
+    u, s, v = sa.BkSvd().run_pca(g, k, omega=omega)
+    _check_against_fixture(fx, u, s, v, k)
+    # the gather-only path on the same handle: same answer (the hybrid product is the default at this size)
+    g.set_option("tile_auto", 0)
+    u2, s2, v2 = sa.BkSvd().run_pca(g, k, omega=omega)
+    assert np.max(np.abs(s2 - s) / s) < 1e-10
+    torch.cuda.empty_cache()
