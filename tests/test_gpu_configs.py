@@ -184,8 +184,10 @@ def test_config3_1M_matches_the_committed_oracle_result(sa):
     omega = sa.omega_fill(0, 2 * k * genes).reshape(2 * k, genes)
     u, s, v = sa.BkSvd().run_pca(g, k, omega=omega)
     _check_against_fixture(fx, u, s, v, k)
-    # the gather-only path on the same handle: same answer (the hybrid product is the default at this size)
+    # the gather-only path on the same handle: same answer (the hybrid product is the default at this size; the trailing
+    # singular values of this matrix lie 2e-4 apart, so two correct runs differ by ~1e-10 there)
     g.set_option("tile_auto", 0)
     u2, s2, v2 = sa.BkSvd().run_pca(g, k, omega=omega)
-    assert np.max(np.abs(s2 - s) / s) < 1e-10
+    assert np.max(np.abs(s2 - s) / s) < 1e-8
+    _check_against_fixture(fx, u2, s2, v2, k)
     torch.cuda.empty_cache()
