@@ -1794,11 +1794,24 @@ void launch_scale_rows(Storage &st, const double *X, uint32_t ldx, uint64_t rows
 
 void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l,
                      double *out, uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw) {
-    if (spmm_tiles_ok(st, cp, ldx, l) && tile_shape_ok(st.tile_k, st.tile_s, st.tile_t, st.tile_b) &&
-        (st.spmm_path == 3 || (st.spmm_path == 0 && st.panel_precision == 0 && spmm_tiles_auto(st, cp, map)))) {
-        // hybrid: LDS-staged tiles + gather of the overflow part (tiles.hip)
-        launch_spmm_tiles(st, cp, map, X, ldx, l, out, ldo, off_a, rank, off_w, ldw);
-        return;
+    // hybrid: LDS-staged tiles + gather of the overflow part (tiles.hip). Panels wider than the 104 columns a ring row holds go
+    // through it in column chunks of equal width (200 -> 2 x 100, 500 -> 5 x 100): a chunk pass costs what a 100-column pass
+    // costs, against two gather instructions per nonzero for every 128 columns of the blocked gather.
+    {
+        const uint32_t n_chunks = (l + 103u) / 104u;
+        const uint32_t lc = n_chunks ? even_up((l + n_chunks - 1u) / n_chunks) : 0u;
+        if (l >= 16 && lc >= 16 && spmm_tiles_ok(st, cp, ldx, std::min(lc, l)) && tile_shape_ok(st.tile_k, st.tile_s, st.tile_t, st.tile_b) &&
+            (st.spmm_path == 3 || (st.spmm_path == 0 && st.panel_precision == 0 && spmm_tiles_auto(st, cp, map)))) {
+            for (uint32_t c0 = 0; c0 < l; c0 += lc) {
+                const uint32_t lw = std::min(lc, l - c0);
+                if (lw < 16u) { // a last sliver narrower than the tile kernel takes: the plain gather serves it
+                    launch_spmm_t<double>(st, cp, map, X + c0, ldx, lw, out + c0, ldo, off_a, rank, off_w ? off_w + c0 : nullptr, ldw);
+                    continue;
+                }
+                launch_spmm_tiles(st, cp, map, X + c0, ldx, lw, out + c0, ldo, off_a, rank, off_w ? off_w + c0 : nullptr, ldw);
+            }
+            return;
+        }
     }
     const bool want_2d = st.spmm_path == 2 || st.spmm_path == 3 || (st.spmm_path == 0 && cp.nnz >= st.blocked_min_nnz && l >= 16);
     if (want_2d && l > 0 && cp.n_outer > 0 && cp.n_inner > 0) {

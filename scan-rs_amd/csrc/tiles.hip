@@ -168,13 +168,11 @@ __global__ void tile_init_rows_kernel(uint8_t *__restrict__ prow, uint64_t n_rec
 __global__ __launch_bounds__(256) void tile_weights_kernel(const uint8_t *__restrict__ prow, const uint8_t *__restrict__ pcnt,
                                                            double *__restrict__ pw, uint64_t n_rec, uint64_t n_outer, TileShape sh, DevMap map,
                                                            const double *__restrict__ uo, const double *__restrict__ vi) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_rec) return;
-    const uint32_t cnt = pcnt[e];
-    if (cnt == 0) return; // an unused position keeps the weight 0 it was built with
-    double w = 0.0;
-    if (uo && ((uint32_t)(e & 63u) / sh.sps) < sh.KU) return; // unit mode: the unit positions carry no weight (never read)
-    {
+    // grid-stride: a launch holds fewer than 2^32 work-items (the dispatch packet's grid size is 32 bits), a layout more records
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_rec; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t cnt = pcnt[e];
+        if (cnt == 0) continue; // an unused position keeps the weight 0 it was built with
+        if (uo && ((uint32_t)(e & 63u) / sh.sps) < sh.KU) continue; // unit mode: the unit positions carry no weight (never read)
         const uint32_t lane = (uint32_t)(e & 63u);
         const uint32_t sv = (uint32_t)(e >> 6);
         const uint32_t b = sh.nset == 1 ? 0u : (sv & (sh.nset - 1u));
@@ -185,13 +183,13 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint8_t *__rest
         const uint32_t bufi = code / sh.T, r = code - bufi * sh.T;
         const uint32_t d = (v % sh.B + sh.B - bufi) % sh.B; // visits the nonzero waited
         const uint32_t inner = (v - d) * sh.T + r;
-        w = eval_map(map, cnt, (uint32_t)o, inner);
+        double w = eval_map(map, cnt, (uint32_t)o, inner);
         if (uo) {
             const double d2 = uo[o] * vi[inner];
             w = (d2 != 0.0 && isfinite(d2)) ? w / d2 : 0.0; // a zero unit weight means a zero weight for every count (log1p, square, scale)
         }
+        pw[e] = w;
     }
-    pw[e] = w;
 }
 
 // The factor of the weight of a count-1 nonzero that depends on one side only (outer or inner position): the chain run on
@@ -395,7 +393,7 @@ static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &c
         hipLaunchKernelGGL(tile_unit_factor_kernel, dim3((unsigned)((cp.n_inner + 255) / 256)), dim3(256), 0, st.stream, map, 0, nl_outer, cp.n_inner, tl.vi.p);
     }
     if (n_rec)
-        hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, st.stream, tl.prow.p, tl.pcnt.p, tl.pw.p, n_rec,
+        hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)std::min<uint64_t>((n_rec + 255) / 256, 1u << 23)), dim3(256), 0, st.stream, tl.prow.p, tl.pcnt.p, tl.pw.p, n_rec,
                            cp.n_outer, tl.sh, map, tl.unit_mode ? tl.uo.p : (const double *)nullptr, tl.unit_mode ? tl.vi.p : (const double *)nullptr);
     if (tl.ov.nnz) materialize_map_values(st, tl.ov, map, tl.ov.fvals.p);
     SCANRS_HIP(hipGetLastError());
