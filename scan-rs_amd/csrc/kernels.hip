@@ -1330,7 +1330,13 @@ __global__ void validate_kernel(const uint64_t *__restrict__ indptr, uint64_t n_
 
 // =============================================================================================
 // launchers
-static inline dim3 grid1(uint64_t n, uint32_t block) { return dim3((unsigned)((n + block - 1) / block)); }
+// One thread per element. The dispatch packet's grid size is 32 bits of WORK-ITEMS (not blocks), and a launch past it silently runs
+// the low 32 bits' worth — refuse instead.
+static inline dim3 grid1(uint64_t n, uint32_t block) {
+    const uint64_t blocks = (n + block - 1) / block;
+    if (blocks * block >= (1ull << 32)) fail(SCANRS_ERR_DEVICE, "a per-element launch over %llu elements exceeds the 2^32 work-items of one dispatch", (unsigned long long)n);
+    return dim3((unsigned)blocks);
+}
 
 struct ProfScope {
     Storage &st;
@@ -1617,8 +1623,9 @@ static void launch_spmm_2d(Storage &st, SparseCopy &cp, const DevMap &map, const
 // load, their nonzeros (usually fewer than 64 together) in one load of indices and one of weights, the row gathers of all of
 // them back to back; the accumulators of the NV vectors are compile-time registers (the gather loop is unrolled over the
 // vectors, its bounds are scalars). Weights are materialized (fvals), no map, no offset; sums carried through `out`.
+// <= 72 VGPRs: two of these waves fit the registers the two persistent tile waves of a SIMD leave (512 - 2 x 184 = 144).
 template <int NV>
-__global__ __launch_bounds__(256) void spmm_gather_ov_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void spmm_gather_ov_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
                                                              const double *__restrict__ fvals, const uint32_t *__restrict__ bounds, uint32_t nb,
                                                              uint32_t b0, uint32_t b1, int first, uint64_t n_outer, const double *__restrict__ X,
                                                              uint32_t ldx, uint32_t l, double *out, uint32_t ldo) {

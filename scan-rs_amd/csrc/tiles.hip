@@ -61,7 +61,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void tile_assign_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
                                                           const uint32_t *__restrict__ values, uint64_t n_outer, TileShape sh,
                                                           unsigned long long *__restrict__ ovc, const unsigned long long *__restrict__ ov_off,
-                                                          uint8_t *__restrict__ prow, uint8_t *__restrict__ pcnt,
+                                                          uint16_t *__restrict__ prow, uint8_t *__restrict__ pcnt,
                                                           uint32_t *__restrict__ ov_indices, uint32_t *__restrict__ ov_values) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_outer * sh.n_parts) return;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void tile_assign_kernel(const uint64_t *__rest
         }
         if (FILL) {
             const uint64_t rec = ((g * sh.nt + v) * sh.nset + b) * 64u + (uint64_t)j * sh.sps + q;
-            prow[rec] = (uint8_t)((tau % sh.B) * sh.T + (idx - tau * sh.T));
+            prow[rec] = (uint16_t)((tau % sh.B) * sh.T + (idx - tau * sh.T));
             pcnt[rec] = (uint8_t)cnt;
         }
     }
@@ -148,24 +148,25 @@ __global__ __launch_bounds__(256) void tile_assign_kernel(const uint64_t *__rest
 
 // An unused general position reads a row that is certainly in the ring at its visit — row 0 of the visit's own tile — with
 // weight 0; an unused unit position (no weight) reads the row of zeros that the kernel keeps behind the ring (row B T).
-__global__ void tile_init_rows_kernel(uint8_t *__restrict__ prow, uint64_t n_rec, TileShape sh) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // one thread per 4 records
-    if (e * 4u >= n_rec) return;
-    const uint32_t v = (uint32_t)((e * 4u / (sh.nset * 64u)) % sh.nt);
-    const uint32_t own = (v % sh.B) * sh.T, zero = sh.B * sh.T;
-    uint32_t word = 0;
-    for (uint32_t i = 0; i < 4u; i++) {
-        const uint32_t lane = (uint32_t)((e * 4u + i) & 63u);
-        word |= ((lane / sh.sps) < sh.KU ? zero : own) << (8u * i);
+__global__ void tile_init_rows_kernel(uint16_t *__restrict__ prow, uint64_t n_rec, TileShape sh) {
+    // 4 records per step, grid-stride (a dispatch holds fewer than 2^32 work-items)
+    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e * 4u < n_rec; e += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = (uint32_t)((e * 4u / (sh.nset * 64u)) % sh.nt);
+        const uint32_t own = (v % sh.B) * sh.T, zero = sh.B * sh.T;
+        uint32_t word[2] = {0u, 0u};
+        for (uint32_t i = 0; i < 4u; i++) {
+            const uint32_t lane = (uint32_t)((e * 4u + i) & 63u);
+            word[i >> 1] |= ((lane / sh.sps) < sh.KU ? zero : own) << (16u * (i & 1u));
+        }
+        reinterpret_cast<uint2 *>(prow)[e] = make_uint2(word[0], word[1]);
     }
-    reinterpret_cast<uint32_t *>(prow)[e] = word;
 }
 
 // pw[rec] = the map chain at the record's (count, outer, inner); unused positions (count 0) keep the weight 0 of the build.
 // One thread per record; nset * 64 is a power of two and (group, visit) pairs fit 32 bits (checked by the builder).
 // Unit mode (uo / vi given): the stored weight is w / (uo[outer] * vi[inner]) — the kernel works on panel rows scaled by
 // vi and scales a vector's sum by uo at the end; the unit positions (count 1: quotient 1) are not read at all.
-__global__ __launch_bounds__(256) void tile_weights_kernel(const uint8_t *__restrict__ prow, const uint8_t *__restrict__ pcnt,
+__global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t *__restrict__ prow, const uint8_t *__restrict__ pcnt,
                                                            double *__restrict__ pw, uint64_t n_rec, uint64_t n_outer, TileShape sh, DevMap map,
                                                            const double *__restrict__ uo, const double *__restrict__ vi) {
     // grid-stride: a launch holds fewer than 2^32 work-items (the dispatch packet's grid size is 32 bits), a layout more records
@@ -247,7 +248,8 @@ __global__ void tile_ovptr_kernel(const unsigned long long *__restrict__ ov_off,
 struct TileLayout {
     TileShape sh{};
     uint64_t n_groups = 0;
-    DevBuf<uint8_t> prow;  // [group][visit][set][64]: ring row of the position
+    DevBuf<uint16_t> prow; // [group][visit][set][64]: ring row of the position (16 bits: the kernel multiplies a half of a
+                           // scalar register by the row pitch in one v_mad_u32_u16 — a byte would cost a scalar extract per position)
     DevBuf<uint8_t> pcnt;  // same index: the raw count (0 = unused position; counts above 255 live in the overflow part)
     DevBuf<double> pw;     // same index: the weight under the map `sig_*`
     SparseCopy ov;         // the overflow part: indptr / indices / values (counts) / fvals (weights)
@@ -258,7 +260,7 @@ struct TileLayout {
     int sig_n = -1;
     uint32_t sig_id[MAX_OPS] = {};
     int sig_outer[MAX_OPS] = {};
-    double bytes() const { return (double)prow.n + (double)pcnt.n + (double)pw.n * 8.0 + (double)ov.nnz * 16.0; }
+    double bytes() const { return (double)prow.n * 2.0 + (double)pcnt.n + (double)pw.n * 8.0 + (double)ov.nnz * 16.0; }
     bool structure_matches(const Storage &st) const {
         return sh.K == st.tile_k && sh.S == st.tile_s && sh.T == st.tile_t && sh.B == st.tile_b && sh.KU == (st.tile_k == 2u && st.tile_ku ? 1u : 0u);
     }
@@ -324,7 +326,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
     SCANRS_HIP(hipMemsetAsync(ovc.p + n_seg, 0, 8, s));
     const dim3 grid((unsigned)((n_seg + 255) / 256));
     hipLaunchKernelGGL((tile_assign_kernel<false>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, cp.n_outer, sh, ovc.p,
-                       (const unsigned long long *)nullptr, (uint8_t *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+                       (const unsigned long long *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     size_t tmp_bytes = 0;
     SCANRS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, ovc.p, ovo.p, 0ull, (size_t)n_seg + 1, rocprim::plus<unsigned long long>(), s));
     DevBuf<char> tmp(std::max<size_t>(tmp_bytes, 16));
@@ -337,7 +339,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
     tl->pcnt.alloc(n_rec);
     tl->pw.alloc(n_rec);
     lap("hipMalloc of records");
-    hipLaunchKernelGGL(tile_init_rows_kernel, dim3((unsigned)((n_rec / 4 + 255) / 256)), dim3(256), 0, s, tl->prow.p, n_rec, sh);
+    hipLaunchKernelGGL(tile_init_rows_kernel, dim3((unsigned)std::min<uint64_t>((n_rec / 4 + 255) / 256, 1u << 23)), dim3(256), 0, s, tl->prow.p, n_rec, sh);
     SCANRS_HIP(hipMemsetAsync(tl->pcnt.p, 0, n_rec, s));
     SCANRS_HIP(hipMemsetAsync(tl->pw.p, 0, n_rec * 8, s)); // unused positions: weight 0 for good
     lap("init rows + counts");
@@ -409,7 +411,7 @@ static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &c
 namespace {
 
 struct TileArgs {
-    const uint8_t *prow;
+    const uint16_t *prow;
     const double *pw;
     const double *uo; // unit mode: factor applied to a vector's sum at the end
     uint64_t n_groups, n_outer, n_inner;
@@ -479,8 +481,8 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
     const uint32_t lcol16 = src_lane * 16u;
     const lds_cptr_t ring = (lds_cptr_t)(lds + lcol16);
     uint32_t rowbytes_v = rowbytes;
-    asm volatile("" : "+v"(rowbytes_v)); // a vector register: v_mad_u32_u24 takes one scalar operand
-    // record rows are bytes; a lane loads the aligned dword that holds the four row bytes of its quad
+    asm volatile("" : "+v"(rowbytes_v)); // a vector register: v_mad_u32_u16 takes one scalar operand
+    // record rows are 16 bits; a lane loads the aligned dword that holds the two rows of its pair
     const uint32_t *prow32 = reinterpret_cast<const uint32_t *>(ta.prow);
 
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -507,7 +509,7 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
         double cw[NSET], nw[NSET];
 #pragma unroll
         for (int b = 0; b < NSET; b++) {
-            crow[b] = prow32[((vbase + t0) * NSET + b) * 16u + (lane >> 2)];
+            crow[b] = prow32[((vbase + t0) * NSET + b) * 32u + (lane >> 1)];
             cw[b] = ta.pw[((vbase + t0) * NSET + b) * 64u + lane];
         }
 
@@ -519,7 +521,7 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
             // the next visit's records: nothing in this visit waits for them
 #pragma unroll
             for (int b = 0; b < NSET; b++) {
-                nrow[b] = prow32[((vbase + tr) * NSET + b) * 16u + (lane >> 2)];
+                nrow[b] = prow32[((vbase + tr) * NSET + b) * 32u + (lane >> 1)];
                 nw[b] = ta.pw[((vbase + tr) * NSET + b) * 64u + lane];
             }
             // The visit's S K positions as one software pipeline over position g (set g / (SPS K), lane g % (SPS K)): per step
@@ -578,16 +580,20 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
                 }
                 if (i >= 1 && i - 1 < NPT) { // A(i - 1)
                     const int g = i - 1;
-                    // ring + row byte * rowbytes in one vector instruction (the address now, not in front of the read)
-                    asm volatile("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr[g % 2]) : "s"(offs[g % 2]), "v"(rowbytes_v), "v"(ring));
+                    // ring + row * rowbytes in one vector instruction (the address now, not in front of the read); the row is the low
+                    // or the high half of the pair's scalar register, picked by op_sel: no scalar extract
+                    if (lane_of(g) % 2 == 0)
+                        asm volatile("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(addr[g % 2]) : "s"(offs[g % 2]), "v"(rowbytes_v), "v"(ring));
+                    else
+                        asm volatile("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(addr[g % 2]) : "s"(offs[g % 2]), "v"(rowbytes_v), "v"(ring));
                 }
                 if (i < NPT) { // R(i)
                     const int b = set_of(i), p = lane_of(i);
-                    if (p % 4 == 0 || (i % PPS) % ns_of(i) == 0) {
-                        asm volatile("" : "+v"(crow[b])); // read the quad's row bytes here, not 64 steps early (they would fill the SGPR file)
-                        rows4 = rdlane(crow[b], p & ~3);
+                    if (p % 2 == 0 || (i % PPS) % ns_of(i) == 0) {
+                        asm volatile("" : "+v"(crow[b])); // read the pair's rows here, not 64 steps early (they would fill the SGPR file)
+                        rows4 = rdlane(crow[b], p & ~1);
                     }
-                    offs[i % 2] = (rows4 >> (8 * (p % 4))) & 255u;
+                    offs[i % 2] = rows4;
                     if (!unit_of(i)) wq[i % WR] = __hiloint2double((int)rdlane(whi[b], p), (int)rdlane(wlo[b], p));
                 }
                 if (i % DM == (TL_DMA_EARLY ? 0 : DM / 2) && i / DM < CH) stage_chunk(t + 1, bufn, i / DM);
@@ -699,9 +705,9 @@ bool spmm_tiles_auto(Storage &st, SparseCopy &cp, const DevMap &map) {
         cp.tsig_outer[i] = map.ops[i].a_outer;
     }
     if (!seen && st.tile_hint <= 0) return false;
-    // room: records (9 B per position) + overflow + the build's temporaries + the partial-sum buffers, and 8 GB for the solver
+    // room: records (11 B per position: row 2, count 1, weight 8) + overflow + the build's temporaries + the partial-sum buffers, and 8 GB for the solver
     const double nt = (double)((cp.n_inner + st.tile_t - 1) / st.tile_t);
-    const double need = 10.0 * 64.0 * (double)((cp.n_outer + st.tile_s - 1) / st.tile_s) * nt * ((st.tile_s + 64 / st.tile_k - 1) / (64 / st.tile_k)) +
+    const double need = 11.0 * 64.0 * (double)((cp.n_outer + st.tile_s - 1) / st.tile_s) * nt * ((st.tile_s + 64 / st.tile_k - 1) / (64 / st.tile_k)) +
                         0.2 * 12.0 * (double)cp.nnz + 32.0 * (double)cp.n_outer * 64.0 + 2.0 * (double)cp.n_outer * 104.0 * 8.0 * 2.0;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
