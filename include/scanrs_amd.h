@@ -333,11 +333,17 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *   "slice_walk" (1)    Ix1 products / moments on the copy with few, long vectors stage the inner-indexed arrays in LDS slices
  *   "spmv_lds" (1)      Ix1 products on the copy with many short vectors stage the vector in LDS parts
  *   "overlap" (1)       small dense work of the solvers runs on a second stream beside the sparse passes
+ *   "device_factor" (1) svd_bk: the b x b Cholesky factors of CholeskyQR and the coefficient bookkeeping of qr(K) stay on the
+ *                       device (no host round trip per orthonormalisation; falls back to the host path by itself when a
+ *                       factorization does not converge within the queued passes); 0: host factorizations
  *   "d2h_threads" (4)   host threads that empty the pinned ring of a large result download
  *   "reuse_cmax" (1e5)  svd_bk: coefficient bound above which a projection column is recomputed directly
  * Unknown keys return SCANRS_ERR_ARGUMENT. The only environment variables the library reads are the diagnostics
  * SCANRS_TRACE and SCANRS_TRACE_EIG (phase timings on stderr). */
 int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value);
+/* Event counters of the handle (diagnostics): "bk_host_retries" = svd_bk calls whose device-side factorizations did not
+ * converge within the queued passes and that were run again with host factorizations. */
+int scanrs_mat_get_counter(scanrs_mat *m, const char *key, uint64_t *value);
 /* Process-wide options of the entry points that take no handle:
  *   "h5_threads" (8)               threads that inflate the chunks of a large filtered HDF5 read
  *   "eig_threads" (4)              host team of the Rayleigh-Ritz eigensolver for matrices of 768+ rows (1, 2 or 4)
@@ -350,6 +356,14 @@ int scanrs_set_global_option(const char *key, double value);
 int scanrs_mat_set_panel_precision(scanrs_mat *m, int precision);
 /* Block until all work queued on the handle's stream is done. */
 int scanrs_mat_sync(scanrs_mat *m);
+
+/* One pass of the factor step of the device-side CholeskyQR (`.qr()` of a b-wide panel, bk_svd.rs:94,98,123,127): g is the
+ * n x n Gram matrix of the panel (row-major, n <= 128), `rows` the panel's row count (shift rule), `pass` the pass number
+ * (from pass 1 on the step first tests max |g - I| < 5e-14 sqrt(n) and answers "converged"). rinv receives R^-1 with
+ * g (+ shift I) = R^T R — or the identity when the step has nothing to apply. done: 1 converged or failed; status: 0 ok,
+ * 1 Cholesky failed after 12 shifts, 2 non-finite input; err = max |g - I|; shift = diagonal shift used. For tests. */
+int scanrs_mat_chol_rinv(scanrs_mat *m, const double *g, uint32_t n, uint64_t rows, int pass, double *rinv, int *done, int *status,
+                         double *err, double *shift);
 
 /* ---- host-side dense helpers (no device needed; used by the solvers where the reference calls
  * LAPACK on k x k matrices, exposed so the CPU test-suite can check them) ------------------------- */

@@ -506,6 +506,22 @@ class AdaptiveMat:
         _check(_lib.scanrs_mat_set_option(self._h, key.encode(), ctypes.c_double(value)))
         return self
 
+    def counter(self, key: str) -> int:
+        v = ctypes.c_uint64()
+        _check(_lib.scanrs_mat_get_counter(self._h, key.encode(), ctypes.byref(v)))
+        return int(v.value)
+
+    def chol_rinv(self, g, rows: int, pass_no: int = 0):
+        """One factor step of the device-side CholeskyQR (scanrs_mat_chol_rinv): (rinv, done, status, err, shift)."""
+        g = _f64(g)
+        n = g.shape[0]
+        rinv = np.zeros((n, n))
+        done, status = ctypes.c_int(), ctypes.c_int()
+        err, shift = ctypes.c_double(), ctypes.c_double()
+        _check(_lib.scanrs_mat_chol_rinv(self._h, _p(g), ctypes.c_uint32(n), ctypes.c_uint64(rows), ctypes.c_int(pass_no), _p(rinv),
+                                         ctypes.byref(done), ctypes.byref(status), ctypes.byref(err), ctypes.byref(shift)))
+        return rinv, int(done.value), int(status.value), float(err.value), float(shift.value)
+
     def target_umi(self) -> float:
         t = ctypes.c_double()
         _check(_lib.scanrs_mat_target_umi(self._h, ctypes.byref(t)))
@@ -830,7 +846,7 @@ EXPORTED_SYMBOLS = [
     "scanrs_pca_bk", "scanrs_pca_rand", "scanrs_pca_irlba", "scanrs_pca_result_device", "scanrs_knn_device", "scanrs_omega_fill", "scanrs_mat_set_shard", "scanrs_mat_set_shard_comm", "scanrs_comm_get_unique_id", "scanrs_comm_create", "scanrs_comm_free",
     "scanrs_multi_create", "scanrs_multi_free", "scanrs_multi_n_shards", "scanrs_multi_shard", "scanrs_multi_normalize", "scanrs_multi_pca_bk", "scanrs_multi_pca_rand", "scanrs_multi_pca_irlba", "scanrs_multi_log_normalize",
     "scanrs_plan_shards", "scanrs_profile_enable", "scanrs_profile_reset", "scanrs_profile_get", "scanrs_mat_sync", "scanrs_mat_set_spmm_path", "scanrs_mat_set_option", "scanrs_set_global_option", "scanrs_mat_set_panel_precision",
-    "scanrs_host_chol_upper", "scanrs_host_inv_upper", "scanrs_host_sym_eig", "scanrs_host_sym_eig_topk",
+    "scanrs_mat_chol_rinv", "scanrs_mat_get_counter", "scanrs_host_chol_upper", "scanrs_host_inv_upper", "scanrs_host_sym_eig", "scanrs_host_sym_eig_topk",
     "scanrs_h5_read_csc_matrix", "scanrs_h5_read_adaptive_csr_matrix", "scanrs_h5_read_matrix_metadata", "scanrs_h5_matrix_free",
     "scanrs_h5_matrix_shape", "scanrs_h5_matrix_arrays", "scanrs_h5_matrix_n_strings", "scanrs_h5_matrix_string", "scanrs_h5_matrix_removed",
     "scanrs_h5_read_umi_counts", "scanrs_h5_get_clustering_keys", "scanrs_h5_get_clustering", "scanrs_h5_get_differential_expression",

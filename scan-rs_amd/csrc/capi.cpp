@@ -1185,6 +1185,8 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.spmv_lds = value != 0.0;
         } else if (k == "overlap") {
             st.overlap = value != 0.0;
+        } else if (k == "device_factor") {
+            st.device_factor = value != 0.0;
         } else if (k == "d2h_threads") {
             st.d2h_threads = (unsigned)std::max(1.0, value);
         } else if (k == "reuse_cmax") {
@@ -1193,6 +1195,16 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
         } else {
             fail(SCANRS_ERR_ARGUMENT, "unknown option '%s'", key);
         }
+    });
+}
+int scanrs_mat_get_counter(scanrs_mat *m, const char *key, uint64_t *value) {
+    return guard([&] {
+        if (!m || !key || !value) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        const std::string k(key);
+        if (k == "bk_host_retries")
+            *value = m->st->bk_host_retries;
+        else
+            fail(SCANRS_ERR_ARGUMENT, "unknown counter '%s'", key);
     });
 }
 int scanrs_mat_set_panel_precision(scanrs_mat *m, int precision) {
@@ -1206,6 +1218,34 @@ int scanrs_mat_sync(scanrs_mat *m) {
     return guard([&] {
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
         SCANRS_HIP(hipStreamSynchronize(m->st->stream));
+    });
+}
+
+// One pass of the device-side CholeskyQR factor step on a host matrix (tests / diagnostics; the solvers queue the same
+// kernel between a Gram kernel and a GEMM without looking at its verdict until the Krylov basis is complete).
+int scanrs_mat_chol_rinv(scanrs_mat *m, const double *g, uint32_t n, uint64_t rows, int pass, double *rinv, int *done, int *status,
+                         double *err, double *shift) {
+    return guard([&] {
+        if (!m || !g || !rinv) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        if (!chol_rinv_ok(n)) fail(SCANRS_ERR_ARGUMENT, "n must be in 1..128");
+        Storage &st = *m->st;
+        double *dG = st.scratch.get<double>("chk_G", (size_t)n * n), *dR = st.scratch.get<double>("chk_R", (size_t)n * n);
+        double *dInfo = st.scratch.get<double>("chk_info", 2);
+        int *dCtl = st.scratch.get<int>("chk_ctl", 2);
+        SCANRS_HIP(hipMemcpyAsync(dG, g, (size_t)n * n * 8, hipMemcpyHostToDevice, st.stream));
+        SCANRS_HIP(hipMemsetAsync(dCtl, 0, 2 * sizeof(int), st.stream));
+        SCANRS_HIP(hipMemsetAsync(dInfo, 0, 2 * sizeof(double), st.stream));
+        launch_chol_rinv(st, dG, n, rows, pass, false, dCtl, dR, dInfo);
+        int ctl[2];
+        double info[2];
+        SCANRS_HIP(hipMemcpyAsync(rinv, dR, (size_t)n * n * 8, hipMemcpyDeviceToHost, st.stream));
+        SCANRS_HIP(hipMemcpyAsync(ctl, dCtl, sizeof ctl, hipMemcpyDeviceToHost, st.stream));
+        SCANRS_HIP(hipMemcpyAsync(info, dInfo, sizeof info, hipMemcpyDeviceToHost, st.stream));
+        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        if (done) *done = ctl[0];
+        if (status) *status = ctl[1];
+        if (err) *err = info[0];
+        if (shift) *shift = info[1];
     });
 }
 

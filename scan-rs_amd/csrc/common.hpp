@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdarg>
 #include <map>
+#include <set>
 #include <memory>
 #include <string>
 #include <utility>
@@ -92,7 +93,11 @@ struct Scratch {
         }
         return reinterpret_cast<T *>(b.p);
     }
-    void clear() { bufs.clear(); }
+    std::set<std::string> filled; // keys whose (constant) contents are already on the device
+    void clear() {
+        bufs.clear();
+        filled.clear();
+    }
 };
 
 // ---- per-kernel-class timing (scanrs_profile_*) -------------------------------------
@@ -192,6 +197,8 @@ struct Storage {
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr; // small dense work that overlaps a sparse pass (svd_bk's cross-block orthogonalisation)
     hipStream_t aux();
+    // scratch key of the stream work is being queued on: the auxiliary stream runs beside the main one and must not share its temporaries
+    std::string skey(const char *k) const { return (aux_stream && stream == aux_stream) ? std::string(k) + "@aux" : std::string(k); }
     hipStream_t ov_stream = nullptr; // the gather over the overflow part of a tile layout runs here, beside the tile kernel (tiles.hip)
     hipEvent_t ev_in = nullptr, ev_ov = nullptr;
     hipStream_t ov();
@@ -237,6 +244,8 @@ struct Storage {
     int slice_walk = 1;                   // Ix1 products / moments on the short-outer copy stage the inner-indexed arrays in LDS slices
     int spmv_lds = 1;                     // Ix1 products on the long-outer copy stage the vector in LDS parts
     int overlap = 1;                      // small dense work of the solvers on a second stream beside the sparse passes
+    uint64_t bk_host_retries = 0;         // svd_bk calls that fell back from the device-side factorizations to the host path (scanrs_mat_get_counter)
+    int device_factor = 1;                // svd_bk: CholeskyQR factors and the coefficient bookkeeping on the device, no host round trip per orthonormalisation (0: host)
     unsigned d2h_threads = 4;             // host threads that empty the pinned ring of a large result download
     double reuse_cmax = 1e5;              // svd_bk: coefficient bound above which a projection column is recomputed directly
     int materialize = 1;                  // keep the map prefix's values per nonzero on the short-outer copy (SCANRS_MATERIALIZE=0: off)
@@ -352,6 +361,9 @@ void compact_nonzeros(Storage &st, SparseCopy &cp);
 
 // ---- host_linalg.cpp --------------------------------------------------------------------------
 // Upper Cholesky G = R^T R of an n x n SPD matrix (row-major, in place: upper triangle = R). false if not SPD.
+bool chol_rinv_ok(uint32_t n);
+void launch_chol_rinv(Storage &st, const double *G, uint32_t n, uint64_t rows, int pass, bool check_only, int *ctl, double *Rinv, double *info);
+void launch_absmax_flag(Storage &st, const double *C, uint32_t count, double limit, int *ctl, double *info);
 bool chol_upper(double *g, int n);
 // in place inverse of an upper-triangular matrix
 void inv_upper(double *r, int n);

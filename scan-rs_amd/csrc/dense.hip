@@ -314,6 +314,224 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const double *__restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Small factorizations on the device (one workgroup, the matrix in LDS): the b x b Cholesky factor and its inverse that
+// CholeskyQR needs between a Gram kernel and a GEMM. On the host they cost a D2H copy, a stream synchronisation and an H2D
+// copy per pass (0.2-0.4 ms each, several per orthonormalisation, and the device idle meanwhile); here the whole
+// orthonormalisation is queued without the host looking at anything. Same arithmetic as host_linalg.cpp's chol_upper /
+// inv_upper (row-oriented, sums in the same order), same shift rule as orth_cholqr (shifted CholeskyQR, Fukaya et al. 2020).
+//   ctl[0]  in/out  1 once this orthonormalisation has converged (or failed): the kernel then returns Rinv = I, so that
+//                   the GEMMs queued behind it leave the panel as it is
+//   ctl[1]  out     status, sticky: 0 ok, 1 Cholesky failed, 2 non-finite Gram matrix
+//   info[0] = max |G - I| of this pass, info[1] = shift used
+// check_only: the last queued pass only tests convergence.
+constexpr uint32_t CHOL_NMAX = 128;
+constexpr int CHOL_E = CHOL_NMAX / 16; // entries per thread and dimension: thread (ty, tx) of 16 x 16 owns (ty + 16 a, tx + 16 b)
+// The matrix lives in REGISTERS (cyclic 16 x 16 distribution, 8 x 8 entries per thread, compile-time indices); a step
+// broadcasts one row (and, for the inverse, one column) through LDS and every thread applies the rank-1 update to its own
+// entries: two barriers and ~130 instructions per step, ~25 us for n = 100 (an LDS-resident version with per-entry
+// read-modify-write loops ran 290 us, bound by LDS latency).
+__global__ __launch_bounds__(256) void chol_rinv_kernel(const double *__restrict__ G, uint32_t n, double rows, int pass, int check_only,
+                                                        int *__restrict__ ctl, double *__restrict__ Rinv, double *__restrict__ info) {
+    __shared__ double rowbuf[CHOL_NMAX], colbuf[CHOL_NMAX], red[3 * 256];
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, ty = tid >> 4, tx = tid & 15u;
+    auto identity_out = [&]() {
+        if (check_only) return;
+        for (uint32_t e = tid; e < n * n; e += nt) Rinv[e] = (e / n == e % n) ? 1.0 : 0.0;
+    };
+    if (ctl[0]) { // already converged (or failed): nothing to apply
+        identity_out();
+        return;
+    }
+    // max |G - I|, largest diagonal entry, finiteness
+    double err = 0.0, dmax = 0.0;
+    int bad = 0;
+    for (uint32_t e = tid; e < n * n; e += nt) {
+        const uint32_t i = e / n, j = e - i * n;
+        const double g = G[e];
+        if (!isfinite(g)) bad = 1;
+        err = fmax(err, fabs(g - (i == j ? 1.0 : 0.0)));
+        if (i == j) dmax = fmax(dmax, g);
+    }
+    red[tid] = err;
+    red[nt + tid] = dmax;
+    red[2 * nt + tid] = (double)bad;
+    __syncthreads();
+    for (uint32_t s = nt / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[tid] = fmax(red[tid], red[tid + s]);
+            red[nt + tid] = fmax(red[nt + tid], red[nt + tid + s]);
+            red[2 * nt + tid] = fmax(red[2 * nt + tid], red[2 * nt + tid + s]);
+        }
+        __syncthreads();
+    }
+    err = red[0];
+    dmax = red[nt];
+    bad = red[2 * nt] != 0.0;
+    __syncthreads();
+    if (tid == 0 && info) info[0] = err;
+    if (bad) {
+        if (tid == 0) {
+            ctl[0] = 1;
+            ctl[1] = 2;
+        }
+        identity_out();
+        return;
+    }
+    if (pass >= 1 && err < 5e-14 * sqrt((double)n)) { // orth_cholqr's stopping rule
+        if (tid == 0) ctl[0] = 1;
+        identity_out();
+        return;
+    }
+    if (check_only) return; // not converged within the queued passes: ctl[0] stays 0, the host falls back
+    double A[CHOL_E][CHOL_E];
+    double shift = 0.0;
+    for (int tries = 0;; tries++) {
+#pragma unroll
+        for (int a = 0; a < CHOL_E; a++)
+#pragma unroll
+            for (int b = 0; b < CHOL_E; b++) {
+                const uint32_t i = ty + 16u * a, j = tx + 16u * b;
+                A[a][b] = (i < n && j < n && j >= i) ? G[i * n + j] + (i == j ? shift : 0.0) : 0.0;
+            }
+        // G (+ shift I) = R^T R, right-looking: an entry (i, j) loses r_ki r_kj for k = 0, 1, ... — the order of chol_upper's row loop
+        bool failed = false;
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t ka = k >> 4, kt = k & 15u;
+#pragma unroll
+            for (int a = 0; a < CHOL_E; a++)
+                if ((uint32_t)a == ka && ty == kt) {
+#pragma unroll
+                    for (int b = 0; b < CHOL_E; b++) rowbuf[tx + 16u * b] = A[a][b]; // row k as it stands (entries left of the diagonal are zeros)
+                }
+            __syncthreads();
+            const double d = rowbuf[k];
+            if (!(d > 0.0) || !isfinite(d)) { // uniform
+                failed = true;
+                break;
+            }
+            const double sq = sqrt(d), inv = 1.0 / sq;
+            double g[CHOL_E], f[CHOL_E];
+#pragma unroll
+            for (int b = 0; b < CHOL_E; b++) g[b] = rowbuf[tx + 16u * b] * inv;
+#pragma unroll
+            for (int a = 0; a < CHOL_E; a++) f[a] = rowbuf[ty + 16u * a] * inv;
+#pragma unroll
+            for (int a = 0; a < CHOL_E; a++) {
+                if (16u * a + 15u < k) continue; // uniform: every row of this block is finished
+                const uint32_t i = ty + 16u * a;
+#pragma unroll
+                for (int b = a; b < CHOL_E; b++) { // blocks left of the diagonal block hold no entry with j >= i
+                    const uint32_t j = tx + 16u * b;
+                    if (i == k)
+                        A[a][b] = j == k ? sq : (j > k ? g[b] : 0.0);
+                    else if (i > k && j >= i)
+                        A[a][b] -= f[a] * g[b];
+                }
+            }
+            __syncthreads(); // rowbuf is rewritten by the next step
+        }
+        __syncthreads();
+        if (!failed) break;
+        shift = shift == 0.0 ? 11.0 * (rows * n + (double)n * (n + 1)) * 1.1e-16 * dmax : shift * 100.0;
+        if (tries + 1 > 12 || !(dmax > 0.0)) {
+            if (tid == 0) {
+                ctl[0] = 1;
+                ctl[1] = 1;
+            }
+            identity_out();
+            return;
+        }
+    }
+    if (tid == 0 && info) info[1] = shift;
+    // X = R^-1 in place, rows bottom-up: row m of X is final once rows > m are; it then enters the sums of every row k < m:
+    // S[k][j] += r_km x_mj (j >= m). S[k][j] takes the register of r_kj, which was consumed at step j.
+    for (int m = (int)n - 1; m >= 0; m--) {
+        const uint32_t ma = (uint32_t)m >> 4, mt = (uint32_t)m & 15u;
+#pragma unroll
+        for (int b = 0; b < CHOL_E; b++)
+            if ((uint32_t)b == ma && tx == mt) {
+#pragma unroll
+                for (int a = 0; a < CHOL_E; a++) colbuf[ty + 16u * a] = A[a][b]; // column m of R (rows < m are used)
+            }
+        __syncthreads();
+        const double invd = 1.0 / colbuf[m];
+#pragma unroll
+        for (int a = 0; a < CHOL_E; a++)
+            if ((uint32_t)a == ma && ty == mt) {
+#pragma unroll
+                for (int b = 0; b < CHOL_E; b++) {
+                    const uint32_t j = tx + 16u * b;
+                    const double x = j == (uint32_t)m ? invd : (j > (uint32_t)m ? -A[a][b] * invd : 0.0);
+                    A[a][b] = x;
+                    rowbuf[j] = x;
+                }
+            }
+        __syncthreads();
+        double cf[CHOL_E], xr[CHOL_E];
+#pragma unroll
+        for (int a = 0; a < CHOL_E; a++) cf[a] = colbuf[ty + 16u * a];
+#pragma unroll
+        for (int b = 0; b < CHOL_E; b++) xr[b] = rowbuf[tx + 16u * b];
+#pragma unroll
+        for (int a = 0; a < CHOL_E; a++) {
+            if (16u * a > (uint32_t)m) continue; // uniform: no row of this block is above row m
+            const uint32_t k = ty + 16u * a;
+#pragma unroll
+            for (int b = a; b < CHOL_E; b++) {
+                if (16u * b + 15u < (uint32_t)m) continue; // uniform: every column of this block is left of column m
+                const uint32_t j = tx + 16u * b;
+                if (k < (uint32_t)m && j >= (uint32_t)m) A[a][b] = j == (uint32_t)m ? cf[a] * xr[b] : fma(cf[a], xr[b], A[a][b]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < CHOL_E; a++)
+#pragma unroll
+        for (int b = 0; b < CHOL_E; b++) {
+            const uint32_t i = ty + 16u * a, j = tx + 16u * b;
+            if (i < n && j < n) Rinv[i * n + j] = j >= i ? A[a][b] : 0.0;
+        }
+}
+
+bool chol_rinv_ok(uint32_t n) { return n >= 1 && n <= CHOL_NMAX; }
+void launch_chol_rinv(Storage &st, const double *G, uint32_t n, uint64_t rows, int pass, bool check_only, int *ctl, double *Rinv, double *info) {
+    if (!chol_rinv_ok(n)) fail(SCANRS_ERR_ARGUMENT, "device Cholesky: n out of range");
+    if (st.prof.on) st.prof.begin(st.stream, "chol_rinv", (double)n * n * 16.0);
+    hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(256), 0, st.stream, G, n, (double)rows, pass, check_only ? 1 : 0, ctl, Rinv, info);
+    if (st.prof.on) st.prof.end(st.stream);
+    SCANRS_HIP(hipGetLastError());
+}
+
+// ctl[1] = 3 (sticky) when max |C| >= limit: the cross-block projection of svd_bk's qr(K) did not reach rounding level
+__global__ void absmax_flag_kernel(const double *__restrict__ C, uint32_t count, double limit, int *__restrict__ ctl, double *__restrict__ info) {
+    __shared__ double red[256];
+    double m = 0.0;
+    for (uint32_t e = threadIdx.x; e < count; e += blockDim.x) {
+        const double x = fabs(C[e]);
+        m = (x > m || x != x) ? x : m;
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (uint32_t s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            const double o = red[threadIdx.x + s];
+            if (o > red[threadIdx.x] || o != o) red[threadIdx.x] = o;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (info) info[0] = red[0];
+        ctl[0] = 1; // a check, not an orthonormalisation: complete as soon as it has run
+        if (!(red[0] < limit) && ctl[1] == 0) ctl[1] = 3;
+    }
+}
+void launch_absmax_flag(Storage &st, const double *C, uint32_t count, double limit, int *ctl, double *info) {
+    hipLaunchKernelGGL(absmax_flag_kernel, dim3(1), dim3(256), 0, st.stream, C, count, limit, ctl, info);
+    SCANRS_HIP(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------------------
 bool gram_tiled_ok(uint32_t n, uint32_t m, uint64_t rows) { return n >= 48 && m >= 48 && rows >= 2048; }
 bool gemm_tiled_ok(uint32_t n, uint32_t m, uint64_t rows) { return n >= 16 && m >= 48 && rows >= 2048; }
 
@@ -328,15 +546,20 @@ void launch_gram_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, c
             tiles.push_back(j);
         }
     const uint32_t n_tiles = (uint32_t)tiles.size() / 2;
-    uint32_t *d_tiles = st.scratch.get<uint32_t>("gramt_tiles", tiles.size());
-    SCANRS_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st.stream));
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    // the list depends on (tn, tm, symmetric) only: uploaded once per shape, so that a Gram product is a pure enqueue
+    char tkey[64];
+    snprintf(tkey, sizeof tkey, "gramt_tiles_%u_%u_%d", tn, tm, symmetric ? 1 : 0);
+    uint32_t *d_tiles = st.scratch.get<uint32_t>(tkey, tiles.size());
+    if (st.scratch.filled.insert(tkey).second) {
+        SCANRS_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st.stream));
+        SCANRS_HIP(hipStreamSynchronize(st.stream));
+    }
     // ~2k workgroups, slices of at least 256 rows and a multiple of the staging depth
     uint64_t splits = std::max<uint64_t>(1, std::min<uint64_t>((rows + 255) / 256, (2048 + n_tiles - 1) / n_tiles));
     uint64_t rps = (rows + splits - 1) / splits;
     rps = (rps + DK - 1) / DK * DK;
     splits = std::max<uint64_t>(1, (rows + rps - 1) / rps);
-    double *slab = st.scratch.get<double>("gram_slab", (size_t)splits * n * m);
+    double *slab = st.scratch.get<double>(st.skey("gram_slab"), (size_t)splits * n * m);
     if (st.prof.on) st.prof.begin(st.stream, "gram_tiled_mfma_f64", (double)rows * (n + (symmetric ? 0 : m)) * 8.0 + (double)n * m * 8.0);
     hipLaunchKernelGGL(gram_tiled_kernel, dim3(n_tiles, (unsigned)splits), dim3(256), 0, st.stream, X, ldx, n, Y, ldy, m, rows, rps,
                        d_tiles, slab);

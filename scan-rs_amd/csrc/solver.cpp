@@ -380,6 +380,74 @@ static void orth_against(Ctx &c, const double *Q, uint32_t ldq, uint32_t nprev, 
     }
 }
 
+// ---- the same orthonormalisations without a host round trip (Storage::device_factor) -------------------------------------
+// Every CholeskyQR pass is Gram kernel -> chol_rinv_kernel (one workgroup: stopping rule, Cholesky with the shift rule,
+// inverse) -> GEMM, all queued; a converged orthonormalisation turns its remaining passes into products with the identity.
+// The verdicts (converged? Cholesky failed? non-finite?) are left in a control block per call and read ONCE, with the
+// coefficient matrix, when the Krylov basis is complete: anything but "converged, ok" makes svd_bk start over on the host
+// path (rank-deficient inputs that need more shifted passes than are queued here).
+struct DevOrth {
+    int *ctl = nullptr;     // 2 ints per call: [done, status]
+    double *info = nullptr; // 2 doubles per call: [max |G - I| or max |C| of the last check, shift]
+    uint32_t used = 0;
+    static constexpr uint32_t CAP = 256;
+    void init(Ctx &c) {
+        ctl = c.st.scratch.get<int>("orth_ctl", 2 * CAP);
+        info = c.st.scratch.get<double>("orth_info", 2 * CAP);
+        SCANRS_HIP(hipMemsetAsync(ctl, 0, 2 * CAP * sizeof(int), c.s));
+        SCANRS_HIP(hipMemsetAsync(info, 0, 2 * CAP * sizeof(double), c.s));
+        used = 0;
+    }
+    uint32_t next() {
+        if (used >= CAP) fail(SCANRS_ERR_NUMERICAL, "orthonormalisation bookkeeping exhausted");
+        return used++;
+    }
+};
+constexpr int DEV_CHOLQR_PASSES = 3; // two applications and a final check (the host loop usually stops at its second Gram matrix)
+
+// coef (coef_rows x n, ld ldcoef, device; optional) follows P: every right-multiplication applied to P is applied to it
+static void orth_cholqr_dev(Ctx &c, DevOrth &od, double *P, double *tmp, uint32_t ld, uint32_t n, uint64_t rows, double *coef = nullptr,
+                            double *coef_tmp = nullptr, uint32_t coef_rows = 0, uint32_t ldcoef = 0) {
+    const uint32_t slot = od.next();
+    int *ctl = od.ctl + 2 * slot;
+    double *info = od.info + 2 * slot;
+    double *dG = c.dev(c.st.skey("orth_G").c_str(), (size_t)n * n);
+    double *dR = c.dev(c.st.skey("orth_Rinv").c_str(), (size_t)n * n);
+    for (int pass = 0; pass < DEV_CHOLQR_PASSES; pass++) {
+        const bool last = pass + 1 == DEV_CHOLQR_PASSES;
+        launch_gram(c.st, P, ld, n, P, ld, n, rows, dG);
+        launch_chol_rinv(c.st, dG, n, rows, pass, last, ctl, dR, info);
+        if (last) break;
+        launch_gemm_nn(c.st, P, ld, n, dR, n, n, rows, 1.0, 0.0, nullptr, 0, tmp, ld);
+        SCANRS_HIP(hipMemcpyAsync(P, tmp, (size_t)rows * ld * 8, hipMemcpyDeviceToDevice, c.s));
+        if (coef) {
+            launch_gemm_nn(c.st, coef, ldcoef, n, dR, n, n, coef_rows, 1.0, 0.0, nullptr, 0, coef_tmp, ldcoef);
+            SCANRS_HIP(hipMemcpyAsync(coef, coef_tmp, (size_t)coef_rows * ldcoef * 8, hipMemcpyDeviceToDevice, c.s));
+        }
+    }
+}
+
+// Block Bj against the first nprev columns of Q and within itself: two rounds of (project, CholeskyQR) — "twice is enough";
+// the host loop's third Gram matrix, which only confirms that the projection has reached rounding level, is the final check here.
+// coef (q x b, ld ldb) / cfull (q x q, ld ldcf): Bj = Korig coef, Q = Korig cfull, both on the device.
+static void orth_against_dev(Ctx &c, DevOrth &od, const double *Q, uint32_t ldq, uint32_t nprev, double *Bj, double *tmp, uint32_t ldb,
+                             uint32_t b, uint64_t rows, double *coef, double *coef_tmp, const double *cfull, uint32_t q, uint32_t ldcf) {
+    double *dC = nprev ? c.dev(c.st.skey("orth_C").c_str(), (size_t)nprev * b) : nullptr;
+    for (int round = 0; round < 2; round++) {
+        if (nprev) {
+            launch_gram(c.st, Q, ldq, nprev, Bj, ldb, b, rows, dC);
+            launch_gemm_nn(c.st, Q, ldq, nprev, dC, b, b, rows, -1.0, 1.0, Bj, ldb, Bj, ldb);
+            // coef -= cfull[:, :nprev] C; rows >= nprev of those columns of cfull are zero (block upper triangular)
+            launch_gemm_nn(c.st, cfull, ldcf, nprev, dC, b, b, nprev, -1.0, 1.0, coef, ldb, coef, ldb);
+        }
+        orth_cholqr_dev(c, od, Bj, tmp, ldb, b, rows, coef, coef_tmp, q, ldb);
+        if (!nprev) return;
+    }
+    const uint32_t slot = od.next();
+    launch_gram(c.st, Q, ldq, nprev, Bj, ldb, b, rows, dC);
+    launch_absmax_flag(c.st, dC, nprev * b, 1e-14, od.ctl + 2 * slot, od.info + 2 * slot);
+}
+
 // Which side of the view is long / sharded
 static bool dim_sharded_rows(const scanrs_mat *m) { return rows_sharded(m); }
 static bool dim_sharded_cols(const scanrs_mat *m) { return cols_sharded(m); }
@@ -561,10 +629,23 @@ static void pca_dev_swap(Storage &st) {
     std::swap(st.pca_dev.rows_u, st.pca_dev.rows_v);
 }
 
-int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
-           const scanrs_snoop *snoop, double *u, double *s, double *v) {
+constexpr int BK_RETRY_ON_HOST = -1000; // device-side factorizations did not converge: run again with host factorizations
+static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
+                       const scanrs_snoop *snoop, double *u, double *s, double *v, bool device_factor) {
     Tick tk_all("bk: total");
     Ctx c(m);
+    // work is queued far ahead of the device here: whatever ends this call early (cancellation, a numerical failure) waits for
+    // both streams before the scratch buffers change hands
+    struct Drain {
+        Storage &st;
+        int n0 = std::uncaught_exceptions();
+        ~Drain() {
+            if (std::uncaught_exceptions() > n0) {
+                (void)hipStreamSynchronize(st.stream);
+                if (st.aux_stream) (void)hipStreamSynchronize(st.aux_stream);
+            }
+        }
+    } drain{c.st};
     const uint64_t M = m->rows(), N = m->cols();
     // global extents decide the branch and the validation, as the reference sees the whole matrix
     const uint64_t Mg = dim_sharded_rows(m) ? c.st.shard.outer_global : M;
@@ -648,6 +729,27 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
     double *Bj = c.dev("bk_Bj", (size_t)ds * ldb);
     double *Btmp = c.dev("bk_Btmp", (size_t)ds * ldb);
     uint32_t next_block = 1;
+    // device_factor: the factors and the coefficient matrix stay on the device (orth_*_dev above); the host copy of cfull is
+    // filled once, when the basis is complete
+    const bool dv = device_factor && chol_rinv_ok(b);
+    DevOrth od;
+    double *cfull_d = nullptr, *coef_d = nullptr, *coef_tmp_d = nullptr;
+    if (dv) {
+        od.init(c);
+        cfull_d = c.dev("bk_cfull", (size_t)q * ldq);
+        coef_d = c.dev("bk_coef", (size_t)q * ldb);
+        coef_tmp_d = c.dev("bk_coef_tmp", (size_t)q * ldb);
+        SCANRS_HIP(hipMemcpy2DAsync(cfull_d, (size_t)ldq * 8, cfull.data(), (size_t)q * 8, (size_t)q * 8, q, hipMemcpyHostToDevice, c.s));
+        c.sync(); // cfull is pageable host memory
+    }
+    auto orth_block_dev = [&](Ctx &cx, uint32_t i) {
+        launch_copy_cols(cx.st, K + (size_t)i * b, ldq, Bj, ldb, ds, b);
+        launch_copy_cols(cx.st, cfull_d + (size_t)i * b, ldq, coef_d, ldb, q, b); // the identity block
+        orth_against_dev(cx, od, K, ldq, i * b, Bj, Btmp, ldb, b, ds, coef_d, coef_tmp_d, cfull_d, q, ldq);
+        launch_copy_cols(cx.st, Bj, ldb, K + (size_t)i * b, ldq, ds, b);
+        launch_copy_cols(cx.st, coef_d, ldb, cfull_d + (size_t)i * b, ldq, q, b);
+        next_block = i + 1;
+    };
     auto orth_block_on = [&](Ctx &cx, uint32_t i) {
         std::vector<double> coef((size_t)q * b, 0.0);
         launch_copy_cols(cx.st, K + (size_t)i * b, ldq, Bj, ldb, ds, b);
@@ -674,21 +776,29 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
         hipEvent_t e = nullptr;
         Ev() { SCANRS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
         ~Ev() { (void)hipEventDestroy(e); }
-    } ev_pass, ev_proj;
+    } ev_pass, ev_proj, ev_aux;
+    std::vector<Ev> ev_k(n_iter); // K block i is in place (main stream)
     std::vector<char> projected(n_iter, 0);
     auto project_block_early = [&](uint32_t j) { // T block j (written by the pass just queued on the main stream) is ready at ev_pass
         const uint32_t nr = (j + 1) * b;
-        std::vector<double> W((size_t)nr * b);
-        for (uint32_t r = 0; r < nr; r++)
-            for (uint32_t cc = 0; cc < b; cc++) W[(size_t)r * b + cc] = cfull[(size_t)r * q + j * b + cc];
+        std::vector<double> W;
+        if (!dv) {
+            W.resize((size_t)nr * b);
+            for (uint32_t r = 0; r < nr; r++)
+                for (uint32_t cc = 0; cc < b; cc++) W[(size_t)r * b + cc] = cfull[(size_t)r * q + j * b + cc];
+        }
         StreamSwap sw(c.st, c.st.aux());
         Ctx cx(m);
-        char key[32];
-        snprintf(key, sizeof(key), "bk_projw%u", j);
-        double *dW = cx.dev(key, (size_t)nr * b);
-        cx.h2d(dW, W.data(), W.size());
         SCANRS_HIP(hipStreamWaitEvent(cx.s, ev_pass.e, 0));
-        launch_gemm_nn(cx.st, T, ldq, nr, dW, b, b, dt, 1.0, 0.0, nullptr, 0, S + (size_t)(j - 1) * b, ld_s);
+        if (dv) { // the coefficients of block j were finished on this stream a moment ago
+            launch_gemm_nn(cx.st, T, ldq, nr, cfull_d + (size_t)j * b, ldq, b, dt, 1.0, 0.0, nullptr, 0, S + (size_t)(j - 1) * b, ld_s);
+        } else {
+            char key[32];
+            snprintf(key, sizeof(key), "bk_projw%u", j);
+            double *dW = cx.dev(key, (size_t)nr * b);
+            cx.h2d(dW, W.data(), W.size());
+            launch_gemm_nn(cx.st, T, ldq, nr, dW, b, b, dt, 1.0, 0.0, nullptr, 0, S + (size_t)(j - 1) * b, ld_s);
+        }
         SCANRS_HIP(hipEventRecord(ev_proj.e, cx.s));
         projected[j] = 1;
     };
@@ -702,7 +812,15 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
         // orthogonal to blocks < i-1 now, on the auxiliary stream, while the sparse pass just queued occupies the
         // main one (host round trips of the small factorizations hidden behind ~40 ms of gather work).
         if (i >= 2) {
-            orth_block(i - 1);
+            if (dv) { // queued on the auxiliary stream, nothing waited for
+                StreamSwap sw(c.st, c.st.aux());
+                Ctx cx(m);
+                SCANRS_HIP(hipStreamWaitEvent(cx.s, ev_k[i - 1].e, 0));
+                orth_block_dev(cx, i - 1);
+                SCANRS_HIP(hipEventRecord(ev_aux.e, cx.s));
+            } else {
+                orth_block(i - 1);
+            }
             if (n_early && i - 1 <= n_early) {
                 SCANRS_HIP(hipEventRecord(ev_pass.e, c.s)); // after the pass that wrote T block i-1
                 project_block_early(i - 1);
@@ -713,16 +831,50 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
             Tick tw("  passes (wait)");
             c.sync();
         }
-        orth_cholqr(c, P, Ptmp, ldb, b, ds, false);
+        if (dv)
+            orth_cholqr_dev(c, od, P, Ptmp, ldb, b, ds);
+        else
+            orth_cholqr(c, P, Ptmp, ldb, b, ds, false);
         launch_copy_cols(c.st, P, ldb, K + (size_t)i * b, ldq, ds, b);
-        c.sync();
+        if (dv) {
+            // the host stays one iteration ahead of the device: the queue never runs dry and a cancellation is seen within one iteration
+            SCANRS_HIP(hipEventRecord(ev_k[i].e, c.s));
+            if (trace_on())
+                c.sync();
+            else if (i >= 1)
+                SCANRS_HIP(hipEventSynchronize(ev_k[i - 1].e));
+        } else {
+            c.sync();
+        }
         progress_check(snoop, (double)i / (double)n_iter * 0.8);
     }
     // the last block (and everything, when there was no iteration to hide behind) on the main stream
     {
         Tick tk("bk: orth(K)");
-        for (uint32_t i = next_block; i < n_iter; i++) orth_block_on(c, i);
-        c.sync();
+        if (dv) {
+            if (next_block > 1) SCANRS_HIP(hipStreamWaitEvent(c.s, ev_aux.e, 0)); // the blocks done beside the passes
+            for (uint32_t i = next_block; i < n_iter; i++) orth_block_dev(c, i);
+            // the one look at what the device-side factorizations did, together with the coefficients
+            std::vector<int> ctl(2 * (size_t)od.used);
+            std::vector<double> info(2 * (size_t)od.used);
+            SCANRS_HIP(hipMemcpy2DAsync(cfull.data(), (size_t)q * 8, cfull_d, (size_t)ldq * 8, (size_t)q * 8, q, hipMemcpyDeviceToHost, c.s));
+            SCANRS_HIP(hipMemcpyAsync(ctl.data(), od.ctl, ctl.size() * sizeof(int), hipMemcpyDeviceToHost, c.s));
+            SCANRS_HIP(hipMemcpyAsync(info.data(), od.info, info.size() * sizeof(double), hipMemcpyDeviceToHost, c.s));
+            c.sync();
+            for (uint32_t sl = 0; sl < od.used; sl++) {
+                if (ctl[2 * sl + 1] == 2) fail(SCANRS_ERR_NUMERICAL, "orthonormalisation: non-finite Gram matrix");
+                if (ctl[2 * sl] != 1 || ctl[2 * sl + 1] != 0) {
+                    if (trace_on())
+                        fprintf(stderr, "[scanrs trace] bk: device factorization %u: done %d status %d (last check %.3e, shift %.3e) -> host path\n", sl,
+                                ctl[2 * sl], ctl[2 * sl + 1], info[2 * sl], info[2 * sl + 1]);
+                    if (c.st.aux_stream) SCANRS_HIP(hipStreamSynchronize(c.st.aux_stream));
+                    return BK_RETRY_ON_HOST;
+                }
+            }
+        } else {
+            for (uint32_t i = next_block; i < n_iter; i++) orth_block_on(c, i);
+            c.sync();
+        }
     }
     progress_check(snoop, 0.82);
     // T' = (op(A) K) C amplifies the rounding of op(A) K by |C|. Columns of Q whose coefficient column stays
@@ -797,12 +949,16 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
             for (uint32_t j = n_iter - 1 - (last_direct ? 1u : 0u); j >= 1; j--) {
                 if (projected[j]) continue; // done early, waiting in S
                 const uint32_t nr = (j + 1) * b;
-                W.assign((size_t)nr * b, 0.0);
-                for (uint32_t r = 0; r < nr; r++)
-                    for (uint32_t cc = 0; cc < b; cc++) W[(size_t)r * b + cc] = cfull[(size_t)r * q + j * b + cc];
-                double *dW = c.dev("bk_projw", (size_t)nr * b);
-                c.h2d(dW, W.data(), W.size());
-                launch_gemm_nn(c.st, T, ldq, nr, dW, b, b, dt, 1.0, 0.0, nullptr, 0, Y, ldb);
+                if (dv) {
+                    launch_gemm_nn(c.st, T, ldq, nr, cfull_d + (size_t)j * b, ldq, b, dt, 1.0, 0.0, nullptr, 0, Y, ldb);
+                } else {
+                    W.assign((size_t)nr * b, 0.0);
+                    for (uint32_t r = 0; r < nr; r++)
+                        for (uint32_t cc = 0; cc < b; cc++) W[(size_t)r * b + cc] = cfull[(size_t)r * q + j * b + cc];
+                    double *dW = c.dev("bk_projw", (size_t)nr * b);
+                    c.h2d(dW, W.data(), W.size());
+                    launch_gemm_nn(c.st, T, ldq, nr, dW, b, b, dt, 1.0, 0.0, nullptr, 0, Y, ldb);
+                }
                 launch_copy_cols(c.st, Y, ldb, T + (size_t)j * b, ldq, dt, b);
             }
             bool any_early = false;
@@ -842,6 +998,16 @@ int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint
     }
     progress_check(snoop, 1.0);
     return SCANRS_OK;
+}
+
+int pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
+           const scanrs_snoop *snoop, double *u, double *s, double *v) {
+    int rc = pca_bk_impl(m, k, k_multiplier, n_iter, seed, omega, snoop, u, s, v, m->st->device_factor != 0);
+    if (rc == BK_RETRY_ON_HOST) {
+        m->st->bk_host_retries++;
+        rc = pca_bk_impl(m, k, k_multiplier, n_iter, seed, omega, snoop, u, s, v, false);
+    }
+    return rc;
 }
 
 int pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, uint64_t seed, const double *omega, double *u,

@@ -162,32 +162,40 @@ __global__ void tile_init_rows_kernel(uint16_t *__restrict__ prow, uint64_t n_re
     }
 }
 
-// pw[rec] = the map chain at the record's (count, outer, inner); unused positions (count 0) keep the weight 0 of the build.
-// One thread per record; nset * 64 is a power of two and (group, visit) pairs fit 32 bits (checked by the builder).
-// Unit mode (uo / vi given): the stored weight is w / (uo[outer] * vi[inner]) — the kernel works on panel rows scaled by
-// vi and scales a vector's sum by uo at the end; the unit positions (count 1: quotient 1) are not read at all.
+// pw[rec] = the map chain at the record's (count, outer, inner), 0 for an unused position. One work-item per position that
+// carries a weight: all 64 of a record row, or — unit mode (uo / vi given) — the lanes behind the `skip` unit positions
+// (never read: no weight). Every such position is written, used or not: whole cache lines leave the CU (with the unused
+// ones skipped the partial-line stores cost twice the HBM traffic of the full ones). nset * 64 is a power of two and
+// (group, visit) pairs fit 32 bits (checked by the builder).
+// Unit mode: the stored weight is w / (uo[outer] * vi[inner]) — the kernel works on panel rows scaled by vi and scales a
+// vector's sum by uo at the end.
 __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t *__restrict__ prow, const uint8_t *__restrict__ pcnt,
                                                            double *__restrict__ pw, uint64_t n_rec, uint64_t n_outer, TileShape sh, DevMap map,
-                                                           const double *__restrict__ uo, const double *__restrict__ vi) {
+                                                           const double *__restrict__ uo, const double *__restrict__ vi, uint32_t skip) {
+    const uint32_t per_row = 64u - skip; // 64 or 32 (K = 2, one unit position)
+    const uint64_t n_work = (n_rec >> 6) * per_row;
     // grid-stride: a launch holds fewer than 2^32 work-items (the dispatch packet's grid size is 32 bits), a layout more records
-    for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_rec; e += (uint64_t)gridDim.x * blockDim.x) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_work; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t sv64 = per_row == 64u ? (i >> 6) : (i >> 5);
+        const uint32_t lane = skip + (uint32_t)(i & (per_row - 1u));
+        const uint64_t e = (sv64 << 6) + lane;
         const uint32_t cnt = pcnt[e];
-        if (cnt == 0) continue; // an unused position keeps the weight 0 it was built with
-        if (uo && ((uint32_t)(e & 63u) / sh.sps) < sh.KU) continue; // unit mode: the unit positions carry no weight (never read)
-        const uint32_t lane = (uint32_t)(e & 63u);
-        const uint32_t sv = (uint32_t)(e >> 6);
-        const uint32_t b = sh.nset == 1 ? 0u : (sv & (sh.nset - 1u));
-        const uint32_t gv = sh.nset == 1 ? sv : sv / sh.nset;
-        const uint32_t g = gv / sh.nt, v = gv - g * sh.nt;
-        const uint64_t o = (uint64_t)g * sh.S + b * sh.sps + lane % sh.sps;
-        const uint32_t code = prow[e];
-        const uint32_t bufi = code / sh.T, r = code - bufi * sh.T;
-        const uint32_t d = (v % sh.B + sh.B - bufi) % sh.B; // visits the nonzero waited
-        const uint32_t inner = (v - d) * sh.T + r;
-        double w = eval_map(map, cnt, (uint32_t)o, inner);
-        if (uo) {
-            const double d2 = uo[o] * vi[inner];
-            w = (d2 != 0.0 && isfinite(d2)) ? w / d2 : 0.0; // a zero unit weight means a zero weight for every count (log1p, square, scale)
+        double w = 0.0;
+        if (cnt) {
+            const uint32_t sv = (uint32_t)sv64;
+            const uint32_t b = sh.nset == 1 ? 0u : (sv & (sh.nset - 1u));
+            const uint32_t gv = sh.nset == 1 ? sv : sv / sh.nset;
+            const uint32_t g = gv / sh.nt, v = gv - g * sh.nt;
+            const uint64_t o = (uint64_t)g * sh.S + b * sh.sps + lane % sh.sps;
+            const uint32_t code = prow[e];
+            const uint32_t bufi = code / sh.T, r = code - bufi * sh.T;
+            const uint32_t d = (v % sh.B + sh.B - bufi) % sh.B; // visits the nonzero waited
+            const uint32_t inner = (v - d) * sh.T + r;
+            w = eval_map(map, cnt, (uint32_t)o, inner);
+            if (uo) {
+                const double d2 = uo[o] * vi[inner];
+                w = (d2 != 0.0 && isfinite(d2)) ? w / d2 : 0.0; // a zero unit weight means a zero weight for every count (log1p, square, scale)
+            }
         }
         pw[e] = w;
     }
@@ -394,9 +402,13 @@ static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &c
         hipLaunchKernelGGL(tile_unit_factor_kernel, dim3((unsigned)((cp.n_outer + 255) / 256)), dim3(256), 0, st.stream, map, 1, nl_outer, cp.n_outer, tl.uo.p);
         hipLaunchKernelGGL(tile_unit_factor_kernel, dim3((unsigned)((cp.n_inner + 255) / 256)), dim3(256), 0, st.stream, map, 0, nl_outer, cp.n_inner, tl.vi.p);
     }
-    if (n_rec)
-        hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)std::min<uint64_t>((n_rec + 255) / 256, 1u << 23)), dim3(256), 0, st.stream, tl.prow.p, tl.pcnt.p, tl.pw.p, n_rec,
-                           cp.n_outer, tl.sh, map, tl.unit_mode ? tl.uo.p : (const double *)nullptr, tl.unit_mode ? tl.vi.p : (const double *)nullptr);
+    if (n_rec) {
+        // the unit positions are lanes [0, KU sps) of a record row; the lanes behind them must be a power of two for the kernel's index split
+        const uint32_t skip = tl.unit_mode && tl.sh.KU * tl.sh.sps == 32u ? 32u : 0u;
+        const uint64_t n_work = (n_rec >> 6) * (64u - skip);
+        hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)std::min<uint64_t>((n_work + 255) / 256, 1u << 23)), dim3(256), 0, st.stream, tl.prow.p, tl.pcnt.p, tl.pw.p, n_rec,
+                           cp.n_outer, tl.sh, map, tl.unit_mode ? tl.uo.p : (const double *)nullptr, tl.unit_mode ? tl.vi.p : (const double *)nullptr, skip);
+    }
     if (tl.ov.nnz) materialize_map_values(st, tl.ov, map, tl.ov.fvals.p);
     SCANRS_HIP(hipGetLastError());
     if (trace_on()) (void)hipStreamSynchronize(st.stream);
@@ -515,7 +527,9 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
 
         for (uint32_t t = t0; t < t1; t++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's LDS-DMA chunks of tile t (the compiler does not see them)
+#ifndef TL_EXPERIMENT_NO_BARRIER // timing experiment only (wrong results): what the barrier per visit costs
             __syncthreads(); // tile t is in the ring; everyone is done with visit t - 1, so the buffer of tile t + 1 - B is free
+#endif
             bufn = bufn + 1u == nbuf ? 0u : bufn + 1u;
             const uint32_t tr = t + 1 < t1 ? t + 1 : t; // the last visit of an item re-loads its own records: no branch in the loop
             // the next visit's records: nothing in this visit waits for them

@@ -914,6 +914,83 @@ def test_components_beyond_the_numerical_rank(sa):
     assert abs(s2[6] - ex2[6]) < 1e-8 * ex2[6]
 
 
+def test_device_cholesky_factor_step(sa):
+    """chol_rinv_kernel (one workgroup, matrix in LDS) against numpy and the host helpers: SPD matrices of every size class,
+    the stopping rule of pass >= 1, the shift rule on a singular Gram matrix, non-finite input."""
+    rng = np.random.default_rng(5)
+    g0, _ = pair(sa, random_counts(rng, 20, 30, 0.3, 5), so.CSR)
+    for n in (1, 2, 7, 16, 17, 64, 100, 127, 128):
+        x = rng.standard_normal((4 * n + 8, n))
+        g = x.T @ x
+        rinv, done, status, err, shift = g0.chol_rinv(g, x.shape[0])
+        assert (done, status, shift) == (0, 0, 0.0) and abs(err - np.max(np.abs(g - np.eye(n)))) < 1e-12 * max(1.0, err)
+        assert np.allclose(np.tril(rinv, -1), 0.0)
+        r = np.linalg.cholesky(g).T
+        assert np.max(np.abs(rinv @ r - np.eye(n))) < 1e-9 * np.linalg.cond(r)
+        q = x @ rinv  # the panel CholeskyQR would produce
+        assert np.max(np.abs(q.T @ q - np.eye(n))) < 1e-10 * np.linalg.cond(g)
+        assert np.max(np.abs(rinv - sa.host_inv_upper(sa.host_chol_upper(g)))) < 1e-10 * np.max(np.abs(rinv)) * np.linalg.cond(r)
+    # pass >= 1 on an orthonormal panel's Gram matrix: converged, identity out
+    n = 50
+    g = np.eye(n) + 1e-15 * rng.standard_normal((n, n))
+    rinv, done, status, err, _ = g0.chol_rinv((g + g.T) / 2, 1000, pass_no=1)
+    assert (done, status) == (1, 0) and np.array_equal(rinv, np.eye(n)) and err < 1e-14
+    rinv, done, status, _, _ = g0.chol_rinv((g + g.T) / 2, 1000, pass_no=0)  # pass 0 always applies
+    assert (done, status) == (0, 0) and np.max(np.abs(rinv - np.eye(n))) < 1e-13
+    # singular Gram matrix: shifted Cholesky (orth_cholqr's rule)
+    x = rng.standard_normal((300, 6))
+    x = np.hstack([x, x[:, :3] * 2.0])
+    g = x.T @ x
+    rinv, done, status, _, shift = g0.chol_rinv(g, 300)
+    assert (done, status) == (0, 0) and shift > 0.0 and np.all(np.isfinite(rinv))
+    g[2, 3] = np.nan
+    rinv, done, status, _, _ = g0.chol_rinv(g, 300)
+    assert (done, status) == (1, 2) and np.array_equal(rinv, np.eye(9))
+    g = -np.eye(4)  # no shift rescues a negative definite matrix (dmax <= 0)
+    rinv, done, status, _, _ = g0.chol_rinv(g, 300)
+    assert (done, status) == (1, 1)
+
+
+def test_device_side_factorizations_match_the_host_path(sa):
+    """svd_bk with the CholeskyQR factors and the coefficient bookkeeping on the device (chol_rinv_kernel, no host round trip
+    per orthonormalisation: the default) against the same call with host factorizations ("device_factor" 0) and the oracle —
+    tall, wide, normalized, k_multiplier / n_iter variations; and a matrix whose Krylov panels are ill-conditioned beyond two passes, which the
+    device path hands back to the host path by itself (bk_svd.rs:94,98,123,127)."""
+    rng = np.random.default_rng(41)
+    cases = [((400, 900), 0.08, 12, (2.0, 5)), ((900, 300), 0.1, 10, (2.0, 3)), ((250, 700), 0.15, 7, (3.0, 4)), ((600, 600), 0.05, 20, (2.0, 5))]
+    for (shape, dens, k, (km, ni)) in cases:
+        dense = random_counts(rng, shape[0], shape[1], dens, 30)
+        for norm in (None, sa.Normalization.CellRanger):
+            res = {}
+            for dev in (1, 0):
+                g, o = pair(sa, dense, so.CSC)
+                if norm is not None:
+                    g = sa.normalize(g, norm)
+                g.set_option("device_factor", dev)
+                res[dev] = sa.BkSvd(km, ni).run_pca(g, k)
+            (u1, s1, v1), (u0, s0, v0) = res[1], res[0]
+            assert np.max(np.abs(s1 - s0) / s0[0]) < 1e-11, (shape, norm)
+            assert np.max(np.abs(_sign_fix(u1, u0) - u0)) < 1e-7 and np.max(np.abs(_sign_fix(v1, v0) - v0)) < 1e-7
+            assert np.max(np.abs(u1.T @ u1 - np.eye(k))) < 1e-12 and np.max(np.abs(v1.T @ v1 - np.eye(k))) < 1e-12
+            if norm is None:
+                exact = np.linalg.svd(dense.astype(np.float64), compute_uv=False)[:k]
+                assert abs(s1[0] - exact[0]) / exact[0] < 1e-6  # the leading value is separated; the rest converge with more iterations
+    # six huge singular values over a floor of ~1: the Krylov panels have a condition number near 1e9, their Gram matrices are
+    # numerically singular -> shifted Cholesky, which needs more passes than the device path queues -> the call is handed to the
+    # host path by itself (counter), and the answer is the host path's
+    base = random_counts(rng, 6, 300, 0.5, 5000)
+    dense = np.vstack([base] * 40) + (rng.random((240, 300)) < 0.01).astype(np.uint32)
+    res = {}
+    for dev in (1, 0):
+        g, _ = pair(sa, dense, so.CSR)
+        g.set_option("device_factor", dev)
+        res[dev] = sa.BkSvd().run_pca(g, 10)
+        assert g.counter("bk_host_retries") == (1 if dev else 0)
+    assert np.array_equal(res[1][1], res[0][1])
+    exact = np.linalg.svd(dense.astype(np.float64), compute_uv=False)
+    assert np.max(np.abs(res[1][1][:6] - exact[:6]) / exact[:6]) < 1e-10
+
+
 def test_irlba_rejects_zero_iterations(sa):
     g, _ = pair(sa, random_counts(np.random.default_rng(0), 30, 40, 0.5, 9), so.CSR)
     with pytest.raises(sa.ScanrsError) as e:
