@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstdarg>
+#include <functional>
 #include <map>
 #include <set>
 #include <memory>

@@ -325,15 +325,19 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const double *__restri
 //   info[0] = max |G - I| of this pass, info[1] = shift used
 // check_only: the last queued pass only tests convergence.
 constexpr uint32_t CHOL_NMAX = 128;
-constexpr int CHOL_E = CHOL_NMAX / 16; // entries per thread and dimension: thread (ty, tx) of 16 x 16 owns (ty + 16 a, tx + 16 b)
-// The matrix lives in REGISTERS (cyclic 16 x 16 distribution, 8 x 8 entries per thread, compile-time indices); a step
+constexpr uint32_t CHOL_TD = 32;              // threads per dimension: 32 x 32 = 1024 threads, 16 waves (4 per SIMD)
+constexpr int CHOL_E = CHOL_NMAX / CHOL_TD;    // entries per thread and dimension: thread (ty, tx) owns (ty + 32 a, tx + 32 b)
+// The matrix lives in REGISTERS (cyclic 32 x 32 distribution, 4 x 4 entries per thread, compile-time indices); a step
 // broadcasts one row (and, for the inverse, one column) through LDS and every thread applies the rank-1 update to its own
-// entries: two barriers and ~130 instructions per step, ~25 us for n = 100 (an LDS-resident version with per-entry
-// read-modify-write loops ran 290 us, bound by LDS latency).
-__global__ __launch_bounds__(256) void chol_rinv_kernel(const double *__restrict__ G, uint32_t n, double rows, int pass, int check_only,
+// entries: two barriers and a few dozen instructions per step. (An LDS-resident version with per-entry read-modify-write
+// loops ran 290 us at n = 100, bound by LDS latency; 256 threads with 8 x 8 entries each ran as long — one wave per SIMD
+// issues its ~500 instructions per step back to back.)
+__global__ __launch_bounds__(1024) void chol_rinv_kernel(const double *__restrict__ G, uint32_t n, double rows, int pass, int check_only,
                                                         int *__restrict__ ctl, double *__restrict__ Rinv, double *__restrict__ info) {
-    __shared__ double rowbuf[CHOL_NMAX], colbuf[CHOL_NMAX], red[3 * 256];
-    const uint32_t tid = threadIdx.x, nt = blockDim.x, ty = tid >> 4, tx = tid & 15u;
+    __shared__ double rowbuf[CHOL_NMAX], colbuf[CHOL_NMAX], red[3 * 1024];
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, ty = tid / CHOL_TD, tx = tid % CHOL_TD;
+    // rows of this wave in row block a: wy0 + 32 a and wy0 + 1 + 32 a (a wave is two rows of the thread grid) — uniform tests skip whole blocks
+    const uint32_t wy0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * (64u / CHOL_TD);
     auto identity_out = [&]() {
         if (check_only) return;
         for (uint32_t e = tid; e < n * n; e += nt) Rinv[e] = (e / n == e % n) ? 1.0 : 0.0;
@@ -390,18 +394,18 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double *__restrict
         for (int a = 0; a < CHOL_E; a++)
 #pragma unroll
             for (int b = 0; b < CHOL_E; b++) {
-                const uint32_t i = ty + 16u * a, j = tx + 16u * b;
+                const uint32_t i = ty + CHOL_TD * a, j = tx + CHOL_TD * b;
                 A[a][b] = (i < n && j < n && j >= i) ? G[i * n + j] + (i == j ? shift : 0.0) : 0.0;
             }
         // G (+ shift I) = R^T R, right-looking: an entry (i, j) loses r_ki r_kj for k = 0, 1, ... — the order of chol_upper's row loop
         bool failed = false;
         for (uint32_t k = 0; k < n; k++) {
-            const uint32_t ka = k >> 4, kt = k & 15u;
+            const uint32_t ka = k / CHOL_TD, kt = k % CHOL_TD;
 #pragma unroll
             for (int a = 0; a < CHOL_E; a++)
                 if ((uint32_t)a == ka && ty == kt) {
 #pragma unroll
-                    for (int b = 0; b < CHOL_E; b++) rowbuf[tx + 16u * b] = A[a][b]; // row k as it stands (entries left of the diagonal are zeros)
+                    for (int b = 0; b < CHOL_E; b++) rowbuf[tx + CHOL_TD * b] = A[a][b]; // row k as it stands (entries left of the diagonal are zeros)
                 }
             __syncthreads();
             const double d = rowbuf[k];
@@ -412,16 +416,16 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double *__restrict
             const double sq = sqrt(d), inv = 1.0 / sq;
             double g[CHOL_E], f[CHOL_E];
 #pragma unroll
-            for (int b = 0; b < CHOL_E; b++) g[b] = rowbuf[tx + 16u * b] * inv;
+            for (int b = 0; b < CHOL_E; b++) g[b] = rowbuf[tx + CHOL_TD * b] * inv;
 #pragma unroll
-            for (int a = 0; a < CHOL_E; a++) f[a] = rowbuf[ty + 16u * a] * inv;
+            for (int a = 0; a < CHOL_E; a++) f[a] = rowbuf[ty + CHOL_TD * a] * inv;
 #pragma unroll
             for (int a = 0; a < CHOL_E; a++) {
-                if (16u * a + 15u < k) continue; // uniform: every row of this block is finished
-                const uint32_t i = ty + 16u * a;
+                if (wy0 + 64u / CHOL_TD - 1u + CHOL_TD * a < k) continue; // uniform: every row this wave holds in the block is finished
+                const uint32_t i = ty + CHOL_TD * a;
 #pragma unroll
                 for (int b = a; b < CHOL_E; b++) { // blocks left of the diagonal block hold no entry with j >= i
-                    const uint32_t j = tx + 16u * b;
+                    const uint32_t j = tx + CHOL_TD * b;
                     if (i == k)
                         A[a][b] = j == k ? sq : (j > k ? g[b] : 0.0);
                     else if (i > k && j >= i)
@@ -446,12 +450,12 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double *__restrict
     // X = R^-1 in place, rows bottom-up: row m of X is final once rows > m are; it then enters the sums of every row k < m:
     // S[k][j] += r_km x_mj (j >= m). S[k][j] takes the register of r_kj, which was consumed at step j.
     for (int m = (int)n - 1; m >= 0; m--) {
-        const uint32_t ma = (uint32_t)m >> 4, mt = (uint32_t)m & 15u;
+        const uint32_t ma = (uint32_t)m / CHOL_TD, mt = (uint32_t)m % CHOL_TD;
 #pragma unroll
         for (int b = 0; b < CHOL_E; b++)
             if ((uint32_t)b == ma && tx == mt) {
 #pragma unroll
-                for (int a = 0; a < CHOL_E; a++) colbuf[ty + 16u * a] = A[a][b]; // column m of R (rows < m are used)
+                for (int a = 0; a < CHOL_E; a++) colbuf[ty + CHOL_TD * a] = A[a][b]; // column m of R (rows < m are used)
             }
         __syncthreads();
         const double invd = 1.0 / colbuf[m];
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double *__restrict
             if ((uint32_t)a == ma && ty == mt) {
 #pragma unroll
                 for (int b = 0; b < CHOL_E; b++) {
-                    const uint32_t j = tx + 16u * b;
+                    const uint32_t j = tx + CHOL_TD * b;
                     const double x = j == (uint32_t)m ? invd : (j > (uint32_t)m ? -A[a][b] * invd : 0.0);
                     A[a][b] = x;
                     rowbuf[j] = x;
@@ -469,17 +473,17 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double *__restrict
         __syncthreads();
         double cf[CHOL_E], xr[CHOL_E];
 #pragma unroll
-        for (int a = 0; a < CHOL_E; a++) cf[a] = colbuf[ty + 16u * a];
+        for (int a = 0; a < CHOL_E; a++) cf[a] = colbuf[ty + CHOL_TD * a];
 #pragma unroll
-        for (int b = 0; b < CHOL_E; b++) xr[b] = rowbuf[tx + 16u * b];
+        for (int b = 0; b < CHOL_E; b++) xr[b] = rowbuf[tx + CHOL_TD * b];
 #pragma unroll
         for (int a = 0; a < CHOL_E; a++) {
-            if (16u * a > (uint32_t)m) continue; // uniform: no row of this block is above row m
-            const uint32_t k = ty + 16u * a;
+            if (wy0 + CHOL_TD * a >= (uint32_t)m) continue; // uniform: no row this wave holds in the block is above row m
+            const uint32_t k = ty + CHOL_TD * a;
 #pragma unroll
             for (int b = a; b < CHOL_E; b++) {
-                if (16u * b + 15u < (uint32_t)m) continue; // uniform: every column of this block is left of column m
-                const uint32_t j = tx + 16u * b;
+                if (CHOL_TD * b + CHOL_TD - 1u < (uint32_t)m) continue; // uniform: every column of this block is left of column m
+                const uint32_t j = tx + CHOL_TD * b;
                 if (k < (uint32_t)m && j >= (uint32_t)m) A[a][b] = j == (uint32_t)m ? cf[a] * xr[b] : fma(cf[a], xr[b], A[a][b]);
             }
         }
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(256) void chol_rinv_kernel(const double *__restrict
     for (int a = 0; a < CHOL_E; a++)
 #pragma unroll
         for (int b = 0; b < CHOL_E; b++) {
-            const uint32_t i = ty + 16u * a, j = tx + 16u * b;
+            const uint32_t i = ty + CHOL_TD * a, j = tx + CHOL_TD * b;
             if (i < n && j < n) Rinv[i * n + j] = j >= i ? A[a][b] : 0.0;
         }
 }
@@ -498,7 +502,7 @@ bool chol_rinv_ok(uint32_t n) { return n >= 1 && n <= CHOL_NMAX; }
 void launch_chol_rinv(Storage &st, const double *G, uint32_t n, uint64_t rows, int pass, bool check_only, int *ctl, double *Rinv, double *info) {
     if (!chol_rinv_ok(n)) fail(SCANRS_ERR_ARGUMENT, "device Cholesky: n out of range");
     if (st.prof.on) st.prof.begin(st.stream, "chol_rinv", (double)n * n * 16.0);
-    hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(256), 0, st.stream, G, n, (double)rows, pass, check_only ? 1 : 0, ctl, Rinv, info);
+    hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(1024), 0, st.stream, G, n, (double)rows, pass, check_only ? 1 : 0, ctl, Rinv, info);
     if (st.prof.on) st.prof.end(st.stream);
     SCANRS_HIP(hipGetLastError());
 }

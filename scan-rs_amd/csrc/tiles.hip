@@ -174,6 +174,13 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t *__res
                                                            const double *__restrict__ uo, const double *__restrict__ vi, uint32_t skip) {
     const uint32_t per_row = 64u - skip; // 64 or 32 (K = 2, one unit position)
     const uint64_t n_work = (n_rec >> 6) * per_row;
+    // The index arithmetic below would be five integer divisions per position (~25 VALU instructions each — as much as the
+    // logarithm and the division of the weight together): quotients through a rounded-down product with the reciprocal
+    // instead. floor((x + 0.5) * (1 / d)) is exact as long as the rounding error stays below the 0.5 / d margin: single
+    // precision for x < 2^16, double for the 32-bit (group, visit) index (x / d < 2^22, d < 2^22: error 2^-30 against 2^-23).
+    const float inv_T = 1.0f / (float)sh.T, inv_sps = 1.0f / (float)sh.sps;
+    const double inv_nt = 1.0 / (double)sh.nt;
+    const uint32_t nset_shift = 31u - (uint32_t)__clz((int)sh.nset);
     // grid-stride: a launch holds fewer than 2^32 work-items (the dispatch packet's grid size is 32 bits), a layout more records
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_work; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t sv64 = per_row == 64u ? (i >> 6) : (i >> 5);
@@ -183,13 +190,15 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t *__res
         double w = 0.0;
         if (cnt) {
             const uint32_t sv = (uint32_t)sv64;
-            const uint32_t b = sh.nset == 1 ? 0u : (sv & (sh.nset - 1u));
-            const uint32_t gv = sh.nset == 1 ? sv : sv / sh.nset;
-            const uint32_t g = gv / sh.nt, v = gv - g * sh.nt;
-            const uint64_t o = (uint64_t)g * sh.S + b * sh.sps + lane % sh.sps;
+            const uint32_t b = sv & (sh.nset - 1u);
+            const uint32_t gv = sv >> nset_shift;
+            const uint32_t g = (uint32_t)(((double)gv + 0.5) * inv_nt), v = gv - g * sh.nt;
+            const uint32_t qs = (uint32_t)(((float)lane + 0.5f) * inv_sps);
+            const uint64_t o = (uint64_t)g * sh.S + b * sh.sps + (lane - qs * sh.sps);
             const uint32_t code = prow[e];
-            const uint32_t bufi = code / sh.T, r = code - bufi * sh.T;
-            const uint32_t d = (v % sh.B + sh.B - bufi) % sh.B; // visits the nonzero waited
+            const uint32_t bufi = (uint32_t)(((float)code + 0.5f) * inv_T), r = code - bufi * sh.T;
+            const uint32_t vmod = sh.B == 4u ? (v & 3u) : v % sh.B; // the default ring has 4 buffers
+            const uint32_t d = vmod >= bufi ? vmod - bufi : vmod + sh.B - bufi; // visits the nonzero waited
             const uint32_t inner = (v - d) * sh.T + r;
             w = eval_map(map, cnt, (uint32_t)o, inner);
             if (uo) {
