@@ -40,6 +40,7 @@ constexpr uint32_t TL_NW = 8;          // waves per workgroup (2 per SIMD)
 constexpr uint32_t TL_LMAX = 104;      // widest panel: 192 ring rows x 104 x 8 B = 159744 B of LDS
 constexpr uint32_t TL_LDS = 160u << 10;
 constexpr int TL_W = 6;                // LDS row reads in flight per wave
+constexpr uint32_t TL_TABC = 16;       // unit mode: counts 1 .. 16 take their weight from the per-position quotient table
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef __attribute__((address_space(3))) const char *lds_cptr_t;
@@ -47,6 +48,12 @@ typedef __attribute__((address_space(3))) const char *lds_cptr_t;
 struct TileShape {
     uint32_t T, B, K, KU, S, sps, nset, nt, n_parts, tpp; // KU of the K positions of a (slot, visit) pair are "unit" positions
 };
+
+static inline dim3 grid_1d(uint64_t n) { // one work-item per element; a dispatch holds fewer than 2^32 of them
+    const uint64_t blocks = (n + 255) / 256;
+    if (blocks * 256 >= (1ull << 32)) fail(SCANRS_ERR_DEVICE, "a per-element launch over %llu elements exceeds the 2^32 work-items of one dispatch", (unsigned long long)n);
+    return dim3((unsigned)blocks);
+}
 
 // ---- builder -------------------------------------------------------------------------------------------------------
 // One thread per (outer vector, part): walks the part's nonzeros in order and deals them to visits first come first served.
@@ -171,9 +178,9 @@ __global__ void tile_init_rows_kernel(uint16_t *__restrict__ prow, uint64_t n_re
 // vector's sum by uo at the end.
 __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t *__restrict__ prow, const uint8_t *__restrict__ pcnt,
                                                            double *__restrict__ pw, uint64_t n_rec, uint64_t n_outer, TileShape sh, DevMap map,
-                                                           const double *__restrict__ uo, const double *__restrict__ vi, uint32_t skip) {
+                                                           const double *__restrict__ uo, const double *__restrict__ vi, uint32_t skip,
+                                                           const double *__restrict__ tab, int tab_outer) {
     const uint32_t per_row = 64u - skip; // 64 or 32 (K = 2, one unit position)
-    const uint64_t n_work = (n_rec >> 6) * per_row;
     // The index arithmetic below would be five integer divisions per position (~25 VALU instructions each — as much as the
     // logarithm and the division of the weight together): quotients through a rounded-down product with the reciprocal
     // instead. floor((x + 0.5) * (1 / d)) is exact as long as the rounding error stays below the 0.5 / d margin: single
@@ -181,32 +188,55 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t *__res
     const float inv_T = 1.0f / (float)sh.T, inv_sps = 1.0f / (float)sh.sps;
     const double inv_nt = 1.0 / (double)sh.nt;
     const uint32_t nset_shift = 31u - (uint32_t)__clz((int)sh.nset);
-    // grid-stride: a launch holds fewer than 2^32 work-items (the dispatch packet's grid size is 32 bits), a layout more records
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_work; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t sv64 = per_row == 64u ? (i >> 6) : (i >> 5);
+    // A thread works the same lane of WU consecutive record rows at a time: their counts and row codes are loaded first, then
+    // the table lookups, then the stores — one position per trip made the pass a chain of three dependent loads per store
+    // (1.5 TB/s). Grid-stride: a launch holds fewer than 2^32 work-items, a layout more records.
+    constexpr int WU = 4;
+    const uint64_t n_rows = n_rec >> 6, n_quads = (n_rows + WU - 1) / WU;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_quads * per_row; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t q4 = per_row == 64u ? (i >> 6) : (i >> 5);
         const uint32_t lane = skip + (uint32_t)(i & (per_row - 1u));
-        const uint64_t e = (sv64 << 6) + lane;
-        const uint32_t cnt = pcnt[e];
-        double w = 0.0;
-        if (cnt) {
-            const uint32_t sv = (uint32_t)sv64;
+        const uint32_t qs = (uint32_t)(((float)lane + 0.5f) * inv_sps);
+        const uint32_t slot = lane - qs * sh.sps;
+        uint32_t cnt[WU], code[WU];
+        bool ok[WU];
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+            const uint64_t sv64 = q4 * WU + u;
+            ok[u] = sv64 < n_rows;
+            const uint64_t e = ((ok[u] ? sv64 : n_rows - 1) << 6) + lane;
+            cnt[u] = ok[u] ? pcnt[e] : 0u; // a row past the end has no positions
+            code[u] = prow[e];
+        }
+        double w[WU];
+        uint32_t oo[WU], in[WU];
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+            const uint32_t sv = (uint32_t)(q4 * WU + u);
             const uint32_t b = sv & (sh.nset - 1u);
             const uint32_t gv = sv >> nset_shift;
             const uint32_t g = (uint32_t)(((double)gv + 0.5) * inv_nt), v = gv - g * sh.nt;
-            const uint32_t qs = (uint32_t)(((float)lane + 0.5f) * inv_sps);
-            const uint64_t o = (uint64_t)g * sh.S + b * sh.sps + (lane - qs * sh.sps);
-            const uint32_t code = prow[e];
-            const uint32_t bufi = (uint32_t)(((float)code + 0.5f) * inv_T), r = code - bufi * sh.T;
+            oo[u] = g * sh.S + b * sh.sps + slot; // outer positions fit 32 bits (the map's arrays are indexed by 32-bit positions)
+            const uint32_t bufi = (uint32_t)(((float)code[u] + 0.5f) * inv_T), r = code[u] - bufi * sh.T;
             const uint32_t vmod = sh.B == 4u ? (v & 3u) : v % sh.B; // the default ring has 4 buffers
             const uint32_t d = vmod >= bufi ? vmod - bufi : vmod + sh.B - bufi; // visits the nonzero waited
-            const uint32_t inner = (v - d) * sh.T + r;
-            w = eval_map(map, cnt, (uint32_t)o, inner);
-            if (uo) {
-                const double d2 = uo[o] * vi[inner];
-                w = (d2 != 0.0 && isfinite(d2)) ? w / d2 : 0.0; // a zero unit weight means a zero weight for every count (log1p, square, scale)
-            }
+            in[u] = (v - d) * sh.T + r;
+            w[u] = 0.0;
+            if (tab && cnt[u] != 0u && cnt[u] <= TL_TABC) // unit mode: the quotient depends on the count and on one side's position only (tile_ratio_table_kernel)
+                w[u] = tab[(size_t)(tab_outer ? oo[u] : in[u]) * TL_TABC + (cnt[u] - 1u)];
         }
-        pw[e] = w;
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+            if (cnt[u] != 0u && !(tab && cnt[u] <= TL_TABC)) {
+                double x = eval_map(map, cnt[u], oo[u], in[u]);
+                if (uo) {
+                    const double d2 = uo[oo[u]] * vi[in[u]];
+                    x = (d2 != 0.0 && isfinite(d2)) ? x / d2 : 0.0; // a zero unit weight means a zero weight for every count (log1p, square, scale)
+                }
+                w[u] = x;
+            }
+            if (ok[u]) pw[((q4 * WU + u) << 6) + lane] = w[u];
+        }
     }
 }
 
@@ -243,6 +273,47 @@ __global__ void tile_unit_factor_kernel(DevMap map, int side_outer, int nl_outer
     out[idx] = x;
 }
 
+// Unit mode: the stored weight of a general position, f(c, o, i) / (uo[o] vi[i]), is N(c a) / N(a) with a = the scales in
+// front of the nonlinear links — all on ONE side for a separable chain — and N those links; every scale behind them cancels.
+// It therefore depends on the count and on that side's position only, and 60 % of the counts above 1 are 2, 95 % at most 4:
+// a table of the quotient for counts 1 .. 16 per position of that side (16 logarithms per cell instead of one per nonzero
+// per orientation: 1.6e7 against 5.6e8 at 10^6 cells) turns the weight refresh into a streaming pass with a cached lookup.
+// G(c) = the chain on x = c with the other side's links left out; tab[idx][c - 1] = G(c) / G(1).
+__global__ void tile_ratio_table_kernel(DevMap map, int nl_outer, uint64_t n, double *__restrict__ tab) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * TL_TABC) return;
+    const uint64_t idx = e / TL_TABC;
+    const uint32_t c = (uint32_t)(e - idx * TL_TABC) + 1u;
+    double g[2];
+    for (int which = 0; which < 2; which++) {
+        double x = which ? (double)c : 1.0;
+        for (int i = 0; i < map.n; i++) {
+            const DevOp &op = map.ops[i];
+            switch (op.kind) {
+            case OP_SCALE_AXIS:
+                if ((op.a_outer != 0) == (nl_outer != 0)) x = op.a[idx] * x;
+                break;
+            case OP_LN_1P:
+                x = map_ln(x + 1.0);
+                break;
+            case OP_LOG2_1P:
+                x = map_log2(x + 1.0);
+                break;
+            case OP_LOG10_1P:
+                x = map_log10(x + 1.0);
+                break;
+            case OP_SQUARE:
+                x = x * x;
+                break;
+            default:
+                break;
+            }
+        }
+        g[which] = x;
+    }
+    tab[e] = (g[0] != 0.0 && isfinite(g[0])) ? g[1] / g[0] : 0.0;
+}
+
 // Xc[r, 0:l] = vi[r] * X[r, 0:l] in compact rows of ldc columns (the panel the unit-mode kernel stages)
 __global__ void tile_scale_panel_kernel(const double *__restrict__ X, uint32_t ldx, uint64_t rows, uint32_t l, uint32_t ldc,
                                         const double *__restrict__ vi, double *__restrict__ Xc) {
@@ -273,11 +344,12 @@ struct TileLayout {
     // unit mode (sh.KU > 0 and a separable map): per-outer / per-inner factors of the weight of a count-1 nonzero
     bool unit_mode = false;
     DevBuf<double> uo, vi;
+    DevBuf<double> ratio_tab; // unit mode: quotient of the weight of counts 1 .. TL_TABC per position of the side that owns the nonlinear links
     // identity of the map the weights were evaluated under (MapOp ids are never reused); -1: none yet
     int sig_n = -1;
     uint32_t sig_id[MAX_OPS] = {};
     int sig_outer[MAX_OPS] = {};
-    double bytes() const { return (double)prow.n * 2.0 + (double)pcnt.n + (double)pw.n * 8.0 + (double)ov.nnz * 16.0; }
+    double bytes() const { return (double)prow.n * 2.0 + (double)pcnt.n + (double)pw.n * 8.0 + (double)ov.nnz * 16.0 + (double)ratio_tab.n * 8.0; }
     bool structure_matches(const Storage &st) const {
         return sh.K == st.tile_k && sh.S == st.tile_s && sh.T == st.tile_t && sh.B == st.tile_b && sh.KU == (st.tile_k == 2u && st.tile_ku ? 1u : 0u);
     }
@@ -387,12 +459,20 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
 // Is f(1, outer, inner) a product of an outer and an inner factor? Yes when the links in front of the first nonlinear link
 // (log, square) index one side only and no binomial residual link takes part; nl_outer = the side that owns them.
 static bool tile_map_separable(const DevMap &map, int &nl_outer) {
-    bool nonlinear = false, pre_outer = false, pre_inner = false;
+    bool nonlinear = false, pre_outer = false, pre_inner = false, post_scale = false;
     for (int i = 0; i < map.n; i++) {
         const int k = map.ops[i].kind;
         if (k == OP_BINOM_DEV || k == OP_BINOM_PEARSON) return false;
-        if (k == OP_LN_1P || k == OP_LOG2_1P || k == OP_LOG10_1P || k == OP_SQUARE) nonlinear = true;
-        if (k == OP_SCALE_AXIS && !nonlinear) (map.ops[i].a_outer ? pre_outer : pre_inner) = true;
+        if (k == OP_LN_1P || k == OP_LOG2_1P || k == OP_LOG10_1P || k == OP_SQUARE) {
+            if (post_scale) return false; // a scale between two nonlinear links does not factor out of the second one
+            nonlinear = true;
+        }
+        if (k == OP_SCALE_AXIS) {
+            if (!nonlinear)
+                (map.ops[i].a_outer ? pre_outer : pre_inner) = true;
+            else
+                post_scale = true;
+        }
     }
     if (nonlinear && pre_outer && pre_inner) return false;
     nl_outer = pre_inner ? 0 : 1;
@@ -410,13 +490,17 @@ static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &c
         if (tl.vi.n != cp.n_inner) tl.vi.alloc(std::max<uint64_t>(cp.n_inner, 1));
         hipLaunchKernelGGL(tile_unit_factor_kernel, dim3((unsigned)((cp.n_outer + 255) / 256)), dim3(256), 0, st.stream, map, 1, nl_outer, cp.n_outer, tl.uo.p);
         hipLaunchKernelGGL(tile_unit_factor_kernel, dim3((unsigned)((cp.n_inner + 255) / 256)), dim3(256), 0, st.stream, map, 0, nl_outer, cp.n_inner, tl.vi.p);
+        const uint64_t n_side = nl_outer ? cp.n_outer : cp.n_inner;
+        if (tl.ratio_tab.n != n_side * TL_TABC) tl.ratio_tab.alloc(std::max<uint64_t>(n_side * TL_TABC, 1));
+        hipLaunchKernelGGL(tile_ratio_table_kernel, grid_1d(n_side * TL_TABC), dim3(256), 0, st.stream, map, nl_outer, n_side, tl.ratio_tab.p);
     }
     if (n_rec) {
         // the unit positions are lanes [0, KU sps) of a record row; the lanes behind them must be a power of two for the kernel's index split
         const uint32_t skip = tl.unit_mode && tl.sh.KU * tl.sh.sps == 32u ? 32u : 0u;
-        const uint64_t n_work = (n_rec >> 6) * (64u - skip);
+        const uint64_t n_work = (((n_rec >> 6) + 3) / 4) * (64u - skip); // 4 record rows per work-item
         hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)std::min<uint64_t>((n_work + 255) / 256, 1u << 23)), dim3(256), 0, st.stream, tl.prow.p, tl.pcnt.p, tl.pw.p, n_rec,
-                           cp.n_outer, tl.sh, map, tl.unit_mode ? tl.uo.p : (const double *)nullptr, tl.unit_mode ? tl.vi.p : (const double *)nullptr, skip);
+                           cp.n_outer, tl.sh, map, tl.unit_mode ? tl.uo.p : (const double *)nullptr, tl.unit_mode ? tl.vi.p : (const double *)nullptr, skip,
+                           tl.unit_mode ? tl.ratio_tab.p : (const double *)nullptr, nl_outer);
     }
     if (tl.ov.nnz) materialize_map_values(st, tl.ov, map, tl.ov.fvals.p);
     SCANRS_HIP(hipGetLastError());
