@@ -898,7 +898,10 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
             if (flagged.size() > room) {
                 std::sort(flagged.begin(), flagged.end(), std::greater<double>());
                 const double need = flagged[room]; // the largest coefficient that has to take the dense route
-                if (need < 100.0 * cmax_limit && (room == 0 || flagged[room - 1] > need)) cmax_limit = std::nextafter(need, INFINITY);
+                if (flagged[0] < 100.0 * cmax_limit) // all of them within the two decades: the pass carries the last block alone (100 columns run 9 % faster than 104)
+                    cmax_limit = std::nextafter(flagged[0], INFINITY);
+                else if (need < 100.0 * cmax_limit && (room == 0 || flagged[room - 1] > need))
+                    cmax_limit = std::nextafter(need, INFINITY);
             }
         }
         for (uint32_t j = 0; j < q; j++)

@@ -40,7 +40,7 @@ constexpr uint32_t TL_NW = 8;          // waves per workgroup (2 per SIMD)
 constexpr uint32_t TL_LMAX = 104;      // widest panel: 192 ring rows x 104 x 8 B = 159744 B of LDS
 constexpr uint32_t TL_LDS = 160u << 10;
 constexpr int TL_W = 6;                // LDS row reads in flight per wave
-constexpr uint32_t TL_TABC = 16;       // unit mode: counts 1 .. 16 take their weight from the per-position quotient table
+constexpr uint32_t TL_TABC = 8;        // unit mode: counts 1 .. 8 take their weight from the per-position quotient table (one 64-byte line per position)
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef __attribute__((address_space(3))) const char *lds_cptr_t;
@@ -179,7 +179,7 @@ __global__ void tile_init_rows_kernel(uint16_t *__restrict__ prow, uint64_t n_re
 __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t *__restrict__ prow, const uint8_t *__restrict__ pcnt,
                                                            double *__restrict__ pw, uint64_t n_rec, uint64_t n_outer, TileShape sh, DevMap map,
                                                            const double *__restrict__ uo, const double *__restrict__ vi, uint32_t skip,
-                                                           const double *__restrict__ tab, int tab_outer) {
+                                                           const double *__restrict__ tab, int tab_outer, uint32_t vmajor_groups) {
     const uint32_t per_row = 64u - skip; // 64 or 32 (K = 2, one unit position)
     // The index arithmetic below would be five integer divisions per position (~25 VALU instructions each — as much as the
     // logarithm and the division of the weight together): quotients through a rounded-down product with the reciprocal
@@ -193,17 +193,25 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t *__res
     // (1.5 TB/s). Grid-stride: a launch holds fewer than 2^32 work-items, a layout more records.
     constexpr int WU = 4;
     const uint64_t n_rows = n_rec >> 6, n_quads = (n_rows + WU - 1) / WU;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_quads * per_row; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t q4 = per_row == 64u ? (i >> 6) : (i >> 5);
+    // Visit-major order (vmajor_groups = the number of groups; grid.y = quad of visits, grid.x over groups x lanes; one set per
+    // visit): the table is indexed by the INNER position there, and with the records in storage order every wave would be
+    // at a different place of it (64 MB at 10^6 cells: every lookup an L2 miss, 8.2 ms); in this order the waves in flight
+    // work the same few hundred inner positions.
+    const uint64_t n_lin = vmajor_groups ? (uint64_t)vmajor_groups * per_row : n_quads * per_row;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lin; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t gq = per_row == 64u ? (i >> 6) : (i >> 5); // linear: quad of rows; visit-major: group
         const uint32_t lane = skip + (uint32_t)(i & (per_row - 1u));
+        // first row of the quad and the rows it may use: linear -> up to the end of the layout; visit-major -> up to the end of the group
+        const uint64_t row0 = vmajor_groups ? gq * sh.nt + (uint64_t)blockIdx.y * WU : gq * WU;
+        const uint64_t row_end = vmajor_groups ? (gq + 1) * sh.nt : n_rows;
         const uint32_t qs = (uint32_t)(((float)lane + 0.5f) * inv_sps);
         const uint32_t slot = lane - qs * sh.sps;
         uint32_t cnt[WU], code[WU];
         bool ok[WU];
 #pragma unroll
         for (int u = 0; u < WU; u++) {
-            const uint64_t sv64 = q4 * WU + u;
-            ok[u] = sv64 < n_rows;
+            const uint64_t sv64 = row0 + u;
+            ok[u] = sv64 < row_end;
             const uint64_t e = ((ok[u] ? sv64 : n_rows - 1) << 6) + lane;
             cnt[u] = ok[u] ? pcnt[e] : 0u; // a row past the end has no positions
             code[u] = prow[e];
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t *__res
         uint32_t oo[WU], in[WU];
 #pragma unroll
         for (int u = 0; u < WU; u++) {
-            const uint32_t sv = (uint32_t)(q4 * WU + u);
+            const uint32_t sv = (uint32_t)(row0 + u);
             const uint32_t b = sv & (sh.nset - 1u);
             const uint32_t gv = sv >> nset_shift;
             const uint32_t g = (uint32_t)(((double)gv + 0.5) * inv_nt), v = gv - g * sh.nt;
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t *__res
                 }
                 w[u] = x;
             }
-            if (ok[u]) pw[((q4 * WU + u) << 6) + lane] = w[u];
+            if (ok[u]) pw[((row0 + u) << 6) + lane] = w[u];
         }
     }
 }
@@ -276,8 +284,8 @@ __global__ void tile_unit_factor_kernel(DevMap map, int side_outer, int nl_outer
 // Unit mode: the stored weight of a general position, f(c, o, i) / (uo[o] vi[i]), is N(c a) / N(a) with a = the scales in
 // front of the nonlinear links — all on ONE side for a separable chain — and N those links; every scale behind them cancels.
 // It therefore depends on the count and on that side's position only, and 60 % of the counts above 1 are 2, 95 % at most 4:
-// a table of the quotient for counts 1 .. 16 per position of that side (16 logarithms per cell instead of one per nonzero
-// per orientation: 1.6e7 against 5.6e8 at 10^6 cells) turns the weight refresh into a streaming pass with a cached lookup.
+// a table of the quotient for counts 1 .. 8 per position of that side (one 64-byte line; 8 logarithms per cell instead of one per
+// nonzero per orientation: 8e6 against 5.6e8 at 10^6 cells; counts above 8 — 0.07 % — are evaluated directly) turns the weight refresh into a streaming pass with a cached lookup.
 // G(c) = the chain on x = c with the other side's links left out; tab[idx][c - 1] = G(c) / G(1).
 __global__ void tile_ratio_table_kernel(DevMap map, int nl_outer, uint64_t n, double *__restrict__ tab) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -498,9 +506,14 @@ static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &c
         // the unit positions are lanes [0, KU sps) of a record row; the lanes behind them must be a power of two for the kernel's index split
         const uint32_t skip = tl.unit_mode && tl.sh.KU * tl.sh.sps == 32u ? 32u : 0u;
         const uint64_t n_work = (((n_rec >> 6) + 3) / 4) * (64u - skip); // 4 record rows per work-item
-        hipLaunchKernelGGL(tile_weights_kernel, dim3((unsigned)std::min<uint64_t>((n_work + 255) / 256, 1u << 23)), dim3(256), 0, st.stream, tl.prow.p, tl.pcnt.p, tl.pw.p, n_rec,
+        const uint32_t vquads = (tl.sh.nt + 3u) / 4u;
+        // the table indexed by the inner position: visit-major order (see the kernel)
+        const bool vmajor = tl.unit_mode && !nl_outer && tl.sh.nset == 1u && vquads <= 65535u && tl.n_groups <= 0xFFFFFFFFull / 64u;
+        dim3 grid((unsigned)std::min<uint64_t>((n_work + 255) / 256, 1u << 23));
+        if (vmajor) grid = dim3((unsigned)((tl.n_groups * (64u - skip) + 255) / 256), vquads);
+        hipLaunchKernelGGL(tile_weights_kernel, grid, dim3(256), 0, st.stream, tl.prow.p, tl.pcnt.p, tl.pw.p, n_rec,
                            cp.n_outer, tl.sh, map, tl.unit_mode ? tl.uo.p : (const double *)nullptr, tl.unit_mode ? tl.vi.p : (const double *)nullptr, skip,
-                           tl.unit_mode ? tl.ratio_tab.p : (const double *)nullptr, nl_outer);
+                           tl.unit_mode ? tl.ratio_tab.p : (const double *)nullptr, nl_outer, vmajor ? (uint32_t)tl.n_groups : 0u);
     }
     if (tl.ov.nnz) materialize_map_values(st, tl.ov, map, tl.ov.fvals.p);
     SCANRS_HIP(hipGetLastError());
