@@ -293,6 +293,62 @@ static void gemm_hostw(Ctx &c, const double *X, uint32_t ldx, uint32_t n, const 
     launch_gemm_nn(c.st, X, ldx, n, dW, m, m, rows, alpha, beta, Out, ldo, Out, ldo);
 }
 
+// Last resort of the orthonormalisations, for panels whose columns are numerically DEPENDENT (a matrix of rank below the
+// panel width: CholeskyQR, shifted or not, cannot converge on them): modified Gram-Schmidt with re-orthogonalisation on the
+// host; a column that is dependent on its predecessors is replaced by a random direction orthogonal to them — what the
+// Householder QR of the reference (`.qr()`, bk_svd.rs:94,98,123,127) leaves in such a column is as arbitrary, and any
+// orthonormal completion gives the same Rayleigh-Ritz values. The panel then no longer is (original basis) * C, so the
+// coefficient bookkeeping of svd_bk is void: Storage::orth_fallbacks tells the solver to compute the projection directly.
+static void orth_host_mgs(Ctx &c, double *P, uint32_t ld, uint32_t n, uint64_t rows) {
+    Tick tk("  orth_host_mgs (rank-deficient panel)");
+    std::vector<double> X((size_t)rows * n);
+    download_panel(c, P, ld, rows, n, X.data());
+    // column-major copy: the inner loops run over contiguous columns
+    std::vector<double> Q((size_t)n * rows);
+    for (uint64_t r = 0; r < rows; r++)
+        for (uint32_t j = 0; j < n; j++) Q[(size_t)j * rows + r] = X[(size_t)r * n + j];
+    SmallRng rng(0x5ca9a5d1u + n);
+    auto dot = [&](const double *a, const double *b) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        uint64_t r = 0;
+        for (; r + 4 <= rows; r += 4) {
+            s0 += a[r] * b[r];
+            s1 += a[r + 1] * b[r + 1];
+            s2 += a[r + 2] * b[r + 2];
+            s3 += a[r + 3] * b[r + 3];
+        }
+        for (; r < rows; r++) s0 += a[r] * b[r];
+        return (s0 + s1) + (s2 + s3);
+    };
+    for (uint32_t j = 0; j < n; j++) {
+        double *v = Q.data() + (size_t)j * rows;
+        const double norm0 = std::sqrt(dot(v, v));
+        for (int attempt = 0; attempt < 8; attempt++) {
+            double before = std::sqrt(dot(v, v));
+            for (int pass = 0; pass < 2; pass++)
+                for (uint32_t i = 0; i < j; i++) {
+                    const double *qi = Q.data() + (size_t)i * rows;
+                    const double h = dot(qi, v);
+                    for (uint64_t r = 0; r < rows; r++) v[r] -= h * qi[r];
+                }
+            const double after = std::sqrt(dot(v, v));
+            // dependent (or zero) column: what is left is rounding noise of the projections
+            const bool dependent = attempt == 0 ? !(after > 1e-10 * norm0) || !(norm0 > 0.0) : !(after > 1e-3 * before);
+            if (!dependent && std::isfinite(after)) {
+                const double inv = 1.0 / after;
+                for (uint64_t r = 0; r < rows; r++) v[r] *= inv;
+                break;
+            }
+            if (attempt == 7) fail(SCANRS_ERR_NUMERICAL, "orthonormalisation: no independent direction found");
+            for (uint64_t r = 0; r < rows; r++) v[r] = rng.normal();
+        }
+    }
+    for (uint64_t r = 0; r < rows; r++)
+        for (uint32_t j = 0; j < n; j++) X[(size_t)r * n + j] = Q[(size_t)j * rows + r];
+    upload_panel(c, X.data(), rows, n, P, ld);
+    c.st.orth_fallbacks++;
+}
+
 // Orthonormalise the columns of P (rows x n, ld) in place: iterated CholeskyQR, with a diagonal shift
 // when the Gram matrix is numerically singular (shifted CholeskyQR). tmp: same size as P.
 // coef (optional, coef_rows x n row-major): kept equal to the matrix C with P = (original basis) * C, i.e.
@@ -318,7 +374,10 @@ static void orth_cholqr(Ctx &c, double *P, double *tmp, uint32_t ld, uint32_t n,
         while (!chol_upper(R.data(), (int)n)) {
             // shifted CholeskyQR (Fukaya et al. 2020): G + s I, s ~ 11 (rows n + n(n+1)) u ||X||^2
             shift = shift == 0.0 ? 11.0 * ((double)rows * n + (double)n * (n + 1)) * 1.1e-16 * dmax : shift * 100.0;
-            if (++tries > 12 || !(dmax > 0.0)) fail(SCANRS_ERR_NUMERICAL, "orthonormalisation: Cholesky failed");
+            if (++tries > 12 || !(dmax > 0.0)) {
+                if (!sharded_rows && rows * (uint64_t)n <= (1ull << 26)) return orth_host_mgs(c, P, ld, n, rows);
+                fail(SCANRS_ERR_NUMERICAL, "orthonormalisation: Cholesky failed");
+            }
             R = G;
             for (uint32_t i = 0; i < n; i++) R[(size_t)i * n + i] += shift;
         }
@@ -345,6 +404,7 @@ static void orth_cholqr(Ctx &c, double *P, double *tmp, uint32_t ld, uint32_t n,
         launch_gemm_nn(c.st, P, ld, n, dW, n, n, rows, 1.0, 0.0, nullptr, 0, tmp, ld);
         SCANRS_HIP(hipMemcpyAsync(P, tmp, (size_t)rows * ld * 8, hipMemcpyDeviceToDevice, c.s));
     }
+    if (!sharded_rows && rows * (uint64_t)n <= (1ull << 26)) return orth_host_mgs(c, P, ld, n, rows);
     fail(SCANRS_ERR_NUMERICAL, "orthonormalisation did not converge");
 }
 
@@ -721,6 +781,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
     // iterations 1..n-1, so they are written straight into T; one extra b-wide product supplies the last block
     // and T' = (op(A) K) C with Q = K C (C small, tracked on the host through the orthonormalisation).
     const bool reuse = (b % 2u) == 0u;
+    const uint64_t fallbacks0 = c.st.orth_fallbacks; // a panel completed with random directions voids Q = K C (orth_host_mgs)
     double *T = c.dev("bk_T", (size_t)dt * ldq);
     // Q = qr(K).Q: block i is already orthonormal; orthogonalise it against blocks < i (in block order), tracking
     // Q = K C in `cfull`
@@ -882,7 +943,12 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
     // blocks are numerically dependent — are recomputed directly as a (narrow) sparse product op(A) Q[:, bad].
     double cmax_limit = c.st.reuse_cmax;
     std::vector<uint32_t> bad;
-    if (reuse) {
+    const bool c_valid = c.st.orth_fallbacks == fallbacks0;
+    if (reuse && !c_valid) {
+        for (uint32_t j = 0; j < q; j++) bad.push_back(j); // everything directly: one q-wide product below
+        if (trace_on()) fprintf(stderr, "[scanrs trace] bk: rank-deficient panels were completed on the host: the projection is computed directly\n");
+    }
+    if (reuse && c_valid) {
         std::vector<double> colmax(q, 0.0);
         for (uint32_t r = 0; r < q; r++)
             for (uint32_t j = 0; j < q; j++) colmax[j] = std::max(colmax[j], std::fabs(cfull[(size_t)r * q + j]));
@@ -925,7 +991,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
     // anyway, computing ALL of it directly — in the same sparse pass as the other bad columns — costs no more
     // 128-column passes than the half-product plus the repair pass, and usually one fewer.
     bool last_direct = false;
-    if (reuse) {
+    if (reuse && c_valid) {
         const uint32_t last_lo = (n_iter - 1) * b;
         uint32_t bad_other = 0;
         for (uint32_t j : bad) bad_other += j < last_lo;

@@ -991,6 +991,31 @@ def test_device_side_factorizations_match_the_host_path(sa):
     assert np.max(np.abs(res[1][1][:6] - exact[:6]) / exact[:6]) < 1e-10
 
 
+def test_rank_deficient_krylov_panels(sa):
+    """A matrix of rank below the block width b = 2k: the Krylov panels are rank-deficient, CholeskyQR cannot orthonormalise
+    them (device or host) and the solver completes them by Gram-Schmidt on the host, as the Householder `.qr()` of the reference
+    would (bk_svd.rs:94,98,123,127), and computes the projection directly: the nonzero singular triplets are exact, the rest
+    are zeros with orthonormal vectors."""
+    rng = np.random.default_rng(77)
+    base = random_counts(rng, 6, 300, 0.5, 20)
+    dense = np.vstack([base] * 40)  # 240 x 300 of rank 6
+    exact = np.linalg.svd(dense.astype(np.float64), compute_uv=False)
+    for storage in (so.CSR, so.CSC):
+        for view_t in (False, True):
+            g, _ = pair(sa, dense, storage)
+            a = g.t() if view_t else g
+            u, s, v = sa.BkSvd().run_pca(a, 10)
+            d = dense.T if view_t else dense
+            assert np.max(np.abs(s[:6] - exact[:6]) / exact[:6]) < 1e-10
+            assert np.max(np.abs(s[6:])) < 1e-7 * exact[0]
+            assert np.max(np.abs(u.T @ u - np.eye(10))) < 1e-9 and np.max(np.abs(v[:, :6].T @ v[:, :6] - np.eye(6))) < 1e-9
+            assert np.max(np.abs(d @ v[:, :6] - u[:, :6] * s[:6])) < 1e-8 * exact[0]
+    # the randomized solver's range finder on the same matrix
+    g, _ = pair(sa, dense, so.CSR)
+    u, s, v = sa.RandSvd().run_pca(g, 8)
+    assert np.max(np.abs(s[:6] - exact[:6]) / exact[:6]) < 1e-8 and np.max(np.abs(s[6:])) < 1e-6 * exact[0]
+
+
 def test_irlba_rejects_zero_iterations(sa):
     g, _ = pair(sa, random_counts(np.random.default_rng(0), 30, 40, 0.5, 9), so.CSR)
     with pytest.raises(sa.ScanrsError) as e:
