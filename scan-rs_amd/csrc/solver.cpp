@@ -274,8 +274,11 @@ static void download_panel_staged(Ctx &c, const double *d, uint32_t ld, uint64_t
 }
 static void download_panel(Ctx &c, const double *d, uint32_t ld, uint64_t rows, uint32_t l, double *h) {
     if (rows == 0 || l == 0) return;
-    if (rows * (uint64_t)l * 8 >= (32u << 20)) return download_panel_staged(c, d, ld, rows, l, h);
-    SCANRS_HIP(hipMemcpy2DAsync(h, (size_t)l * 8, d, (size_t)ld * 8, (size_t)l * 8, rows, hipMemcpyDeviceToHost, c.s));
+    if (rows * (uint64_t)l * 8 >= (8u << 20)) return download_panel_staged(c, d, ld, rows, l, h);
+    if (ld == l)
+        SCANRS_HIP(hipMemcpyAsync(h, d, (size_t)rows * l * 8, hipMemcpyDeviceToHost, c.s));
+    else
+        SCANRS_HIP(hipMemcpy2DAsync(h, (size_t)l * 8, d, (size_t)ld * 8, (size_t)l * 8, rows, hipMemcpyDeviceToHost, c.s));
     c.sync();
 }
 
