@@ -1,5 +1,5 @@
 import numpy as np, time, sys
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import scanrs_amd as sa
 rng=np.random.default_rng(0)
 for n,k in ((500,50),(1000,100)):
