@@ -245,6 +245,7 @@ struct Storage {
     int slice_walk = 1;                   // Ix1 products / moments on the short-outer copy stage the inner-indexed arrays in LDS slices
     int spmv_lds = 1;                     // Ix1 products on the long-outer copy stage the vector in LDS parts
     int overlap = 1;                      // small dense work of the solvers on a second stream beside the sparse passes
+    const int *skip_flag = nullptr;       // device flag the dense kernels launched now test first (nonzero: return at once) — set around the queued passes of a device-side orthonormalisation
     uint64_t orth_fallbacks = 0;          // orthonormalisations that ended in the host Gram-Schmidt for rank-deficient panels (solver.cpp)
     uint64_t bk_host_retries = 0;         // svd_bk calls that fell back from the device-side factorizations to the host path (scanrs_mat_get_counter)
     int device_factor = 1;                // svd_bk: CholeskyQR factors and the coefficient bookkeeping on the device, no host round trip per orthonormalisation (0: host)

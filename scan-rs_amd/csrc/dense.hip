@@ -44,7 +44,8 @@ __device__ __forceinline__ void tile_mma(const double *__restrict__ As, const do
 __global__ __launch_bounds__(256) void gram_tiled_kernel(const double *__restrict__ X, uint32_t ldx, uint32_t n,
                                                          const double *__restrict__ Y, uint32_t ldy, uint32_t m, uint64_t rows,
                                                          uint64_t rows_per_split, const uint32_t *__restrict__ tile_ij,
-                                                         double *__restrict__ slab) {
+                                                         double *__restrict__ slab, const int *__restrict__ skip) {
+    if (skip && *skip) return; // a converged orthonormalisation: its queued passes do nothing (Storage::skip_flag)
     __shared__ double As[DK * DLD];
     __shared__ double Bs[DK * DLD];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -120,7 +121,8 @@ __global__ __launch_bounds__(256) void gram_tiled_kernel(const double *__restric
 
 // ordered sum of the row-split partials; with `symmetric` the strictly-lower tiles were skipped and are mirrored
 __global__ void gram_tiled_finish_kernel(const double *__restrict__ slab, uint32_t splits, uint32_t n, uint32_t m,
-                                         int symmetric, double *__restrict__ C) {
+                                         int symmetric, double *__restrict__ C, const int *__restrict__ skip) {
+    if (skip && *skip) return;
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (uint64_t)n * m) return;
     uint32_t row = (uint32_t)(e / m), col = (uint32_t)(e % m);
@@ -135,7 +137,8 @@ __global__ void gram_tiled_finish_kernel(const double *__restrict__ slab, uint32
 __global__ __launch_bounds__(256) void gemm_tiled_kernel(const double *__restrict__ X, uint32_t ldx, uint32_t n,
                                                          const double *__restrict__ W, uint32_t ldw, uint32_t m, uint64_t rows,
                                                          double alpha, double beta, const double *Cin, uint32_t ldc,
-                                                         double *Out, uint32_t ldo) {
+                                                         double *Out, uint32_t ldo, const int *__restrict__ skip) {
+    if (skip && *skip) return;
     __shared__ double As[DK * DLD];
     __shared__ double Bs[DK * DLD];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -225,7 +228,8 @@ constexpr uint32_t SK_R = 256, SK_C = 64, SK_ALD = 272, SK_BLD = 80;
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const double *__restrict__ X, uint32_t ldx, uint32_t n,
                                                           const double *__restrict__ W, uint32_t ldw, uint32_t m, uint64_t rows,
                                                           double alpha, double beta, const double *Cin, uint32_t ldc,
-                                                          double *Out, uint32_t ldo) {
+                                                          double *Out, uint32_t ldo, const int *__restrict__ skip) {
+    if (skip && *skip) return;
     __shared__ double As[DK * SK_ALD];
     __shared__ double Bs[DK * SK_BLD];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
@@ -566,9 +570,9 @@ void launch_gram_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, c
     double *slab = st.scratch.get<double>(st.skey("gram_slab"), (size_t)splits * n * m);
     if (st.prof.on) st.prof.begin(st.stream, "gram_tiled_mfma_f64", (double)rows * (n + (symmetric ? 0 : m)) * 8.0 + (double)n * m * 8.0);
     hipLaunchKernelGGL(gram_tiled_kernel, dim3(n_tiles, (unsigned)splits), dim3(256), 0, st.stream, X, ldx, n, Y, ldy, m, rows, rps,
-                       d_tiles, slab);
+                       d_tiles, slab, st.skip_flag);
     hipLaunchKernelGGL(gram_tiled_finish_kernel, dim3((unsigned)(((uint64_t)n * m + 255) / 256)), dim3(256), 0, st.stream, slab,
-                       (uint32_t)splits, n, m, symmetric ? 1 : 0, C);
+                       (uint32_t)splits, n, m, symmetric ? 1 : 0, C, st.skip_flag);
     if (st.prof.on) st.prof.end(st.stream);
     SCANRS_HIP(hipGetLastError());
 }
@@ -578,7 +582,7 @@ void launch_gemm_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, c
     if ((m - 1u) % DT < SK_C) { // the last (or only) 128-column tile would be at most half full
         if (st.prof.on) st.prof.begin(st.stream, "gemm_skinny_mfma_f64", (double)rows * (n + m) * 8.0 + (double)n * m * 8.0);
         hipLaunchKernelGGL(gemm_skinny_kernel, dim3((unsigned)((rows + SK_R - 1) / SK_R), (m + SK_C - 1) / SK_C), dim3(256), 0, st.stream, X,
-                           ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
+                           ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo, st.skip_flag);
         if (st.prof.on) st.prof.end(st.stream);
         SCANRS_HIP(hipGetLastError());
         return;
@@ -586,7 +590,7 @@ void launch_gemm_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, c
     if (st.prof.on) st.prof.begin(st.stream, "gemm_tiled_mfma_f64", (double)rows * (n + m) * 8.0 + (double)n * m * 8.0);
     if (trace_on()) fprintf(stderr, "[scanrs trace] gemm_tiled rows=%llu n=%u m=%u ldx=%u ldw=%u beta=%g\n", (unsigned long long)rows, n, m, ldx, ldw, beta);
     hipLaunchKernelGGL(gemm_tiled_kernel, dim3((unsigned)((rows + DT - 1) / DT), (m + DT - 1) / DT), dim3(256), 0, st.stream, X, ldx,
-                       n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
+                       n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo, st.skip_flag);
     if (st.prof.on) st.prof.end(st.stream);
     SCANRS_HIP(hipGetLastError());
 }

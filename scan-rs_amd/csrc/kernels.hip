@@ -996,7 +996,8 @@ __global__ __launch_bounds__(256) void weighted_colsum_finish_kernel(const doubl
 __global__ __launch_bounds__(64) void gram_kernel(const double *__restrict__ X, uint32_t ldx, uint32_t n,
                                                   const double *__restrict__ Y, uint32_t ldy, uint32_t m, uint64_t rows,
                                                   uint64_t rows_per_split, uint32_t tiles_m,
-                                                  double *__restrict__ slab) {
+                                                  double *__restrict__ slab, const int *__restrict__ skip) {
+    if (skip && *skip) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t li = lane & 15u, lk = lane >> 4;
     const uint32_t i0 = (blockIdx.x / tiles_m) * 32u, j0 = (blockIdx.x % tiles_m) * 32u;
@@ -1038,7 +1039,8 @@ __global__ __launch_bounds__(64) void gram_kernel(const double *__restrict__ X, 
     }
 }
 __global__ void gram_finish_kernel(const double *__restrict__ slab, uint32_t splits, uint64_t nm,
-                                   double *__restrict__ C) {
+                                   double *__restrict__ C, const int *__restrict__ skip) {
+    if (skip && *skip) return;
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nm) return;
     double s = 0.0;
@@ -1053,7 +1055,8 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const double *__restrict__
                                                       const double *__restrict__ W, uint32_t ldw, uint32_t m,
                                                       uint64_t rows, double alpha, double beta,
                                                       const double *Cin, uint32_t ldc, double *Out,
-                                                      uint32_t ldo) {
+                                                      uint32_t ldo, const int *__restrict__ skip) {
+    if (skip && *skip) return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t li = lane & 15u, lk = lane >> 4;
     const uint64_t r0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u;
@@ -1113,7 +1116,8 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(const double *__restrict__
 // ---------------------------------------------------------------------------------------------
 // small element-wise helpers
 __global__ void copy_cols_kernel(const double *__restrict__ src, uint32_t lds, double *__restrict__ dst, uint32_t ldd,
-                                 uint64_t rows, uint32_t l) {
+                                 uint64_t rows, uint32_t l, const int *__restrict__ skip) {
+    if (skip && *skip) return;
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= rows * l) return;
     const uint64_t r = e / l;
@@ -2048,9 +2052,9 @@ void launch_gram(Storage &st, const double *X, uint32_t ldx, uint32_t n, const d
     {
         ProfScope ps(st, "gram_mfma_f64", (double)rows * (n + (X == Y && n == m ? 0 : m)) * 8.0 + (double)n * m * 8.0);
         hipLaunchKernelGGL(gram_kernel, dim3((unsigned)tiles, (unsigned)splits), dim3(64), 0, st.stream, X, ldx, n, Y, ldy,
-                           m, rows, rps, tiles_m, slab);
+                           m, rows, rps, tiles_m, slab, st.skip_flag);
         hipLaunchKernelGGL(gram_finish_kernel, grid1((uint64_t)n * m, 256), dim3(256), 0, st.stream, slab,
-                           (uint32_t)splits, (uint64_t)n * m, C);
+                           (uint32_t)splits, (uint64_t)n * m, C, st.skip_flag);
     }
     SCANRS_HIP(hipGetLastError());
 }
@@ -2069,13 +2073,13 @@ void launch_gemm_nn(Storage &st, const double *X, uint32_t ldx, uint32_t n, cons
     const dim3 block(256);
     if (m <= 16) {
         hipLaunchKernelGGL((gemm_nn_kernel<1>), dim3((unsigned)((waves + 3) / 4), (m + 15u) / 16u), block, 0, st.stream, X,
-                           ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
+                           ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo, st.skip_flag);
     } else if (m <= 32) {
         hipLaunchKernelGGL((gemm_nn_kernel<2>), dim3((unsigned)((waves + 3) / 4), (m + 31u) / 32u), block, 0, st.stream, X,
-                           ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
+                           ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo, st.skip_flag);
     } else {
         hipLaunchKernelGGL((gemm_nn_kernel<4>), dim3((unsigned)((waves + 3) / 4), (m + 63u) / 64u), block, 0, st.stream, X,
-                           ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
+                           ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo, st.skip_flag);
     }
     SCANRS_HIP(hipGetLastError());
 }
@@ -2083,7 +2087,7 @@ void launch_gemm_nn(Storage &st, const double *X, uint32_t ldx, uint32_t n, cons
 void launch_copy_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows,
                       uint32_t l) {
     if (rows == 0 || l == 0) return;
-    hipLaunchKernelGGL(copy_cols_kernel, grid1(rows * l, 256), dim3(256), 0, st.stream, src, lds, dst, ldd, rows, l);
+    hipLaunchKernelGGL(copy_cols_kernel, grid1(rows * l, 256), dim3(256), 0, st.stream, src, lds, dst, ldd, rows, l, st.skip_flag);
     SCANRS_HIP(hipGetLastError());
 }
 void launch_permute_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows,

@@ -480,16 +480,21 @@ static void orth_cholqr_dev(Ctx &c, DevOrth &od, double *P, double *tmp, uint32_
     double *info = od.info + 2 * slot;
     double *dG = c.dev(c.st.skey("orth_G").c_str(), (size_t)n * n);
     double *dR = c.dev(c.st.skey("orth_Rinv").c_str(), (size_t)n * n);
+    struct SkipScope { // the dense kernels queued inside return at once when this orthonormalisation has converged
+        Storage &st;
+        ~SkipScope() { st.skip_flag = nullptr; }
+    } scope{c.st};
     for (int pass = 0; pass < DEV_CHOLQR_PASSES; pass++) {
         const bool last = pass + 1 == DEV_CHOLQR_PASSES;
+        if (pass >= 1) c.st.skip_flag = ctl; // ctl[0]: done. The Gram kernel of pass 1 still runs (nothing has converged before its check)
         launch_gram(c.st, P, ld, n, P, ld, n, rows, dG);
         launch_chol_rinv(c.st, dG, n, rows, pass, last, ctl, dR, info);
         if (last) break;
         launch_gemm_nn(c.st, P, ld, n, dR, n, n, rows, 1.0, 0.0, nullptr, 0, tmp, ld);
-        SCANRS_HIP(hipMemcpyAsync(P, tmp, (size_t)rows * ld * 8, hipMemcpyDeviceToDevice, c.s));
+        launch_copy_cols(c.st, tmp, ld, P, ld, rows, ld);
         if (coef) {
             launch_gemm_nn(c.st, coef, ldcoef, n, dR, n, n, coef_rows, 1.0, 0.0, nullptr, 0, coef_tmp, ldcoef);
-            SCANRS_HIP(hipMemcpyAsync(coef, coef_tmp, (size_t)coef_rows * ldcoef * 8, hipMemcpyDeviceToDevice, c.s));
+            launch_copy_cols(c.st, coef_tmp, ldcoef, coef, ldcoef, coef_rows, ldcoef);
         }
     }
 }
