@@ -139,17 +139,31 @@ Storage::~Storage() {
         (void)hipStreamDestroy(stream);
     }
 }
+// Three streams per handle, three priorities where the device has them: the main stream (sparse products: the persistent tile
+// kernel must get its CUs first) above the overflow gather (fills the registers the tile kernel leaves; the product waits for
+// it) above the auxiliary stream (dense work nothing waits for until the end of the iterations). With two levels the lower
+// two share one.
+static int stream_priority(int level) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest); // numerically greatest <= least
+    if (level == 0) return greatest;
+    if (level == 2 || least - greatest < 2) return least;
+    return (least + greatest) / 2;
+}
 hipStream_t Storage::aux() {
     if (!overlap) return stream;
-    if (!aux_stream) SCANRS_HIP(hipStreamCreate(&aux_stream));
+    if (!aux_stream) {
+        // lowest priority: at the end of a persistent tile kernel the NEXT one (main stream) gets the CUs first and this stream's
+        // dense kernels fill what its tail and the overflow gather's tail leave — at equal priority a 2-3 ms projection GEMM that
+        // became runnable at the same moment held the next sparse product back by its whole duration
+        SCANRS_HIP(hipStreamCreateWithPriority(&aux_stream, hipStreamDefault, stream_priority(2)));
+    }
     return aux_stream;
 }
 hipStream_t Storage::ov() {
     if (!ov_stream) {
         // lowest priority: the persistent tile kernel's workgroups are placed first, the gather fills what is left of a CU
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        SCANRS_HIP(hipStreamCreateWithPriority(&ov_stream, hipStreamNonBlocking, least));
+        SCANRS_HIP(hipStreamCreateWithPriority(&ov_stream, hipStreamNonBlocking, stream_priority(1)));
         SCANRS_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
         SCANRS_HIP(hipEventCreateWithFlags(&ev_ov, hipEventDisableTiming));
     }
@@ -294,7 +308,7 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
     st->storage = storage;
     // a blocking stream: legacy null-stream copies (ours and the host program's, e.g. torch's default
     // stream that produced a device-resident input) stay ordered with the kernels launched here
-    SCANRS_HIP(hipStreamCreate(&st->stream));
+    SCANRS_HIP(hipStreamCreateWithPriority(&st->stream, hipStreamDefault, stream_priority(0)));
     st->scratch.stream = st->stream;
     SparseCopy &cp = st->primary;
     cp.n_outer = storage == SCANRS_CSR ? rows : cols;
