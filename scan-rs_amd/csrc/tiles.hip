@@ -532,6 +532,7 @@ struct TileArgs {
     const uint16_t *prow;
     const double *pw;
     const double *uo; // unit mode: factor applied to a vector's sum at the end
+    uint32_t *next_item; // items are taken from this counter (zeroed before the launch)
     uint64_t n_groups, n_outer, n_inner;
     TileShape sh;
 };
@@ -603,7 +604,17 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
     // record rows are 16 bits; a lane loads the aligned dword that holds the two rows of its pair
     const uint32_t *prow32 = reinterpret_cast<const uint32_t *>(ta.prow);
 
-    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    __shared__ uint32_t s_item;
+    for (;;) {
+        // Items are taken from a counter, in order: a workgroup that starts late (its CU was still running a dense kernel of the
+        // auxiliary stream) or draws slow items simply takes fewer — with a fixed stride the launch ended when its unluckiest
+        // workgroup did (the pass after the last Gram-Schmidt block ran 22.3 instead of 20.4 ms).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // everyone is done with the ring of the previous item and has read s_item
+        if (threadIdx.x == 0) s_item = atomicAdd(ta.next_item, 1u);
+        __syncthreads();
+        const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_item);
+        if (item >= n_items) break;
         // part-major: the workgroups resident at one time walk the SAME range of tiles, so a tile comes from HBM once and from
         // L2 / Infinity Cache for everybody else (with the parts interleaved every workgroup streamed its own range of the
         // 800 MB panel of the gene-major product: 118 GB of staging reads per pass, 5 TB/s, and that bound the pass)
@@ -612,8 +623,6 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
         const uint64_t group_raw = (uint64_t)wgg * TL_NW + wave;
         const bool live = group_raw < ta.n_groups;
         const uint64_t group = live ? group_raw : ta.n_groups - 1; // idle waves shadow the last group (they still stage tiles and meet the barriers)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads(); // everyone is done with the ring of the previous item
         uint32_t bufn = t0 % nbuf; // ring buffer of the tile being staged
 #pragma unroll
         for (int i = 0; i < CH; i++) stage_chunk(t0, bufn, i);
@@ -885,7 +894,9 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
             launch_gather2d_ov(st, st.stream, tl.ov, Xov, Xov == X ? ldx : ldxov, l, ovout, ldc);
         }
     }
-    TileArgs ta{tl.prow.p, tl.pw.p, tl.unit_mode ? tl.uo.p : nullptr, tl.n_groups, cp.n_outer, cp.n_inner, sh};
+    uint32_t *next_item = st.scratch.get<uint32_t>("tile_next_item", 1);
+    SCANRS_HIP(hipMemsetAsync(next_item, 0, sizeof(uint32_t), st.stream));
+    TileArgs ta{tl.prow.p, tl.pw.p, tl.unit_mode ? tl.uo.p : nullptr, next_item, tl.n_groups, cp.n_outer, cp.n_inner, sh};
     // algorithmic bytes of the nonzeros this kernel works: 8 B each + indptr + the two panels
     const double bytes = (double)(cp.nnz - tl.ov.nnz) * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_inner * l * 8.0 + (double)cp.n_outer * l * 8.0;
     const bool long_outer = cp.n_outer >= cp.n_inner;
