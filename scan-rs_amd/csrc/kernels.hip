@@ -1742,9 +1742,11 @@ void materialize_map_values(Storage &st, SparseCopy &cp, const DevMap &map, doub
 void launch_gather2d_ov(Storage &st, hipStream_t s, SparseCopy &ov, const double *X, uint32_t ldx, uint32_t l, double *out,
                         uint32_t ldo) {
     const uint32_t nb = (uint32_t)((ov.n_inner + (1ull << BT_SHIFT) - 1) >> BT_SHIFT); // bounds were built with the layout
-    // panel slice per step: the L2 slice of the blocked gather unless ov_tile_bytes says otherwise (one step over the whole panel
-    // finishes this gather sooner but its Infinity-Cache / HBM row reads slow the tile kernel's staging down: measured worse)
-    const size_t ovb = st.ov_tile_bytes ? st.ov_tile_bytes : st.l2_tile_bytes;
+    // panel slice per step: twice the L2 slice of the blocked gather unless ov_tile_bytes says otherwise. Beside the tile kernel
+    // the gather is bound by the drain at the end of every step, not by L2 hits: 245 steps of 3.5 MB over the 800 MB gene-major
+    // panel end 1 ms later than 123 of 7 MB (pass 21.3 vs 20.5 ms; 10.5 MB: 20.8; the whole panel in one step: 24 ms — its
+    // Infinity-Cache / HBM row reads slow the tile kernel's staging down). The 26 MB cell-major panel does not care (20.6 ms).
+    const size_t ovb = st.ov_tile_bytes ? st.ov_tile_bytes : 2 * st.l2_tile_bytes;
     uint32_t m = (uint32_t)(ovb / ((size_t)(1u << BT_SHIFT) * l * 8));
     if (m < 1u) m = 1u;
     const uint32_t steps = (nb + m - 1u) / m;
