@@ -128,6 +128,10 @@ Storage::~Storage() {
         (void)hipStreamSynchronize(aux_stream);
         (void)hipStreamDestroy(aux_stream);
     }
+    if (aux2_stream) {
+        (void)hipStreamSynchronize(aux2_stream);
+        (void)hipStreamDestroy(aux2_stream);
+    }
     if (ov_stream) {
         (void)hipStreamSynchronize(ov_stream);
         (void)hipStreamDestroy(ov_stream);
@@ -139,9 +143,9 @@ Storage::~Storage() {
         (void)hipStreamDestroy(stream);
     }
 }
-// Three streams per handle, three priorities where the device has them: the main stream (sparse products: the persistent tile
+// Four streams per handle, three priorities where the device has them: the main stream (sparse products: the persistent tile
 // kernel must get its CUs first) above the overflow gather (fills the registers the tile kernel leaves; the product waits for
-// it) above the auxiliary stream (dense work nothing waits for until the end of the iterations). With two levels the lower
+// it) above the two auxiliary streams (dense work nothing waits for until the end of the iterations). With two levels the lower
 // two share one.
 static int stream_priority(int level) {
     int least = 0, greatest = 0;
@@ -159,6 +163,11 @@ hipStream_t Storage::aux() {
         SCANRS_HIP(hipStreamCreateWithPriority(&aux_stream, hipStreamDefault, stream_priority(2)));
     }
     return aux_stream;
+}
+hipStream_t Storage::aux2() {
+    if (!overlap) return stream;
+    if (!aux2_stream) SCANRS_HIP(hipStreamCreateWithPriority(&aux2_stream, hipStreamDefault, stream_priority(2)));
+    return aux2_stream;
 }
 hipStream_t Storage::ov() {
     if (!ov_stream) {

@@ -198,8 +198,14 @@ struct Storage {
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr; // small dense work that overlaps a sparse pass (svd_bk's cross-block orthogonalisation)
     hipStream_t aux();
+    hipStream_t aux2_stream = nullptr; // svd_bk's early projection GEMMs (bulk work nothing waits for until the end of the iterations)
+    hipStream_t aux2();
     // scratch key of the stream work is being queued on: the auxiliary stream runs beside the main one and must not share its temporaries
-    std::string skey(const char *k) const { return (aux_stream && stream == aux_stream) ? std::string(k) + "@aux" : std::string(k); }
+    std::string skey(const char *k) const {
+        if (aux_stream && stream == aux_stream) return std::string(k) + "@aux";
+        if (aux2_stream && stream == aux2_stream) return std::string(k) + "@aux2";
+        return std::string(k);
+    }
     hipStream_t ov_stream = nullptr; // the gather over the overflow part of a tile layout runs here, beside the tile kernel (tiles.hip)
     hipEvent_t ev_in = nullptr, ev_ov = nullptr;
     hipStream_t ov();

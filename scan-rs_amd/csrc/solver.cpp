@@ -715,6 +715,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
             if (std::uncaught_exceptions() > n0) {
                 (void)hipStreamSynchronize(st.stream);
                 if (st.aux_stream) (void)hipStreamSynchronize(st.aux_stream);
+                if (st.aux2_stream) (void)hipStreamSynchronize(st.aux2_stream);
             }
         }
     } drain{c.st};
@@ -841,10 +842,14 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
     };
     // T'_j = (op(A) K)[:, 0:(j+1)b] * C[0:(j+1)b, block j] for the blocks whose coefficients are known before the end: a
     // dense MFMA GEMM queued on the auxiliary stream behind the pass that delivers the last half-product it reads, so it
-    // runs beside the next (gather-bound) sparse pass. Out of place (S): later blocks still need the half-products in T.
+    // runs in the gaps the sparse passes leave. Out of place: later blocks still need the half-products in T, so the projected
+    // blocks are collected in a second panel T2 of the same shape (block 0, whose projection is the half-product itself, is
+    // copied there by the first early projection), and the Rayleigh-Ritz step reads T2 — nothing is copied back at the end.
+    // The projections have a stream of their own: on the stream of the Gram-Schmidt chains a 3 ms GEMM stood between the main
+    // stream and the chain it was waiting for at the end of the iterations.
     const uint32_t n_early = (reuse && n_iter >= 3) ? n_iter - 2 : 0; // blocks 1 .. n_iter-2
-    const uint32_t ld_s = even_up(std::max(1u, n_early * b));
-    double *S = n_early ? c.dev("bk_S", (size_t)dt * ld_s) : nullptr;
+    double *T2 = reuse ? c.dev("bk_T2", (size_t)dt * ldq) : nullptr;
+    bool block0_copied = false;
     struct Ev {
         hipEvent_t e = nullptr;
         Ev() { SCANRS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
@@ -860,17 +865,22 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
             for (uint32_t r = 0; r < nr; r++)
                 for (uint32_t cc = 0; cc < b; cc++) W[(size_t)r * b + cc] = cfull[(size_t)r * q + j * b + cc];
         }
-        StreamSwap sw(c.st, c.st.aux());
+        StreamSwap sw(c.st, c.st.aux2());
         Ctx cx(m);
         SCANRS_HIP(hipStreamWaitEvent(cx.s, ev_pass.e, 0));
-        if (dv) { // the coefficients of block j were finished on this stream a moment ago
-            launch_gemm_nn(cx.st, T, ldq, nr, cfull_d + (size_t)j * b, ldq, b, dt, 1.0, 0.0, nullptr, 0, S + (size_t)(j - 1) * b, ld_s);
+        if (!block0_copied) {
+            launch_copy_cols(cx.st, T, ldq, T2, ldq, dt, b);
+            block0_copied = true;
+        }
+        if (dv) { // the coefficients of block j: finished on the auxiliary stream (ev_aux was recorded behind them)
+            SCANRS_HIP(hipStreamWaitEvent(cx.s, ev_aux.e, 0));
+            launch_gemm_nn(cx.st, T, ldq, nr, cfull_d + (size_t)j * b, ldq, b, dt, 1.0, 0.0, nullptr, 0, T2 + (size_t)j * b, ldq);
         } else {
             char key[32];
             snprintf(key, sizeof(key), "bk_projw%u", j);
             double *dW = cx.dev(key, (size_t)nr * b);
             cx.h2d(dW, W.data(), W.size());
-            launch_gemm_nn(cx.st, T, ldq, nr, dW, b, b, dt, 1.0, 0.0, nullptr, 0, S + (size_t)(j - 1) * b, ld_s);
+            launch_gemm_nn(cx.st, T, ldq, nr, dW, b, b, dt, 1.0, 0.0, nullptr, 0, T2 + (size_t)j * b, ldq);
         }
         SCANRS_HIP(hipEventRecord(ev_proj.e, cx.s));
         projected[j] = 1;
@@ -941,6 +951,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
                         fprintf(stderr, "[scanrs trace] bk: device factorization %u: done %d status %d (last check %.3e, shift %.3e) -> host path\n", sl,
                                 ctl[2 * sl], ctl[2 * sl + 1], info[2 * sl], info[2 * sl + 1]);
                     if (c.st.aux_stream) SCANRS_HIP(hipStreamSynchronize(c.st.aux_stream));
+                    if (c.st.aux2_stream) SCANRS_HIP(hipStreamSynchronize(c.st.aux2_stream));
                     return BK_RETRY_ON_HOST;
                 }
             }
@@ -1022,33 +1033,31 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
         }
         if (trace_on()) fprintf(stderr, "[scanrs trace] bk: last block %s\n", last_direct ? "computed directly with the repair pass" : "through its half-product");
     }
+    double *Tfin = T; // the panel the Rayleigh-Ritz step reads
     {
         Tick tk("bk: projection");
         if (reuse && (bad.size() * 2 < q || last_direct)) {
-            // in place, last block first: T'_j = T[:, 0:(j+1)b] * C[0:(j+1)b, block j]
+            // T2 block j = T[:, 0:(j+1)b] * C[0:(j+1)b, block j] for the blocks not projected early
             std::vector<double> W;
             for (uint32_t j = n_iter - 1 - (last_direct ? 1u : 0u); j >= 1; j--) {
-                if (projected[j]) continue; // done early, waiting in S
+                if (projected[j]) continue; // done early
                 const uint32_t nr = (j + 1) * b;
                 if (dv) {
-                    launch_gemm_nn(c.st, T, ldq, nr, cfull_d + (size_t)j * b, ldq, b, dt, 1.0, 0.0, nullptr, 0, Y, ldb);
+                    launch_gemm_nn(c.st, T, ldq, nr, cfull_d + (size_t)j * b, ldq, b, dt, 1.0, 0.0, nullptr, 0, T2 + (size_t)j * b, ldq);
                 } else {
                     W.assign((size_t)nr * b, 0.0);
                     for (uint32_t r = 0; r < nr; r++)
                         for (uint32_t cc = 0; cc < b; cc++) W[(size_t)r * b + cc] = cfull[(size_t)r * q + j * b + cc];
                     double *dW = c.dev("bk_projw", (size_t)nr * b);
                     c.h2d(dW, W.data(), W.size());
-                    launch_gemm_nn(c.st, T, ldq, nr, dW, b, b, dt, 1.0, 0.0, nullptr, 0, Y, ldb);
+                    launch_gemm_nn(c.st, T, ldq, nr, dW, b, b, dt, 1.0, 0.0, nullptr, 0, T2 + (size_t)j * b, ldq);
                 }
-                launch_copy_cols(c.st, Y, ldb, T + (size_t)j * b, ldq, dt, b);
             }
+            if (!block0_copied) launch_copy_cols(c.st, T, ldq, T2, ldq, dt, b);
             bool any_early = false;
             for (uint32_t j = 1; j < n_iter; j++) any_early = any_early || projected[j];
-            if (any_early) {
-                SCANRS_HIP(hipStreamWaitEvent(c.s, ev_proj.e, 0)); // the last early GEMM (they are ordered on the auxiliary stream)
-                for (uint32_t j = 1; j < n_iter; j++)
-                    if (projected[j]) launch_copy_cols(c.st, S + (size_t)(j - 1) * b, ld_s, T + (size_t)j * b, ldq, dt, b);
-            }
+            if (any_early) SCANRS_HIP(hipStreamWaitEvent(c.s, ev_proj.e, 0)); // the last early GEMM (they are ordered on their stream)
+            Tfin = T2;
             if (!bad.empty()) {
                 const uint32_t nbad = (uint32_t)bad.size(), ldbad = even_up(nbad);
                 uint32_t *d_idx = c.st.scratch.get<uint32_t>("bk_badidx", nbad);
@@ -1058,7 +1067,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
                 double *Tbad = c.dev("bk_Tbad", (size_t)dt * ldbad);
                 launch_permute_cols(c.st, K, ldq, Qbad, ldbad, ds, d_idx, nbad, false);
                 mat_apply(m, to_t_transpose, Qbad, ldbad, nbad, Tbad, ldbad);
-                launch_permute_cols(c.st, Tbad, ldbad, T, ldq, dt, d_idx, nbad, true);
+                launch_permute_cols(c.st, Tbad, ldbad, T2, ldq, dt, d_idx, nbad, true);
             }
         } else {
             bool any_early = false;
@@ -1072,10 +1081,10 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
     progress_check(snoop, 0.93);
     // m >= n: T = A Q (m x q): U = T E S^-1, V = Q E.   n > m: T^T = A^T Q (n x q): U = Q E, V = T E S^-1.
     if (rows_ge) {
-        ritz_finish(c, K, ldq, q, ds, T, ldq, dt, t_sharded, k, v, s, u);
+        ritz_finish(c, K, ldq, q, ds, Tfin, ldq, dt, t_sharded, k, v, s, u);
         pca_dev_swap(c.st); // side S = cols: it holds V
     } else {
-        ritz_finish(c, K, ldq, q, ds, T, ldq, dt, t_sharded, k, u, s, v);
+        ritz_finish(c, K, ldq, q, ds, Tfin, ldq, dt, t_sharded, k, u, s, v);
     }
     progress_check(snoop, 1.0);
     return SCANRS_OK;

@@ -11,6 +11,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a stuck test (a device call that never returns) must fail with a stack dump, not hold the whole run: pytest-timeout is
+    # part of the image; the longest test (the 30 M-cell shard) takes about a minute
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 900.0
 
 
 @pytest.fixture(scope="session")
