@@ -525,7 +525,8 @@ def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_
     per (outer vector, visit) dealt first come first served with materialized weights, and the L2-blocked gather over the
     nonzeros no visit had room for, on two streams) against the plain gather kernel and the oracle: shapes around the slot
     (32) / workgroup (256) / tile edges, empty vectors, dense spots that fill the overflow part, matrices with no overflow at
-    all, with and without the rank-r offset, panel widths 16 .. 104 (other widths fall through to path 2)."""
+    all, with and without the rank-r offset, panel widths 16 .. 104 in one launch, wider ones in equal column chunks (105: 2 x 54,
+    230: 3 x 78), narrower ones through the gather kernels."""
     rng = np.random.default_rng(31 + storage)
     for rows, cols, fill in ((1, 1, 1.0), (31, 95, 0.5), (32, 96, 0.3), (33, 97, 0.9), (257, 200, 0.05), (700, 1000, 0.03),
                              (97, 5000, 0.02), (2000, 193, 0.2), (300, 400, 0.004)):
@@ -549,7 +550,7 @@ def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_
                 g1.set_offset(u, v)
                 g3.set_offset(u, v)
                 ref_m = so.LowRankOffset(o, u, v)
-            for l in (16, 17, 50, 100, 104, 105, 8):
+            for l in (16, 17, 50, 100, 104, 105, 230, 8):
                 q = rng.standard_normal((cols, l))
                 a1, a3, ref = g1.dot(q), g3.dot(q), ref_m.dot(q)
                 assert_close(a3, ref, rtol=1e-10, atol=1e-9)
