@@ -904,12 +904,15 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
             } else {
                 orth_block(i - 1);
             }
-            if (n_early && i - 1 <= n_early) {
-                SCANRS_HIP(hipEventRecord(ev_pass.e, c.s)); // after the pass that wrote T block i-1
-                project_block_early(i - 1);
-            }
         }
         mat_apply(m, !to_t_transpose, Yi, ldy, b, P, ldb);
+        if (i >= 2 && n_early && i - 1 <= n_early) {
+            // behind BOTH passes of this iteration: the projection GEMM then shares the device with the chain of small kernels that
+            // orthonormalises the panel (and with the start of the next product, whose workgroups take their items dynamically)
+            // instead of with the overflow gather's tail, which the product waits for
+            SCANRS_HIP(hipEventRecord(ev_pass.e, c.s));
+            project_block_early(i - 1);
+        }
         if (trace_on()) { // separate the wait for the two passes from the factorization in the trace
             Tick tw("  passes (wait)");
             c.sync();
