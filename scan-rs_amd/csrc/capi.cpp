@@ -143,16 +143,14 @@ Storage::~Storage() {
         (void)hipStreamDestroy(stream);
     }
 }
-// Four streams per handle, three priorities where the device has them: the main stream (sparse products: the persistent tile
-// kernel must get its CUs first) above the overflow gather (fills the registers the tile kernel leaves; the product waits for
-// it) above the two auxiliary streams (dense work nothing waits for until the end of the iterations). With two levels the lower
-// two share one.
+// Four streams per handle: the main stream (sparse products: the persistent tile kernel must get its CUs first) at the default
+// priority, the overflow gather (fills the registers the tile kernel leaves) and the two auxiliary streams (dense work nothing
+// waits for until the end of the iterations) at the lowest.
 static int stream_priority(int level) {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest); // numerically greatest <= least
-    if (level == 0) return greatest;
-    if (level == 2 || least - greatest < 2) return least;
-    return (least + greatest) / 2;
+    (void)level;
+    return least;
 }
 hipStream_t Storage::aux() {
     if (!overlap) return stream;
@@ -317,7 +315,7 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
     st->storage = storage;
     // a blocking stream: legacy null-stream copies (ours and the host program's, e.g. torch's default
     // stream that produced a device-resident input) stay ordered with the kernels launched here
-    SCANRS_HIP(hipStreamCreateWithPriority(&st->stream, hipStreamDefault, stream_priority(0)));
+    SCANRS_HIP(hipStreamCreate(&st->stream));
     st->scratch.stream = st->stream;
     SparseCopy &cp = st->primary;
     cp.n_outer = storage == SCANRS_CSR ? rows : cols;

@@ -854,10 +854,15 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
         hipEvent_t e = nullptr;
         Ev() { SCANRS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); }
         ~Ev() { (void)hipEventDestroy(e); }
-    } ev_pass, ev_proj, ev_aux;
-    std::vector<Ev> ev_k(n_iter); // K block i is in place (main stream)
+    };
+    // one event object per iteration and purpose: an event is never recorded again while a wait on its previous record may still be queued
+    std::vector<Ev> ev_k(n_iter);    // K block i is in place (main stream)
+    std::vector<Ev> ev_pass(n_iter); // both passes of iteration i are done (main stream)
+    std::vector<Ev> ev_aux(n_iter);  // the Gram-Schmidt chain queued in iteration i is done (auxiliary stream)
+    std::vector<Ev> ev_proj(n_iter); // the projection queued in iteration i is done (projection stream)
+    int last_aux = -1, last_proj = -1;
     std::vector<char> projected(n_iter, 0);
-    auto project_block_early = [&](uint32_t j) { // T block j (written by the pass just queued on the main stream) is ready at ev_pass
+    auto project_block_early = [&](uint32_t j, uint32_t it) { // queued in iteration `it`: T block j is ready at ev_pass[it]
         const uint32_t nr = (j + 1) * b;
         std::vector<double> W;
         if (!dv) {
@@ -867,13 +872,13 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
         }
         StreamSwap sw(c.st, c.st.aux2());
         Ctx cx(m);
-        SCANRS_HIP(hipStreamWaitEvent(cx.s, ev_pass.e, 0));
+        SCANRS_HIP(hipStreamWaitEvent(cx.s, ev_pass[it].e, 0));
         if (!block0_copied) {
             launch_copy_cols(cx.st, T, ldq, T2, ldq, dt, b);
             block0_copied = true;
         }
         if (dv) { // the coefficients of block j: finished on the auxiliary stream (ev_aux was recorded behind them)
-            SCANRS_HIP(hipStreamWaitEvent(cx.s, ev_aux.e, 0));
+            SCANRS_HIP(hipStreamWaitEvent(cx.s, ev_aux[it].e, 0));
             launch_gemm_nn(cx.st, T, ldq, nr, cfull_d + (size_t)j * b, ldq, b, dt, 1.0, 0.0, nullptr, 0, T2 + (size_t)j * b, ldq);
         } else {
             char key[32];
@@ -882,7 +887,8 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
             cx.h2d(dW, W.data(), W.size());
             launch_gemm_nn(cx.st, T, ldq, nr, dW, b, b, dt, 1.0, 0.0, nullptr, 0, T2 + (size_t)j * b, ldq);
         }
-        SCANRS_HIP(hipEventRecord(ev_proj.e, cx.s));
+        SCANRS_HIP(hipEventRecord(ev_proj[it].e, cx.s));
+        last_proj = (int)it;
         projected[j] = 1;
     };
     for (uint32_t i = 0; i < n_iter; i++) {
@@ -900,7 +906,8 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
                 Ctx cx(m);
                 SCANRS_HIP(hipStreamWaitEvent(cx.s, ev_k[i - 1].e, 0));
                 orth_block_dev(cx, i - 1);
-                SCANRS_HIP(hipEventRecord(ev_aux.e, cx.s));
+                SCANRS_HIP(hipEventRecord(ev_aux[i].e, cx.s));
+                last_aux = (int)i;
             } else {
                 orth_block(i - 1);
             }
@@ -910,8 +917,8 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
             // behind BOTH passes of this iteration: the projection GEMM then shares the device with the chain of small kernels that
             // orthonormalises the panel (and with the start of the next product, whose workgroups take their items dynamically)
             // instead of with the overflow gather's tail, which the product waits for
-            SCANRS_HIP(hipEventRecord(ev_pass.e, c.s));
-            project_block_early(i - 1);
+            SCANRS_HIP(hipEventRecord(ev_pass[i].e, c.s));
+            project_block_early(i - 1, i);
         }
         if (trace_on()) { // separate the wait for the two passes from the factorization in the trace
             Tick tw("  passes (wait)");
@@ -938,7 +945,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
     {
         Tick tk("bk: orth(K)");
         if (dv) {
-            if (next_block > 1) SCANRS_HIP(hipStreamWaitEvent(c.s, ev_aux.e, 0)); // the blocks done beside the passes
+            if (last_aux >= 0) SCANRS_HIP(hipStreamWaitEvent(c.s, ev_aux[last_aux].e, 0)); // the blocks done beside the passes (one stream: the last record covers them all)
             for (uint32_t i = next_block; i < n_iter; i++) orth_block_dev(c, i);
             // the one look at what the device-side factorizations did, together with the coefficients
             std::vector<int> ctl(2 * (size_t)od.used);
@@ -1059,7 +1066,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
             if (!block0_copied) launch_copy_cols(c.st, T, ldq, T2, ldq, dt, b);
             bool any_early = false;
             for (uint32_t j = 1; j < n_iter; j++) any_early = any_early || projected[j];
-            if (any_early) SCANRS_HIP(hipStreamWaitEvent(c.s, ev_proj.e, 0)); // the last early GEMM (they are ordered on their stream)
+            if (any_early && last_proj >= 0) SCANRS_HIP(hipStreamWaitEvent(c.s, ev_proj[last_proj].e, 0)); // the last early GEMM (they are ordered on their stream)
             Tfin = T2;
             if (!bad.empty()) {
                 const uint32_t nbad = (uint32_t)bad.size(), ldbad = even_up(nbad);
@@ -1075,7 +1082,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
         } else {
             bool any_early = false;
             for (uint32_t j = 1; j < n_iter; j++) any_early = any_early || projected[j];
-            if (any_early) SCANRS_HIP(hipStreamWaitEvent(c.s, ev_proj.e, 0)); // they read T, which is overwritten now
+            if (any_early && last_proj >= 0) SCANRS_HIP(hipStreamWaitEvent(c.s, ev_proj[last_proj].e, 0)); // they read T, which is overwritten now
             mat_apply(m, to_t_transpose, K, ldq, q, T, ldq);
         }
         c.sync();

@@ -15,6 +15,13 @@ def pytest_configure(config):
     # part of the image; the longest test (the 30 M-cell shard) takes about a minute
     if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
         config.option.timeout = 900.0
+        config.option.timeout_method = "thread"  # a call stuck inside the library never returns to the interpreter: only a watchdog thread can end it
+    # `kill -USR1 <pid>` (or `timeout -s USR1 ...`) dumps every thread's Python stack, also while the main thread sits in a C call
+    import faulthandler
+    import signal
+
+    if hasattr(signal, "SIGUSR1"):
+        faulthandler.register(signal.SIGUSR1, all_threads=True, chain=False)
 
 
 @pytest.fixture(scope="session")
