@@ -716,6 +716,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
                 (void)hipStreamSynchronize(st.stream);
                 if (st.aux_stream) (void)hipStreamSynchronize(st.aux_stream);
                 if (st.aux2_stream) (void)hipStreamSynchronize(st.aux2_stream);
+                if (st.ov_stream) (void)hipStreamSynchronize(st.ov_stream);
             }
         }
     } drain{c.st};
