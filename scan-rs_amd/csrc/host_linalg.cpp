@@ -352,6 +352,31 @@ bool sym_eig_topk(const double *a_in, int n, int k, double *w, double *z) {
         t_last = now;
     };
     std::vector<double> A(a_in, a_in + (size_t)n * n);
+    // Work on A / 2^e with 2^e ~ max |a_ij| (exact: a power of two) and hand the eigenvalues back times 2^e: the squared norms of
+    // the inverse iteration underflow for matrices of entries below ~1e-150 (and overflow above ~1e150) otherwise.
+    double amax = 0.0;
+    for (double x : A) amax = std::max(amax, std::fabs(x));
+    if (!std::isfinite(amax)) return false;
+    if (amax == 0.0) { // the zero matrix: every orthonormal set is an eigenbasis
+        for (int j = 0; j < k; j++) w[j] = 0.0;
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < k; j++) z[(size_t)i * k + j] = i == j ? 1.0 : 0.0;
+        return true;
+    }
+    int scale_exp = 0;
+    if (amax > 0.0) {
+        (void)std::frexp(amax, &scale_exp);
+        if (scale_exp != 0)
+            for (double &x : A) x = std::ldexp(x, -scale_exp);
+    }
+    struct Rescale { // on every way out
+        double *w;
+        int k, e;
+        ~Rescale() {
+            if (e != 0)
+                for (int j = 0; j < k; j++) w[j] = std::ldexp(w[j], e);
+        }
+    } rescale{w, k, scale_exp};
     std::vector<double> d(n), e(n, 0.0), tau(n, 0.0);
     std::vector<double> V((size_t)n * n, 0.0);
     std::vector<double> p(n), v(n), vn(n), pn(n);

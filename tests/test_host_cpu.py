@@ -295,6 +295,31 @@ def test_host_sym_eig_topk(sa):
     assert np.max(np.abs(g @ z - z * w)) < 1e-12 * ws[0]
 
 
+def test_host_sym_eig_topk_bisection_edge_cases(sa):
+    """k <= n / 4 takes the k largest eigenvalues by bisection on Sturm counts (host_linalg.cpp): exactly repeated values,
+    indefinite matrices, a diagonal and a zero matrix, the smallest sizes the branch sees."""
+    rng = np.random.default_rng(8)
+    for n, k in ((4, 1), (8, 2), (40, 10), (101, 25)):
+        q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        for lam in (np.concatenate([[5.0] * (k + 1), rng.random(n - k - 1)]),          # the top k + 1 values equal
+                    np.concatenate([np.linspace(3.0, 1.0, k), -np.linspace(0.5, 9.0, n - k)]),  # indefinite, |negative| larger
+                    np.sort(rng.standard_normal(n))[::-1] * 1e-150,                     # tiny scale
+                    np.sort(rng.standard_normal(n))[::-1] * 1e+150):                    # huge scale
+            g = (q * lam) @ q.T
+            g = (g + g.T) / 2
+            w, z = sa.host_sym_eig_topk(g, k)
+            ws = np.sort(lam)[::-1][:k]
+            scale = np.max(np.abs(lam))
+            assert np.max(np.abs(w - ws)) <= 1e-12 * scale, (n, k)
+            assert np.max(np.abs(z.T @ z - np.eye(k))) < 1e-10
+            assert np.max(np.abs(g @ z - z * w)) <= 1e-11 * scale
+        d = np.diag(np.arange(n, 0, -1, dtype=np.float64))
+        w, z = sa.host_sym_eig_topk(d, k)
+        assert np.array_equal(w, np.arange(n, n - k, -1, dtype=np.float64))
+        w, z = sa.host_sym_eig_topk(np.zeros((n, n)), k)
+        assert np.all(w == 0.0) and np.max(np.abs(z.T @ z - np.eye(k))) < 1e-12
+
+
 def test_sym_eig_topk_does_not_depend_on_the_thread_count():
     """The tridiagonalisation sums its partial products in four fixed slots whether one thread or a team walks them
     (host_linalg.cpp): replicated ranks, hosts with fewer cores and a dismissed team all get bit-identical factors."""
