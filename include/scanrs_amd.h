@@ -332,6 +332,11 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *   "slice_walk" (1)    Ix1 products / moments on the copy with few, long vectors stage the inner-indexed arrays in LDS slices
  *   "spmv_lds" (1)      Ix1 products on the copy with many short vectors stage the vector in LDS parts
  *   "overlap" (1)       small dense work of the solvers runs on a second stream beside the sparse passes
+ *   "col_moments" (1)   mean_var_axis / sum of a log-normalized map (scale factors on the summed-over axis, then a logarithm):
+ *                       walk the copy whose outer vectors are the summed-over axis — a table of the map at counts 1..8 per outer
+ *                       vector instead of one logarithm per nonzero, sums scattered into LDS as 64-bit fixed point (order-
+ *                       independent, so bit-reproducible). Taken when that copy exists and the matrix is large; 2: whenever
+ *                       eligible; 0: never. Results agree with the ordinary pass to ~1e-13 relative.
  *   "device_factor" (1) svd_bk: the b x b Cholesky factors of CholeskyQR and the coefficient bookkeeping of qr(K) stay on the
  *                       device (no host round trip per orthonormalisation; falls back to the host path by itself when a
  *                       factorization does not converge within the queued passes); 0: host factorizations

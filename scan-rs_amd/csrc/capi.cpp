@@ -32,10 +32,21 @@ uint32_t next_map_op_id() {
     return next.fetch_add(1, std::memory_order_relaxed);
 }
 
-bool trace_on() {
+// SCANRS_TRACE=1: phase timings (with the synchronisations they need); SCANRS_TRACE=2: stage markers only — one line per host
+// step of the solvers, nothing synchronised: where a call that does not return is standing.
+static int trace_level() {
     static int v = -1;
-    if (v < 0) v = getenv("SCANRS_TRACE") ? 1 : 0;
-    return v == 1;
+    if (v < 0) {
+        const char *e = getenv("SCANRS_TRACE");
+        v = !e ? 0 : (e[0] == '2' ? 2 : 1);
+    }
+    return v;
+}
+bool trace_on() { return trace_level() == 1; }
+void stage_mark(const char *what, long a, long b) {
+    if (trace_level() != 2) return;
+    fprintf(stderr, "[scanrs stage] %s %ld %ld\n", what, a, b);
+    fflush(stderr);
 }
 
 template <typename F>
@@ -431,13 +442,28 @@ static void log_normalize_impl(scanrs_mat *m, double umi_count_sum, int log_fn, 
 static void axis_sums(scanrs_mat *m, int axis, int mode, double *d_sum, double *d_sumsq) {
     Storage &st = *m->st;
     const bool outer_view_rows = axis == 1;
-    SparseCopy &cp = copy_outer_view_rows(m, outer_view_rows);
-    const DevMap map = m->dev_map(outer_view_rows);
-    launch_row_reduce(st, cp, map, mode, nullptr, d_sum, d_sumsq);
+    // From the copy whose outer vectors are the SUMMED-OVER axis when the map allows it (kernels.hip, col_moments_kernel: a
+    // per-outer table instead of one logarithm per nonzero) and that copy exists already; else the ordinary pass over the copy
+    // whose outer vectors are the slices.
+    bool done = false;
+    if (st.col_moments && mode != 0) {
+        const bool other_outer_rows = (!outer_view_rows) != m->transposed;
+        const bool exists = other_outer_rows == (st.storage == SCANRS_CSR) || st.has_other;
+        if (exists) {
+            SparseCopy &co = copy_outer_view_rows(m, !outer_view_rows);
+            if (st.col_moments == 2 || co.nnz >= st.blocked_min_nnz) done = launch_col_moments(st, co, m->dev_map(!outer_view_rows), mode, d_sum, d_sumsq);
+        }
+    }
+    SparseCopy &cp = done ? copy_outer_view_rows(m, !outer_view_rows) : copy_outer_view_rows(m, outer_view_rows);
+    if (!done) {
+        const DevMap map = m->dev_map(outer_view_rows);
+        launch_row_reduce(st, cp, map, mode, nullptr, d_sum, d_sumsq);
+    }
+    const uint64_t n_out = done ? cp.n_inner : cp.n_outer;
     const bool contraction_sharded = outer_view_rows ? cols_sharded(m) : rows_sharded(m);
     if (contraction_sharded) {
-        allreduce_f64(st, d_sum, cp.n_outer);
-        if (mode == 2) allreduce_f64(st, d_sumsq, cp.n_outer);
+        allreduce_f64(st, d_sum, n_out);
+        if (mode == 2) allreduce_f64(st, d_sumsq, n_out);
     }
 }
 // shape()[axis] as the reference's mean_axis divides by (sqz/src/mat.rs:274), global when sharded
@@ -457,6 +483,7 @@ static void set_offset_dev(scanrs_mat *m, uint32_t rank, std::shared_ptr<DevBuf<
 static void scale_and_center_impl(scanrs_mat *m, int axis, const double *given_scaling) {
     // sqz/src/mat.rs:986-1001
     Tick tk("normalize: scale_and_center");
+    stage_mark("scale_and_center");
     if (axis != 0 && axis != 1) fail(SCANRS_ERR_ARGUMENT, "axis must be 0 or 1");
     if (m->off_rank) fail(SCANRS_ERR_ARGUMENT, "matrix already carries a low-rank offset");
     Storage &st = *m->st;
@@ -972,7 +999,9 @@ int scanrs_pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_ite
                   const scanrs_snoop *snoop, double *u, double *s, double *v) {
     return guard([&] {
         if (!m || !s) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        stage_mark("pca_bk enter");
         pca_bk(m, k, k_multiplier, n_iter, seed, omega, snoop, u, s, v);
+        stage_mark("pca_bk leave");
     });
 }
 int scanrs_pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, uint64_t seed, const double *omega,
@@ -1206,6 +1235,8 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.spmv_lds = value != 0.0;
         } else if (k == "overlap") {
             st.overlap = value != 0.0;
+        } else if (k == "col_moments") {
+            st.col_moments = (int)value;
         } else if (k == "device_factor") {
             st.device_factor = value != 0.0;
         } else if (k == "d2h_threads") {

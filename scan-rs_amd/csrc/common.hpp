@@ -32,6 +32,7 @@ namespace scanrs {
 
 // SCANRS_TRACE=1: wall-clock of host-side phases on stderr (diagnostics only)
 bool trace_on();
+void stage_mark(const char *what, long a = 0, long b = 0); // SCANRS_TRACE=2: a line on stderr, no synchronisation
 struct Tick {
     const char *what;
     std::chrono::steady_clock::time_point t0;
@@ -159,6 +160,7 @@ struct SparseCopy {
     DevBuf<Item> items;
     DevBuf<MultiRow> multi;
     uint32_t n_items = 0, n_multi = 0, n_slab = 0;
+    uint32_t max_value = 0;  // largest count (0: not computed yet; counts are >= 1) — bound of the mapped values for col_moments_kernel
     DevBuf<uint32_t> bounds; // L2-blocked gather: offset of the first nonzero >= b*1024 within each outer vector
     // L2-blocked gather, launch order: outer vectors by descending length (longest first) and the sorted lengths
     // on the host (how many vectors are "hot" for a given step count is a binary search)
@@ -254,6 +256,7 @@ struct Storage {
     const int *skip_flag = nullptr;       // device flag the dense kernels launched now test first (nonzero: return at once) — set around the queued passes of a device-side orthonormalisation
     uint64_t orth_fallbacks = 0;          // orthonormalisations that ended in the host Gram-Schmidt for rank-deficient panels (solver.cpp)
     uint64_t bk_host_retries = 0;         // svd_bk calls that fell back from the device-side factorizations to the host path (scanrs_mat_get_counter)
+    int col_moments = 1;                  // per-axis sums of a log-normalized map from the copy whose OUTER vectors are summed over (per-cell table + LDS fixed-point scatter) when eligible; 0: always the ordinary pass
     int device_factor = 1;                // svd_bk: CholeskyQR factors and the coefficient bookkeeping on the device, no host round trip per orthonormalisation (0: host)
     unsigned d2h_threads = 4;             // host threads that empty the pinned ring of a large result download
     double reuse_cmax = 1e5;              // svd_bk: coefficient bound above which a projection column is recomputed directly
@@ -370,6 +373,7 @@ void compact_nonzeros(Storage &st, SparseCopy &cp);
 
 // ---- host_linalg.cpp --------------------------------------------------------------------------
 // Upper Cholesky G = R^T R of an n x n SPD matrix (row-major, in place: upper triangle = R). false if not SPD.
+bool launch_col_moments(Storage &st, SparseCopy &cp, const DevMap &map, int mode, double *out_sum, double *out_sumsq);
 bool chol_rinv_ok(uint32_t n);
 void launch_chol_rinv(Storage &st, const double *G, uint32_t n, uint64_t rows, int pass, bool check_only, int *ctl, double *Rinv, double *info);
 void launch_absmax_flag(Storage &st, const double *C, uint32_t count, double limit, int *ctl, double *info);

@@ -2117,6 +2117,218 @@ void launch_fill_f64(Storage &st, double *p, uint64_t n, double v) {
     hipLaunchKernelGGL(fill_kernel, grid1(n, 256), dim3(256), 0, st.stream, p, n, v);
     SCANRS_HIP(hipGetLastError());
 }
+// ---- per-INNER-position sums of mapped values from the copy whose outer vectors are the summed-over axis ----------------------
+// The moments of normalize() (sum and sum of squares of log(1 + x s_c) per gene over the cells) walk the gene-major copy and
+// pay one f64 logarithm per nonzero (5.9 ms at 10^9 nonzeros: the pass is bound by that arithmetic, not by its 8 B per
+// nonzero). On the CELL-major copy the logarithm's argument depends on the count and the outer vector only, and 99.9 % of
+// the counts are at most 8: a wave evaluates a cell's eight values once and every nonzero is a lookup — but the sums belong
+// to the inner positions, i.e. they are scattered. They are collected in LDS (a workgroup owns a range of 8192 inner positions
+// and a block of cells; the nonzeros of a cell inside the range are a contiguous run: bounds table) as 64-bit FIXED-POINT
+// numbers with integer atomics: integer addition is associative, so the result does not depend on the order in which the waves
+// arrive (float atomics would make it depend on timing), and with the scale chosen per launch from a bound of the values
+// (col_moments_plan) a workgroup's sums cannot overflow and round each term below 2^-30 of the largest value; the partial sums
+// of the workgroups are added in double, in workgroup order.
+constexpr uint32_t CM_RANGE_SHIFT = 13; // inner positions per range: 8192 x 2 x 8 B = 128 KB of LDS
+constexpr uint32_t CM_TAB = 8;          // counts 1 .. 8 come from the per-cell table
+constexpr uint32_t CM_NV = 4;           // cells per wave and trip (their bounds, their segments' loads side by side)
+template <int MODE>
+__global__ __launch_bounds__(1024) void col_moments_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                           const uint32_t *__restrict__ values, const uint32_t *__restrict__ bounds, uint32_t nb,
+                                                           uint64_t n_outer, uint64_t cells_per_wg, uint32_t n_inner, DevMap map, double scale1,
+                                                           double scale2, unsigned long long *__restrict__ slab) {
+    extern __shared__ unsigned long long cm_acc[]; // [inner position of the range][MODE]
+    const uint32_t range = blockIdx.y, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const uint32_t g0 = range << CM_RANGE_SHIFT, ng = min(1u << CM_RANGE_SHIFT, n_inner - g0);
+    const uint32_t tiles_per_range = (1u << CM_RANGE_SHIFT) >> BT_SHIFT;
+    const uint32_t b0 = range * tiles_per_range, b1 = min(nb, b0 + tiles_per_range);
+    for (uint32_t i = tid; i < ng * MODE; i += blockDim.x) cm_acc[i] = 0ull;
+    __syncthreads();
+    const uint64_t c_begin = (uint64_t)wg * cells_per_wg, c_end = min(n_outer, c_begin + cells_per_wg);
+    for (uint64_t c4 = c_begin + (uint64_t)wave * CM_NV; c4 < c_end; c4 += (uint64_t)n_waves * CM_NV) {
+        uint32_t len_l = 0, blo = 0, bhi = 0;
+        if (lane < CM_NV && c4 + lane < c_end) {
+            const uint32_t *bd = bounds + (c4 + lane) * (nb + 1);
+            const uint32_t o0 = bd[b0];
+            len_l = bd[b1] - o0;
+            const uint64_t base = indptr[c4 + lane] + o0;
+            blo = (uint32_t)base;
+            bhi = (uint32_t)(base >> 32);
+        }
+        // lanes 8 r .. 8 r + 7: the chain at counts 1 .. 8 of cell r of this trip
+        double tab = 0.0;
+        if (lane < CM_NV * CM_TAB && c4 + lane / CM_TAB < c_end) tab = eval_map(map, (lane % CM_TAB) + 1u, (uint32_t)(c4 + lane / CM_TAB), 0u);
+        uint32_t start[CM_NV + 1];
+        uint64_t base[CM_NV];
+        start[0] = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < CM_NV; r++) {
+            start[r + 1] = start[r] + rdlane(len_l, r);
+            base[r] = ((uint64_t)rdlane(bhi, r) << 32) | rdlane(blo, r);
+        }
+        const uint32_t total = start[CM_NV];
+        for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
+            const uint32_t p = q0 + lane;
+            const bool on = p < total;
+            uint32_t r = 0;
+            uint64_t a = base[0] + p;
+#pragma unroll
+            for (uint32_t rr = 1; rr < CM_NV; rr++)
+                if (p >= start[rr]) {
+                    r = rr;
+                    a = base[rr] + (p - start[rr]);
+                }
+            uint32_t g = 0, cnt = 1;
+            if (on) {
+                g = indices[a] - g0;
+                cnt = values[a];
+            }
+            double v = __shfl(tab, (int)(r * CM_TAB + min(cnt, CM_TAB) - 1u)); // every lane takes part in the exchange
+            if (on) {
+                if (cnt > CM_TAB) v = eval_map(map, cnt, (uint32_t)(c4 + r), 0u);
+                atomicAdd(&cm_acc[(size_t)g * MODE], (unsigned long long)__double2ll_rn(v * scale1));
+                if (MODE == 2) atomicAdd(&cm_acc[(size_t)g * MODE + 1], (unsigned long long)__double2ll_rn(v * v * scale2));
+            }
+        }
+    }
+    __syncthreads();
+    unsigned long long *dst = slab + ((size_t)range * gridDim.x + wg) * ((size_t)MODE << CM_RANGE_SHIFT);
+    for (uint32_t i = tid; i < ng * MODE; i += blockDim.x) dst[i] = cm_acc[i];
+}
+// the partial sums of the workgroups, added in double in workgroup order
+template <int MODE>
+__global__ void col_moments_finish_kernel(const unsigned long long *__restrict__ slab, uint32_t n_wg, uint32_t n_inner, double inv1, double inv2,
+                                          double *__restrict__ out_sum, double *__restrict__ out_sumsq) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_inner) return;
+    const uint32_t range = g >> CM_RANGE_SHIFT, gi = g & ((1u << CM_RANGE_SHIFT) - 1u);
+    double s1 = 0.0, s2 = 0.0;
+    for (uint32_t w = 0; w < n_wg; w++) {
+        const unsigned long long *src = slab + ((size_t)range * n_wg + w) * ((size_t)MODE << CM_RANGE_SHIFT) + (size_t)gi * MODE;
+        s1 += (double)(long long)src[0];
+        if (MODE == 2) s2 += (double)(long long)src[1];
+    }
+    out_sum[g] = s1 * inv1;
+    if (MODE == 2 && out_sumsq) out_sumsq[g] = s2 * inv2;
+}
+__global__ void max_u32_kernel(const uint32_t *__restrict__ v, uint64_t n, uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) m = max(m, v[i]);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63u) == 0) atomicMax(out, m);
+}
+// [0] = smallest, [1] = largest value as order-preserving bit patterns of non-negative doubles; [2] != 0: a negative or non-finite value
+__global__ void minmax_nonneg_kernel(const double *__restrict__ v, uint64_t n, unsigned long long *__restrict__ out) {
+    unsigned long long lo = ~0ull, hi = 0ull;
+    int bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const double x = v[i];
+        if (!(x >= 0.0) || !isfinite(x)) {
+            bad = 1;
+        } else {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+            lo = b < lo ? b : lo;
+            hi = b > hi ? b : hi;
+        }
+    }
+    atomicMin(&out[0], lo);
+    atomicMax(&out[1], hi);
+    if (bad) atomicMax(&out[2], 1ull);
+}
+
+// Can the per-inner sums of `map` over `cp` (outer = the summed-over axis) take col_moments_kernel? Every link must be a
+// ScaleAxis over the OUTER position with non-negative finite factors or a logarithm (then the value is non-negative and grows
+// with the count and with the factors: its largest possible value follows from the largest count and the largest factors).
+// Returns the fixed-point scales in s1 / s2; false = use the ordinary pass.
+static bool col_moments_plan(Storage &st, SparseCopy &cp, const DevMap &map, int mode, uint32_t n_wg, double &s1, double &s2) {
+    bool has_log = false;
+    for (int i = 0; i < map.n; i++) {
+        const int k = map.ops[i].kind;
+        if (k == OP_SCALE_AXIS) {
+            if (!map.ops[i].a_outer) return false;
+        } else if (k == OP_LN_1P || k == OP_LOG2_1P || k == OP_LOG10_1P) {
+            has_log = true;
+        } else {
+            return false;
+        }
+    }
+    if (!has_log || cp.n_outer == 0 || cp.n_inner == 0) return false;
+    if (cp.max_value == 0) { // structure only: once per copy
+        uint32_t *d = st.scratch.get<uint32_t>("cm_maxv", 1);
+        SCANRS_HIP(hipMemsetAsync(d, 0, 4, st.stream));
+        hipLaunchKernelGGL(max_u32_kernel, dim3(2048), dim3(256), 0, st.stream, cp.values.p, cp.nnz, d);
+        uint32_t h = 0;
+        SCANRS_HIP(hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, st.stream));
+        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        cp.max_value = std::max(h, 1u);
+    }
+    double x = (double)cp.max_value;
+    unsigned long long *d = st.scratch.get<unsigned long long>("cm_minmax", 3);
+    for (int i = 0; i < map.n; i++) {
+        const int k = map.ops[i].kind;
+        if (k == OP_SCALE_AXIS) {
+            const unsigned long long init[3] = {~0ull, 0ull, 0ull};
+            SCANRS_HIP(hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, st.stream));
+            hipLaunchKernelGGL(minmax_nonneg_kernel, dim3(512), dim3(256), 0, st.stream, map.ops[i].a, cp.n_outer, d);
+            unsigned long long h[3];
+            SCANRS_HIP(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, st.stream));
+            SCANRS_HIP(hipStreamSynchronize(st.stream));
+            if (h[2]) return false;
+            double amax;
+            memcpy(&amax, &h[1], 8);
+            x *= amax;
+        } else if (k == OP_LN_1P) {
+            x = std::log1p(x);
+        } else if (k == OP_LOG2_1P) {
+            x = std::log2(1.0 + x);
+        } else {
+            x = std::log10(1.0 + x);
+        }
+        if (!std::isfinite(x)) return false;
+    }
+    // a workgroup adds at most cells_per_wg values of at most x (x^2): keep the sums below 2^62 and the terms' rounding at 2^-30 of x or finer
+    const double cells = std::ceil((double)cp.n_outer / n_wg);
+    const double b1 = std::max(x, 1e-300) * cells * 1.0001, b2 = std::max(x * x, 1e-300) * cells * 1.0001;
+    const int e1 = 62 - (int)std::ceil(std::log2(b1)), e2 = 62 - (int)std::ceil(std::log2(b2));
+    if (e1 > 1000 || e2 > 1000 || (double)e1 + std::log2(std::max(x, 1e-300)) < 30.0 || (mode == 2 && (double)e2 + std::log2(std::max(x * x, 1e-300)) < 30.0)) return false;
+    s1 = std::ldexp(1.0, e1);
+    s2 = std::ldexp(1.0, e2);
+    return true;
+}
+static uint32_t ensure_bounds(Storage &st, SparseCopy &cp);
+// out_sum[i] (and out_sumsq[i]) over the outer vectors of cp, per INNER position i. false: not eligible (nothing was launched).
+bool launch_col_moments(Storage &st, SparseCopy &cp, const DevMap &map, int mode, double *out_sum, double *out_sumsq) {
+    if (mode != 1 && mode != 2) return false;
+    int dev = 0, n_cu = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    const uint32_t n_ranges = (uint32_t)((cp.n_inner + (1ull << CM_RANGE_SHIFT) - 1) >> CM_RANGE_SHIFT);
+    if (cp.n_inner >= (1ull << 31) || n_ranges > 65535u) return false;
+    // one workgroup per CU and range at a time; the cells dealt over as many workgroups as keep every CU busy for all ranges
+    const uint32_t n_wg = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_cu, (cp.n_outer + 63) / 64));
+    double s1 = 0.0, s2 = 0.0;
+    if (!col_moments_plan(st, cp, map, mode, n_wg, s1, s2)) return false;
+    const uint32_t nb = ensure_bounds(st, cp);
+    const uint64_t cells_per_wg = (cp.n_outer + n_wg - 1) / n_wg;
+    unsigned long long *slab = st.scratch.get<unsigned long long>("cm_slab", (size_t)n_ranges * n_wg * ((size_t)mode << CM_RANGE_SHIFT));
+    const size_t shmem = ((size_t)mode << CM_RANGE_SHIFT) * 8;
+    ProfScope ps(st, mode == 2 ? "col_moments" : "col_sums", (double)cp.nnz * 8.0 + (double)cp.n_outer * (n_ranges + 1) * 4.0);
+    if (mode == 2) {
+        SCANRS_HIP(hipFuncSetAttribute((const void *)col_moments_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((col_moments_kernel<2>), dim3(n_wg, n_ranges), dim3(1024), shmem, st.stream, cp.indptr.p, cp.indices.p, cp.values.p, cp.bounds.p, nb,
+                           cp.n_outer, cells_per_wg, (uint32_t)cp.n_inner, map, s1, s2, slab);
+        hipLaunchKernelGGL((col_moments_finish_kernel<2>), dim3((unsigned)((cp.n_inner + 255) / 256)), dim3(256), 0, st.stream, slab, n_wg, (uint32_t)cp.n_inner,
+                           1.0 / s1, 1.0 / s2, out_sum, out_sumsq);
+    } else {
+        SCANRS_HIP(hipFuncSetAttribute((const void *)col_moments_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL((col_moments_kernel<1>), dim3(n_wg, n_ranges), dim3(1024), shmem, st.stream, cp.indptr.p, cp.indices.p, cp.values.p, cp.bounds.p, nb,
+                           cp.n_outer, cells_per_wg, (uint32_t)cp.n_inner, map, s1, s2, slab);
+        hipLaunchKernelGGL((col_moments_finish_kernel<1>), dim3((unsigned)((cp.n_inner + 255) / 256)), dim3(256), 0, st.stream, slab, n_wg, (uint32_t)cp.n_inner,
+                           1.0 / s1, 1.0 / s2, out_sum, (double *)nullptr);
+    }
+    SCANRS_HIP(hipGetLastError());
+    return true;
+}
+
 void launch_finish_moments(Storage &st, const double *sum, const double *sumsq, uint64_t n, double m, int given_scale,
                            const double *scale_in, double *neg_mean_over_scale, double *inv_scale, double *scale_out) {
     if (n == 0) return;

@@ -594,7 +594,9 @@ static void jacobi_svd_tall(std::vector<double> A, size_t rows, int n, std::vect
 static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint64_t ds, const double *T, uint32_t ldt,
                         uint64_t dt, bool t_sharded, uint32_t k, double *hS, double *hSigma, double *hT) {
     std::vector<double> G;
+    stage_mark("ritz gram");
     gram_host(c, T, ldt, q, T, ldt, q, dt, t_sharded, G);
+    stage_mark("ritz gram done");
     for (uint32_t i = 0; i < q; i++) // symmetrise against rounding asymmetry
         for (uint32_t j = i + 1; j < q; j++) {
             const double a = 0.5 * (G[(size_t)i * q + j] + G[(size_t)j * q + i]);
@@ -681,7 +683,9 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
     c.h2d(dEs, Es.data(), Es.size());
     launch_gemm_nn(c.st, T, ldt, q, dEs, k, k, dt, 1.0, 0.0, nullptr, 0, dT, ldk);
     {
+        stage_mark("ritz factors sync");
         c.sync();
+        stage_mark("ritz factors synced");
         Tick tk("ritz: download of the factors");
         if (hS) download_panel(c, dS, ldk, ds, k, hS); // null: the caller keeps the result in HBM (scanrs_pca_result_device)
         if (hT) download_panel(c, dT, ldk, dt, k, hT);
@@ -894,6 +898,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
     };
     for (uint32_t i = 0; i < n_iter; i++) {
         Tick tk("bk: iteration");
+        stage_mark("bk iteration", i);
         // m >= n: B = qr((A B)^T A)^T .Q  (bk_svd.rs:94);  n > m: T = (B A)^T; B = qr(A T).Q^T  (bk_svd.rs:122-123)
         double *Yi = (reuse && i >= 1) ? T + (size_t)(i - 1) * b : Y;
         const uint32_t ldy = (reuse && i >= 1) ? ldq : ldb;
@@ -935,8 +940,11 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
             SCANRS_HIP(hipEventRecord(ev_k[i].e, c.s));
             if (trace_on())
                 c.sync();
-            else if (i >= 1)
+            else if (i >= 1) {
+                stage_mark("bk pacing wait", i - 1);
                 SCANRS_HIP(hipEventSynchronize(ev_k[i - 1].e));
+                stage_mark("bk pacing done", i - 1);
+            }
         } else {
             c.sync();
         }
@@ -954,7 +962,9 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
             SCANRS_HIP(hipMemcpy2DAsync(cfull.data(), (size_t)q * 8, cfull_d, (size_t)ldq * 8, (size_t)q * 8, q, hipMemcpyDeviceToHost, c.s));
             SCANRS_HIP(hipMemcpyAsync(ctl.data(), od.ctl, ctl.size() * sizeof(int), hipMemcpyDeviceToHost, c.s));
             SCANRS_HIP(hipMemcpyAsync(info.data(), od.info, info.size() * sizeof(double), hipMemcpyDeviceToHost, c.s));
+            stage_mark("bk verdict sync");
             c.sync();
+            stage_mark("bk verdict synced");
             for (uint32_t sl = 0; sl < od.used; sl++) {
                 if (ctl[2 * sl + 1] == 2) fail(SCANRS_ERR_NUMERICAL, "orthonormalisation: non-finite Gram matrix");
                 if (ctl[2 * sl] != 1 || ctl[2 * sl + 1] != 0) {
@@ -1086,7 +1096,9 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
             if (any_early && last_proj >= 0) SCANRS_HIP(hipStreamWaitEvent(c.s, ev_proj[last_proj].e, 0)); // they read T, which is overwritten now
             mat_apply(m, to_t_transpose, K, ldq, q, T, ldq);
         }
+        stage_mark("bk projection sync");
         c.sync();
+        stage_mark("bk projection synced");
     }
     Tick tk_fin("bk: ritz_finish");
     progress_check(snoop, 0.93);

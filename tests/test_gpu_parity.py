@@ -121,6 +121,66 @@ def test_mat_stats_golden(sa, golden, storage):
     assert a.t().shape() == [5, 4]
 
 
+def test_axis_moments_from_the_summed_over_copy(sa):
+    """mean_var_axis / sum_axis of a log-normalized map through col_moments_kernel (the copy whose OUTER vectors are the
+    summed-over axis: a table of the map at counts 1..8 per outer vector, sums scattered into LDS as 64-bit fixed point) against
+    the ordinary pass and the oracle: several ranges of 8192 inner positions, empty vectors on both sides, counts far above 8,
+    every logarithm, two scale links, both storages and the transposed view; maps it must refuse (a factor on the other axis,
+    a negative factor, no logarithm) fall back to the ordinary pass and give the same numbers. Bit-reproducible."""
+    rng = np.random.default_rng(23)
+    for rows, cols, fill in ((40, 17000, 0.02), (9000, 300, 0.05), (257, 8193, 0.1), (3, 5, 0.9)):
+        dense = random_counts(rng, rows, cols, fill, 6)
+        big = rng.random((rows, cols)) < 0.002
+        dense[big] = rng.integers(9, 70000, size=int(big.sum()))  # counts far above the table
+        dense[:, rng.random(cols) < 0.1] = 0
+        dense[rng.random(rows) < 0.1, :] = 0
+        for storage in (so.CSR, so.CSC):
+            for axis in (0, 1):  # mean_var_axis(axis) sums over dense.shape[axis] positions: ScaleAxis(axis) holds one factor for each of them
+                other = axis
+                n_other = dense.shape[axis]
+                f1, f2 = rng.random(n_other) * 3.0, rng.random(n_other) + 0.5
+                for fn_g, fn_o in ((sa.FN_LOG2_1P, so.OP_LOG2_1P), (sa.FN_LN_1P, so.OP_LN_1P), (sa.FN_LOG10_1P, so.OP_LOG10_1P)):
+                    res = {}
+                    for mode in (2, 0):
+                        g, o = pair(sa, dense, storage)
+                        g.set_option("col_moments", mode)
+                        g.dot(np.ones((cols, 1)))
+                        g.rdot(np.ones((1, rows)))  # both copies exist
+                        g.compose_scale_axis(other, f1).compose_scale_axis(other, f2).apply(fn_g)
+                        g.profile_enable(True)
+                        g.profile_reset()
+                        res[mode] = (g.mean_var_axis(axis), g.sum_axis(axis), g.t().mean_var_axis(1 - axis))
+                        prof = g.profile_get()
+                        g.profile_enable(False)
+                        assert (("col_moments" in prof and "col_sums" in prof) if mode == 2 else ("col_moments" not in prof)), (mode, list(prof))
+                        if mode == 2:
+                            again = g.mean_var_axis(axis)
+                            assert np.array_equal(again[0], res[2][0][0]) and np.array_equal(again[1], res[2][0][1])
+                    o = o.compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=other, a=f1)).compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=other, a=f2)).apply(fn_o)
+                    mo, vo = o.mean_var_axis(axis)
+                    for (m_, v_), s_, (mt, vt) in (res[2], res[0]):
+                        assert_close(m_, mo, rtol=1e-12, atol=1e-13)
+                        assert_close(v_, vo, rtol=1e-10, atol=1e-12)
+                        assert_close(mt, mo, rtol=1e-12, atol=1e-13)
+                    assert_close(res[2][1], res[0][1], rtol=1e-12, atol=1e-12)
+    # maps the scatter form refuses: same numbers through the ordinary pass
+    dense = random_counts(rng, 300, 9000, 0.05, 6)
+    for make in (lambda g: g.compose_scale_axis(0, rng.random(300) + 0.1).apply(sa.FN_LOG2_1P),     # factor per slice, not per summed-over position
+                 lambda g: g.compose_scale_axis(1, -(np.arange(9000) % 2) * 0.5 + 0.4).apply(sa.FN_LOG2_1P),  # negative factors
+                 lambda g: g.compose_scale_axis(1, np.arange(9000) + 1.0)):                          # no logarithm
+        out = []
+        state = rng.bit_generator.state
+        for mode in (2, 0):
+            rng.bit_generator.state = state
+            g, _ = pair(sa, dense, so.CSR)
+            g.set_option("col_moments", mode)
+            g.dot(np.ones((9000, 1)))
+            g.rdot(np.ones((1, 300)))
+            make(g)
+            out.append(g.mean_var_axis(1))
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_mat_misc_center_golden(sa, golden):
     g = golden["mat_misc"]
     for storage in (so.CSR, so.CSC):
