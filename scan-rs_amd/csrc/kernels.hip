@@ -2136,12 +2136,12 @@ __global__ __launch_bounds__(1024) void col_moments_kernel(const uint64_t *__res
                                                            const uint32_t *__restrict__ values, const uint32_t *__restrict__ bounds, uint32_t nb,
                                                            uint64_t n_outer, uint64_t cells_per_wg, uint32_t n_inner, DevMap map, double scale1,
                                                            double scale2, unsigned long long *__restrict__ slab) {
-    extern __shared__ unsigned long long cm_acc[]; // [inner position of the range][MODE]
+    extern __shared__ unsigned long long cm_acc[]; // [MODE][inner position of the range]: one array per moment (interleaved, the 16-byte stride put 64 lanes on 16 bank groups)
     const uint32_t range = blockIdx.y, wg = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, n_waves = blockDim.x >> 6;
     const uint32_t g0 = range << CM_RANGE_SHIFT, ng = min(1u << CM_RANGE_SHIFT, n_inner - g0);
     const uint32_t tiles_per_range = (1u << CM_RANGE_SHIFT) >> BT_SHIFT;
     const uint32_t b0 = range * tiles_per_range, b1 = min(nb, b0 + tiles_per_range);
-    for (uint32_t i = tid; i < ng * MODE; i += blockDim.x) cm_acc[i] = 0ull;
+    for (uint32_t i = tid; i < (MODE << CM_RANGE_SHIFT); i += blockDim.x) cm_acc[i] = 0ull;
     __syncthreads();
     const uint64_t c_begin = (uint64_t)wg * cells_per_wg, c_end = min(n_outer, c_begin + cells_per_wg);
     for (uint64_t c4 = c_begin + (uint64_t)wave * CM_NV; c4 < c_end; c4 += (uint64_t)n_waves * CM_NV) {
@@ -2166,33 +2166,51 @@ __global__ __launch_bounds__(1024) void col_moments_kernel(const uint64_t *__res
             base[r] = ((uint64_t)rdlane(bhi, r) << 32) | rdlane(blo, r);
         }
         const uint32_t total = start[CM_NV];
-        for (uint32_t q0 = 0; q0 < total; q0 += 64u) {
-            const uint32_t p = q0 + lane;
-            const bool on = p < total;
-            uint32_t r = 0;
-            uint64_t a = base[0] + p;
+        // four strides of 64 nonzeros per trip: their index and count loads go out together (one stride per trip made the walk a
+        // chain of load latencies: 3.9 ms per pass instead of 2.x)
+        constexpr uint32_t CM_U = 4;
+        for (uint32_t q0 = 0; q0 < total; q0 += 64u * CM_U) {
+            uint32_t g[CM_U], cnt[CM_U], r[CM_U];
+            bool on[CM_U];
 #pragma unroll
-            for (uint32_t rr = 1; rr < CM_NV; rr++)
-                if (p >= start[rr]) {
-                    r = rr;
-                    a = base[rr] + (p - start[rr]);
+            for (uint32_t u = 0; u < CM_U; u++) {
+                const uint32_t p = q0 + 64u * u + lane;
+                on[u] = p < total;
+                r[u] = 0;
+                uint64_t a = base[0] + p;
+#pragma unroll
+                for (uint32_t rr = 1; rr < CM_NV; rr++)
+                    if (p >= start[rr]) {
+                        r[u] = rr;
+                        a = base[rr] + (p - start[rr]);
+                    }
+                g[u] = 0;
+                cnt[u] = 1;
+                if (on[u]) {
+                    g[u] = indices[a] - g0;
+                    cnt[u] = values[a];
                 }
-            uint32_t g = 0, cnt = 1;
-            if (on) {
-                g = indices[a] - g0;
-                cnt = values[a];
             }
-            double v = __shfl(tab, (int)(r * CM_TAB + min(cnt, CM_TAB) - 1u)); // every lane takes part in the exchange
-            if (on) {
-                if (cnt > CM_TAB) v = eval_map(map, cnt, (uint32_t)(c4 + r), 0u);
-                atomicAdd(&cm_acc[(size_t)g * MODE], (unsigned long long)__double2ll_rn(v * scale1));
-                if (MODE == 2) atomicAdd(&cm_acc[(size_t)g * MODE + 1], (unsigned long long)__double2ll_rn(v * v * scale2));
+#pragma unroll
+            for (uint32_t u = 0; u < CM_U; u++) {
+                if (q0 + 64u * u >= total) break; // uniform
+                double v = __shfl(tab, (int)(r[u] * CM_TAB + min(cnt[u], CM_TAB) - 1u)); // every lane takes part in the exchange
+                if (on[u]) {
+                    if (cnt[u] > CM_TAB) v = eval_map(map, cnt[u], (uint32_t)(c4 + r[u]), 0u);
+                    // 0 <= t < 2^51 (col_moments_plan): t + 2^52 holds round-to-nearest(t) in its mantissa — two instructions
+                    // instead of the ~15 of a general f64 -> i64 conversion, which made this loop VALU-bound
+                    atomicAdd(&cm_acc[g[u]], (unsigned long long)__double_as_longlong(v * scale1 + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull);
+                    if (MODE == 2)
+                        atomicAdd(&cm_acc[(1u << CM_RANGE_SHIFT) + g[u]],
+                                  (unsigned long long)__double_as_longlong(v * v * scale2 + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull);
+                }
             }
         }
     }
     __syncthreads();
     unsigned long long *dst = slab + ((size_t)range * gridDim.x + wg) * ((size_t)MODE << CM_RANGE_SHIFT);
-    for (uint32_t i = tid; i < ng * MODE; i += blockDim.x) dst[i] = cm_acc[i];
+    for (uint32_t i = tid; i < (MODE << CM_RANGE_SHIFT); i += blockDim.x) dst[i] = cm_acc[i];
+    (void)ng;
 }
 // the partial sums of the workgroups, added in double in workgroup order
 template <int MODE>
@@ -2203,9 +2221,9 @@ __global__ void col_moments_finish_kernel(const unsigned long long *__restrict__
     const uint32_t range = g >> CM_RANGE_SHIFT, gi = g & ((1u << CM_RANGE_SHIFT) - 1u);
     double s1 = 0.0, s2 = 0.0;
     for (uint32_t w = 0; w < n_wg; w++) {
-        const unsigned long long *src = slab + ((size_t)range * n_wg + w) * ((size_t)MODE << CM_RANGE_SHIFT) + (size_t)gi * MODE;
+        const unsigned long long *src = slab + ((size_t)range * n_wg + w) * ((size_t)MODE << CM_RANGE_SHIFT) + gi;
         s1 += (double)(long long)src[0];
-        if (MODE == 2) s2 += (double)(long long)src[1];
+        if (MODE == 2) s2 += (double)(long long)src[1u << CM_RANGE_SHIFT];
     }
     out_sum[g] = s1 * inv1;
     if (MODE == 2 && out_sumsq) out_sumsq[g] = s2 * inv2;
@@ -2288,7 +2306,9 @@ static bool col_moments_plan(Storage &st, SparseCopy &cp, const DevMap &map, int
     // a workgroup adds at most cells_per_wg values of at most x (x^2): keep the sums below 2^62 and the terms' rounding at 2^-30 of x or finer
     const double cells = std::ceil((double)cp.n_outer / n_wg);
     const double b1 = std::max(x, 1e-300) * cells * 1.0001, b2 = std::max(x * x, 1e-300) * cells * 1.0001;
-    const int e1 = 62 - (int)std::ceil(std::log2(b1)), e2 = 62 - (int)std::ceil(std::log2(b2));
+    // ... and every term below 2^51 (the kernel's conversion)
+    const int e1 = std::min(62 - (int)std::ceil(std::log2(b1)), 50 - (int)std::ceil(std::log2(std::max(x, 1e-300) * 1.0001)));
+    const int e2 = std::min(62 - (int)std::ceil(std::log2(b2)), 50 - (int)std::ceil(std::log2(std::max(x * x, 1e-300) * 1.0001)));
     if (e1 > 1000 || e2 > 1000 || (double)e1 + std::log2(std::max(x, 1e-300)) < 30.0 || (mode == 2 && (double)e2 + std::log2(std::max(x * x, 1e-300)) < 30.0)) return false;
     s1 = std::ldexp(1.0, e1);
     s2 = std::ldexp(1.0, e2);
