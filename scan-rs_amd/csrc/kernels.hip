@@ -2168,14 +2168,17 @@ __global__ __launch_bounds__(1024) void col_moments_kernel(const uint64_t *__res
         const uint32_t total = start[CM_NV];
         // four strides of 64 nonzeros per trip: their index and count loads go out together (one stride per trip made the walk a
         // chain of load latencies: 3.9 ms per pass instead of 2.x)
-        constexpr uint32_t CM_U = 4;
+        constexpr uint32_t CM_U = 8;
         for (uint32_t q0 = 0; q0 < total; q0 += 64u * CM_U) {
             uint32_t g[CM_U], cnt[CM_U], r[CM_U];
             bool on[CM_U];
 #pragma unroll
             for (uint32_t u = 0; u < CM_U; u++) {
-                const uint32_t p = q0 + 64u * u + lane;
-                on[u] = p < total;
+                const uint32_t p_raw = q0 + 64u * u + lane;
+                on[u] = p_raw < total;
+                // no branch around the loads (a lane past the end re-reads the trip's last nonzero and is masked below): behind a
+                // branch every stride waited for its own index before the next stride's loads went out
+                const uint32_t p = on[u] ? p_raw : total - 1u;
                 r[u] = 0;
                 uint64_t a = base[0] + p;
 #pragma unroll
@@ -2184,12 +2187,8 @@ __global__ __launch_bounds__(1024) void col_moments_kernel(const uint64_t *__res
                         r[u] = rr;
                         a = base[rr] + (p - start[rr]);
                     }
-                g[u] = 0;
-                cnt[u] = 1;
-                if (on[u]) {
-                    g[u] = indices[a] - g0;
-                    cnt[u] = values[a];
-                }
+                g[u] = indices[a] - g0;
+                cnt[u] = values[a];
             }
 #pragma unroll
             for (uint32_t u = 0; u < CM_U; u++) {
