@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-PMC_PROFILE = "r03d_pmc_traffic.json"  # committed PMC passes (separate --pmc runs) the `traffic` field is read from
+PMC_PROFILE = "r03f_pmc_traffic.json"  # committed PMC passes (separate --pmc runs) the `traffic` field is read from
 
 
 def parse():

@@ -4,7 +4,7 @@
 #   usage: tools/profile_round.sh TAG      (e.g. r02a)
 # Counters go in their own runs (rocprofv3 --pmc with --kernel-trace only), the program directly after `--`.
 set -u
-TAG=${1:-r03d}
+TAG=${1:-r03f}
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
