@@ -1216,6 +1216,9 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.tile_b = (uint32_t)value;
         } else if (k == "ov_tile_kb") {
             st.ov_tile_bytes = (size_t)std::max(0.0, value) << 10;
+        } else if (k == "tile_max_overflow") {
+            if (!(value > 0.0) || value > 1.0) fail(SCANRS_ERR_ARGUMENT, "tile_max_overflow must be in (0, 1]");
+            st.tile_max_overflow = value;
         } else if (k == "tile_auto") {
             st.tile_auto = value != 0.0;
         } else if (k == "tile_overlap") {

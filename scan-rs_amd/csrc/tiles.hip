@@ -380,7 +380,9 @@ bool tile_shape_ok(uint32_t K, uint32_t S, uint32_t T, uint32_t B) {
     return ks && B >= 2 && T >= 8 && T <= 24u * K && B * T <= 192;
 }
 
-TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
+// max_overflow > 0: give up (nullptr) when more than that share of the nonzeros would land in the overflow part — known after the
+// counting pass, before anything large is allocated.
+TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_overflow) {
     Tick tick("tile layout build");
     if (!tile_shape_ok(st.tile_k, st.tile_s, st.tile_t, st.tile_b))
         fail(SCANRS_ERR_ARGUMENT, "unsupported tile shape K=%u S=%u T=%u B=%u", st.tile_k, st.tile_s, st.tile_t, st.tile_b);
@@ -432,6 +434,12 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp) {
     SCANRS_HIP(hipMemcpyAsync(&n_ov, ovo.p + n_seg, 8, hipMemcpyDeviceToHost, s));
     SCANRS_HIP(hipStreamSynchronize(s));
     lap("count + scan");
+    if (max_overflow > 0.0 && (double)n_ov > max_overflow * (double)cp.nnz) {
+        if (trace_on())
+            fprintf(stderr, "[scanrs trace] tile layout: %llu outer x %llu inner: %.1f %% of the nonzeros would overflow (limit %.0f %%) -> gather kernels for this orientation\n",
+                    (unsigned long long)cp.n_outer, (unsigned long long)cp.n_inner, 100.0 * (double)n_ov / (double)cp.nnz, 100.0 * max_overflow);
+        return nullptr;
+    }
     tl->prow.alloc(n_rec);
     tl->pcnt.alloc(n_rec);
     tl->pw.alloc(n_rec);
@@ -826,6 +834,9 @@ bool spmm_tiles_auto(Storage &st, SparseCopy &cp, const DevMap &map) {
     if (!st.tile_auto || cp.nnz < std::max<uint64_t>(st.blocked_min_nnz, 1ull << 24)) return false;
     if (((cp.n_outer + st.tile_s - 1) / st.tile_s) * ((cp.n_inner + st.tile_t - 1) / st.tile_t) > 0xFFFFFFFFull) return false; // 32-bit visit index
     if (cp.tiles && cp.tiles->structure_matches(st)) return true; // the weights follow the map in one streaming pass
+    const uint64_t shape_sig = 1ull + st.tile_k + 16ull * st.tile_s + 4096ull * st.tile_t + (1ull << 24) * st.tile_b + (1ull << 32) * st.tile_ku +
+                               (1ull << 34) * (uint64_t)(st.tile_max_overflow * 1000.0);
+    if (cp.tile_rejected_shape == shape_sig) return false; // this shape left too much in the overflow part (below)
     bool seen = cp.tsig_n == map.n;
     for (int i = 0; seen && i < map.n; i++) seen = cp.tsig_id[i] == map.ops[i].id && cp.tsig_outer[i] == map.ops[i].a_outer;
     cp.tsig_n = map.n;
@@ -841,7 +852,21 @@ bool spmm_tiles_auto(Storage &st, SparseCopy &cp, const DevMap &map) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
     const double have = (double)free_b + (cp.tiles ? cp.tiles->bytes() : 0.0); // a stale layout is released first
-    return have > need + 8.0 * (double)(1ull << 30);
+    if (!(have > need + 8.0 * (double)(1ull << 30))) return false;
+    // Build now: the layout is only worth having when few nonzeros miss it. The overflow gather runs at two waves per SIMD
+    // beside the tile kernel and becomes the long pole at about 12 % of the nonzeros; with the heavy-tailed gene profile of
+    // real data (genes detected in most cells: tens of nonzeros per 48-cell tile against 2 positions) the gene-major layout of
+    // a 10^6 x 33 k matrix overflowed by 70 % and its pass took 109 ms against the gather kernels' 39 (tools/pass_bench.py
+    // gene_shape=0.1 shared_profile=1; the cell-major layout of the same matrix: 5.8 %, 19.5 ms). Such an orientation stays on
+    // the gather kernels, and is not tried again until the tile shape changes.
+    cp.tiles.reset();
+    TileLayout *t = tile_layout_build(st, cp, st.tile_max_overflow);
+    if (!t) {
+        cp.tile_rejected_shape = shape_sig;
+        return false;
+    }
+    cp.tiles.reset(t, tile_layout_free);
+    return true;
 }
 
 void launch_gather2d_ov(Storage &st, hipStream_t s, SparseCopy &ov, const double *X, uint32_t ldx, uint32_t l, double *out, uint32_t ldo); // kernels.hip
@@ -851,7 +876,7 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     if ((ldx & 1u) || (ldo & 1u)) fail(SCANRS_ERR_ARGUMENT, "panel leading dimensions must be even");
     if (!cp.tiles || !cp.tiles->structure_matches(st)) {
         cp.tiles.reset(); // free the old layout before the new one is allocated
-        cp.tiles.reset(tile_layout_build(st, cp), tile_layout_free);
+        cp.tiles.reset(tile_layout_build(st, cp, 0.0), tile_layout_free); // forced (spmm_path 3): whatever the overflow
     }
     TileLayout &tl = *cp.tiles;
     if (!tl.weights_match(map)) tile_layout_weights(st, tl, cp, map);

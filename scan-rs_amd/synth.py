@@ -153,7 +153,8 @@ def synth_counts_par(n_cells: int, n_genes: int, density: float, seed: int = 0, 
 
 
 def synth_counts_torch(n_cells: int, n_genes: int, density: float, seed: int, device, cell_begin: int = 0,
-                       cell_end: int | None = None, n_clusters: int = 20, chunk: int = 4096):
+                       cell_end: int | None = None, n_clusters: int = 20, chunk: int = 4096, gene_shape: float = 0.4,
+                       shared_profile: float = 0.0):
     """Device-side generator: returns (indptr int64[n_local+1], indices int32[nnz], values int32[nnz])
     for cells [cell_begin, cell_end) of the global matrix. Every chunk of `chunk` global cells has its own
     generator seed, so any partition of the cells over ranks yields the same global matrix."""
@@ -166,6 +167,12 @@ def synth_counts_torch(n_cells: int, n_genes: int, density: float, seed: int, de
     # Gamma(0.4, scale 2.0): standard gamma * 2 (drawn once, identically on every rank)
     torch.manual_seed(seed)
     rates = torch._standard_gamma(conc) * 2.0
+    if gene_shape != 0.4 or shared_profile > 0.0:
+        # experiments only (tools/pass_bench.py): a heavier-tailed gene profile (Gamma shape below 0.4) and / or a part of it
+        # shared by all clusters — genes detected in most cells, as real data has them; the default model is untouched
+        base = torch._standard_gamma(torch.full((1, n_genes), gene_shape, device=device, dtype=torch.float32))
+        own = torch._standard_gamma(torch.full((n_clusters, n_genes), gene_shape, device=device, dtype=torch.float32))
+        rates = shared_profile * base + (1.0 - shared_profile) * own
     scale = density / float(rates.mean())
     counts_parts, idx_parts, val_parts = [], [], []
     first_chunk = cell_begin // chunk

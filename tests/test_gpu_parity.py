@@ -622,6 +622,44 @@ def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_
                 assert_close(a1, a3, rtol=1e-11, atol=1e-10)
 
 
+def test_auto_path_leaves_a_dense_orientation_to_the_gather_kernels(sa):
+    """Outer vectors with tens of nonzeros per tile (genes detected in most cells) do not fit the two positions per visit of the
+    tile layout: the auto path builds the layout only for the orientation whose overflow stays below `tile_max_overflow` and
+    keeps the gather kernels for the other one (a forced path 3 still takes it); same numbers either way."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(17)
+    cells, genes = 300_000, 3000
+    dense_cols = np.arange(0, genes, 60)  # 50 genes detected in 90 % of the cells, one per 60
+    m = sp.random(cells, genes, 0.01, format="csr", random_state=3, data_rvs=lambda n: rng.integers(1, 6, n)).astype(np.uint32)
+    d = (rng.random((cells, dense_cols.size)) < 0.9)
+    rows, cols = np.nonzero(d)
+    extra = sp.csr_matrix((rng.integers(1, 9, rows.size).astype(np.uint32), (rows, dense_cols[cols])), shape=(cells, genes))
+    m = (m + extra).tocsr()
+    m.sort_indices()
+    assert m.nnz > (1 << 24)
+    g = sa.AdaptiveMat.from_csmat(cells, genes, sa.CSR, m.indptr.astype(np.uint64), m.indices.astype(np.uint32), m.data.astype(np.uint32))
+    ref = sa.AdaptiveMat.from_csmat(cells, genes, sa.CSR, m.indptr.astype(np.uint64), m.indices.astype(np.uint32), m.data.astype(np.uint32))
+    ref.set_spmm_path(2)
+    x = rng.standard_normal((genes, 40))
+    y = rng.standard_normal((40, cells))
+    outs = {}
+    for name, h in (("auto", g), ("gather", ref)):
+        h.profile_enable(True)
+        for _ in range(2):  # the auto path builds a layout on the second sighting of a map
+            outs[name] = (h.dot(x), h.rdot(y))
+        h.profile_reset()
+        outs[name] = (h.dot(x), h.rdot(y))
+        outs[name + "_prof"] = list(h.profile_get())
+        h.profile_enable(False)
+    prof = outs["auto_prof"]
+    assert any(k.startswith("spmm_tile_kernel/long-outer") for k in prof), prof      # outer = cells: sparse vectors, tile layout
+    assert not any(k.startswith("spmm_tile_kernel/short-outer") for k in prof), prof  # outer = genes: 50 dense vectors, refused
+    assert any(k.startswith("spmm_gather2d_kernel<1>/short-outer") for k in prof), prof
+    for a, b in zip(outs["auto"], outs["gather"]):
+        assert np.max(np.abs(a - b)) <= 1e-11 * np.max(np.abs(b))
+
+
 def test_lds_staged_product_whole_pca_and_remap(sa):
     """The whole PCA through the hybrid product agrees with the default path and is bitwise repeatable; re-normalizing the
     handle (new map ids) rebuilds the tile layout instead of reusing stale weights."""

@@ -14,9 +14,14 @@ from scanrs_amd.synth import synth_counts_torch
 
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 genes, l = 33_000, int(sys.argv[2]) if len(sys.argv) > 2 else 100
-configs = sys.argv[3:] or ["0"]
+kw = {k: float(v) for k, v in (a.split("=") for a in sys.argv[3:] if "=" in a)}  # gene_shape=0.1 shared_profile=1: a heavy-tailed model
+configs = [a for a in sys.argv[3:] if "=" not in a] or ["0"]
 dev = torch.device("cuda", 0)
-ip, ix, vv = synth_counts_torch(cells, genes, 0.03, 0, dev)
+ip, ix, vv = synth_counts_torch(cells, genes, 0.03, 0, dev, **kw)
+if kw:
+    per_gene = torch.bincount(ix.long(), minlength=genes).float() / cells
+    print("gene detection rates: max %.2f, genes above 10 %%: %d, their share of the nonzeros: %.0f %%" % (
+        float(per_gene.max()), int((per_gene > 0.1).sum()), 100 * float(per_gene[per_gene > 0.1].sum() / per_gene.sum())), flush=True)
 nnz = int(ip[-1].item())
 xg = torch.randn(genes, l, device=dev, dtype=torch.float64)
 xc = torch.randn(cells, l, device=dev, dtype=torch.float64)
