@@ -317,7 +317,7 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *   "tile_k" (2)        hybrid product: record positions per (outer vector, visit): 2, 3 or 4
  *   "tile_s" (32)       hybrid product: outer vectors per wave (32, or 28 with tile_k 2 or 4: 168 instead of 184 registers per tile wave)
  *   "ov_tile_kb" (0)    hybrid product: panel slice per step of the overflow gather (0 = twice l2_tile_kb)
- *   "tile_max_overflow" (0.12)  auto path: an orientation whose tile layout would leave more than this share of the nonzeros to
+ *   "tile_max_overflow" (0.35)  auto path: an orientation whose tile layout would leave more than this share of the nonzeros to
  *                       the overflow gather (dense outer vectors: genes detected in most cells) stays on the gather kernels
  *   "tile_ku" (1)       hybrid product, tile_k 2: 1 = one of the two positions takes only count-1 nonzeros, whose rows are added
  *                       without a weight (maps whose value at count 1 is an outer factor times an inner factor); 0 = none

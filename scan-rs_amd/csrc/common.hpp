@@ -243,7 +243,7 @@ struct Storage {
     uint32_t tile_ku = 1;                 // ... unit positions among them (0 or 1; used with tile_k 2): count-1 nonzeros, added without a weight
     uint32_t tile_t = 48, tile_b = 4;     // ... panel rows per tile (<= 24 tile_k) and tile buffers in the LDS ring (tile_t * tile_b <= 192)
     size_t ov_tile_bytes = 0;             // hybrid product: panel slice per step of the overflow gather (0 = twice l2_tile_bytes)
-    double tile_max_overflow = 0.12;      // auto path: an orientation whose layout would leave more than this share of the nonzeros to the overflow gather stays on the gather kernels
+    double tile_max_overflow = 0.35;      // auto path: an orientation whose layout would leave more than this share of the nonzeros to the overflow gather stays on the gather kernels
     int tile_auto = 1;                    // auto path may use the hybrid product (0: only spmm_path 3 does)
     int tile_hint = 0;                    // > 0 while a solver that repeats the same products is running (svd_bk, svd_rand)
     int tile_overlap = 1;                 // hybrid product: 1 = the overflow gather runs beside the tile kernel (own stream); 0 = after it (measurement)

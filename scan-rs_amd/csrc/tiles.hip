@@ -853,8 +853,9 @@ bool spmm_tiles_auto(Storage &st, SparseCopy &cp, const DevMap &map) {
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
     const double have = (double)free_b + (cp.tiles ? cp.tiles->bytes() : 0.0); // a stale layout is released first
     if (!(have > need + 8.0 * (double)(1ull << 30))) return false;
-    // Build now: the layout is only worth having when few nonzeros miss it. The overflow gather runs at two waves per SIMD
-    // beside the tile kernel and becomes the long pole at about 12 % of the nonzeros; with the heavy-tailed gene profile of
+    // Build now: the layout is only worth having when not too many nonzeros miss it (the overflow gather runs at two waves
+    // per SIMD beside the tile kernel). At 27-28 % overflow (100 k x 20 k at 5 % density, both orientations) the hybrid product
+    // still wins, 50 against 61 ms per PCA; with the heavy-tailed gene profile of
     // real data (genes detected in most cells: tens of nonzeros per 48-cell tile against 2 positions) the gene-major layout of
     // a 10^6 x 33 k matrix overflowed by 70 % and its pass took 109 ms against the gather kernels' 39 (tools/pass_bench.py
     // gene_shape=0.1 shared_profile=1; the cell-major layout of the same matrix: 5.8 %, 19.5 ms). Such an orientation stays on
