@@ -122,7 +122,8 @@ def _par_chunk(args):
     return counts, gene[first].astype(np.uint32), rng.geometric(0.6, size=int(first.sum())).astype(np.uint32)
 
 
-def synth_counts_par(n_cells: int, n_genes: int, density: float, seed: int = 0, n_clusters: int = 20, chunk: int = 8192, workers: int = 0):
+def synth_counts_par(n_cells: int, n_genes: int, density: float, seed: int = 0, n_clusters: int = 20, chunk: int = 8192, workers: int = 0,
+                     _in_helper: bool = False):
     """The model of `synth_counts_fast` with one generator per chunk of `chunk` cells (seed sequence [seed, chunk id]), so the
     chunks can be drawn by a pool of processes: the million-cell fixture input (10^9 nonzeros) in well under a minute on a
     many-core host instead of five. Returns (indptr uint64[n_cells + 1], indices uint32[nnz], values uint32[nnz]), cell-major,
@@ -141,6 +142,12 @@ def synth_counts_par(n_cells: int, n_genes: int, density: float, seed: int = 0, 
             for ci, c0 in enumerate(range(0, n_cells, chunk))]
     workers = workers or min(len(jobs), max(1, (os.cpu_count() or 1) - 1), 64)
     if workers > 1 and len(jobs) > 1:
+        if not _in_helper:
+            # Never fork a pool from the calling process: in a `-m gpu` test run it has initialised HIP and carries the runtime's
+            # threads, and a forked child can inherit a lock whose owner does not exist in it (pool.map then never returns —
+            # the intermittent stall of round 3). The pool lives in a FRESH interpreter that has only numpy loaded; the arrays
+            # come back through .npy files in a scratch directory.
+            return _par_in_subprocess(n_cells, n_genes, density, seed, n_clusters, chunk, workers)
         with mp.get_context("fork").Pool(workers) as pool:
             parts = pool.map(_par_chunk, jobs, chunksize=1)
     else:
@@ -150,6 +157,24 @@ def synth_counts_par(n_cells: int, n_genes: int, density: float, seed: int = 0, 
     indices = np.concatenate([p[1] for p in parts])
     values = np.concatenate([p[2] for p in parts])
     return indptr, indices, values
+
+
+def _par_in_subprocess(n_cells, n_genes, density, seed, n_clusters, chunk, workers):
+    """`synth_counts_par` in a child interpreter started with subprocess (this file run as a script: numpy only, no HIP)."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    out = tempfile.mkdtemp(prefix="scanrs_synth_", dir=base)
+    try:
+        subprocess.run([sys.executable, os.path.abspath(__file__), "par", str(n_cells), str(n_genes), repr(float(density)), str(seed),
+                        str(n_clusters), str(chunk), str(workers), out], check=True, timeout=3600)
+        return tuple(np.load(os.path.join(out, name + ".npy")) for name in ("indptr", "indices", "values"))
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def synth_counts_torch(n_cells: int, n_genes: int, density: float, seed: int, device, cell_begin: int = 0,
@@ -201,3 +226,16 @@ def synth_counts_torch(n_cells: int, n_genes: int, density: float, seed: int, de
     indptr = torch.zeros(counts.shape[0] + 1, dtype=torch.int64, device=device)
     indptr[1:] = torch.cumsum(counts, dim=0)
     return indptr, torch.cat(idx_parts), torch.cat(val_parts)
+
+
+if __name__ == "__main__":  # helper mode of synth_counts_par: `synth.py par cells genes density seed clusters chunk workers outdir`
+    import os
+    import sys
+
+    if len(sys.argv) == 10 and sys.argv[1] == "par":
+        a = sys.argv
+        ip_, ix_, vv_ = synth_counts_par(int(a[2]), int(a[3]), float(a[4]), int(a[5]), int(a[6]), int(a[7]), int(a[8]), _in_helper=True)
+        for name_, arr_ in (("indptr", ip_), ("indices", ix_), ("values", vv_)):
+            np.save(os.path.join(a[9], name_ + ".npy"), arr_)
+    else:
+        raise SystemExit("usage: synth.py par cells genes density seed clusters chunk workers outdir")
