@@ -344,6 +344,7 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *                       factorization does not converge within the queued passes); 0: host factorizations
  *   "d2h_threads" (4)   host threads that empty the pinned ring of a large result download
  *   "reuse_cmax" (1e5)  svd_bk: coefficient bound above which a projection column is recomputed directly
+ *   "sync_timeout_s" (120)  PROCESS-WIDE (same as scanrs_set_global_option): deadline of every host-side wait for the device
  * Unknown keys return SCANRS_ERR_ARGUMENT. The only environment variables the library reads are the diagnostics
  * SCANRS_TRACE and SCANRS_TRACE_EIG (phase timings on stderr). */
 int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value);
@@ -354,7 +355,15 @@ int scanrs_mat_get_counter(scanrs_mat *m, const char *key, uint64_t *value);
  *   "h5_threads" (8)               threads that inflate the chunks of a large filtered HDF5 read
  *   "eig_threads" (4)              host team of the Rayleigh-Ritz eigensolver for matrices of 768+ rows (1, 2 or 4)
  *   "knn_exhaustive" (0)           1: never use the bf16-MFMA filter of scanrs_knn*
- *   "knn_filter_min_points" (32768), "knn_ratio" (4), "knn_stats" (0)   tuning / statistics of that filter */
+ *   "knn_filter_min_points" (32768), "knn_ratio" (4), "knn_stats" (0)   tuning / statistics of that filter
+ *   "sync_timeout_s" (120)         BOUNDED WAITS: no call of this library blocks on the device without a deadline. Every wait for
+ *                                  a stream or an event (and every barrier between the shard threads of scanrs_multi_*) is a poll
+ *                                  with this deadline in seconds; when it passes, the call returns SCANRS_ERR_DEVICE and
+ *                                  scanrs_last_error() names the wait (function, file:line), the calling thread's last solver
+ *                                  stages and which of the handle's streams (main / aux / aux2 / overflow) still had work; the
+ *                                  same report and the whole stage ring go to stderr. The handle must then be freed (its queued
+ *                                  work never finished); start over in a fresh process — a process whose device stopped
+ *                                  answering cannot be repaired from inside, and must not exec() another program either. */
 int scanrs_set_global_option(const char *key, double value);
 /* Arithmetic of the large sparse products: 0 (default) = f64 throughout, the reference's arithmetic; 1 = opt-in fast
  * mode: the dense panel is rounded to f32 before it is gathered (half the on-chip bytes per nonzero), products and
@@ -370,6 +379,12 @@ int scanrs_mat_sync(scanrs_mat *m);
  * 1 Cholesky failed after 12 shifts, 2 non-finite input; err = max |g - I|; shift = diagonal shift used. For tests. */
 int scanrs_mat_chol_rinv(scanrs_mat *m, const double *g, uint32_t n, uint64_t rows, int pass, double *rinv, int *done, int *status,
                          double *err, double *shift);
+
+/* Diagnostics of the bounded waits (no device needed): runs the library's wait loop on an event that is never signalled and
+ * returns SCANRS_ERR_DEVICE once `timeout_s` seconds have passed, with the report a real stuck wait leaves behind. */
+int scanrs_debug_wait_never(double timeout_s);
+/* ... and the barrier between the shard threads of the single-process multi-GPU form, entered by one thread of `world` alone */
+int scanrs_debug_barrier_alone(uint32_t world);
 
 /* ---- host-side dense helpers (no device needed; used by the solvers where the reference calls
  * LAPACK on k x k matrices, exposed so the CPU test-suite can check them) ------------------------- */

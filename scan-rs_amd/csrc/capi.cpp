@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -43,10 +44,132 @@ static int trace_level() {
     return v;
 }
 bool trace_on() { return trace_level() == 1; }
+
+// the calling thread's last stage marks (what a timed-out wait reports)
+namespace {
+struct StageRing {
+    static constexpr int N = 16;
+    struct Rec {
+        char what[40];
+        long a, b;
+        std::chrono::steady_clock::time_point t;
+    } rec[N];
+    unsigned n = 0;
+};
+thread_local StageRing tl_stages;
+thread_local const Storage *tl_handle = nullptr;
+std::atomic<double> g_sync_timeout_s{120.0};
+} // namespace
 void stage_mark(const char *what, long a, long b) {
+    StageRing::Rec &r = tl_stages.rec[tl_stages.n++ % StageRing::N];
+    strncpy(r.what, what, sizeof(r.what) - 1);
+    r.what[sizeof(r.what) - 1] = 0;
+    r.a = a;
+    r.b = b;
+    r.t = std::chrono::steady_clock::now();
     if (trace_level() != 2) return;
     fprintf(stderr, "[scanrs stage] %s %ld %ld\n", what, a, b);
     fflush(stderr);
+}
+double sync_timeout_s() { return g_sync_timeout_s.load(std::memory_order_relaxed); }
+void set_sync_timeout_s(double s) { g_sync_timeout_s.store(s, std::memory_order_relaxed); }
+CurrentHandle::CurrentHandle(const Storage *st) : prev(tl_handle) { tl_handle = st; }
+CurrentHandle::~CurrentHandle() { tl_handle = prev; }
+
+// Poll `query` (hipSuccess: done, hipErrorNotReady: not yet, anything else: a device error) until the deadline. Spins for the
+// first 200 us — the waits on the solvers' critical path end within that — then sleeps 20 us, then 200 us per round.
+template <typename Q>
+static hipError_t poll_until(Q &&query, double timeout_s, double *waited_s) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = query();
+        if (e != hipErrorNotReady) return e;
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el > timeout_s) {
+            if (waited_s) *waited_s = el;
+            return hipErrorNotReady;
+        }
+        if (el < 200e-6)
+            std::this_thread::yield();
+        else
+            std::this_thread::sleep_for(std::chrono::microseconds(el < 5e-3 ? 20 : 200));
+    }
+}
+static const char *base_name(const char *file) {
+    const char *b = strrchr(file, '/');
+    return b ? b + 1 : file;
+}
+// message + stderr dump of a wait that ran into its deadline; `busy` = query of one named stream (may be null on the CPU test path)
+static void timeout_report(const char *kind, const char *func, const char *file, int line, double waited, hipStream_t waited_stream) {
+    char where[160] = "";
+    if (tl_handle) { // which of the handle's streams still have work (hipStreamQuery never blocks)
+        const Storage &st = *tl_handle;
+        struct {
+            const char *name;
+            hipStream_t s;
+        } streams[] = {{"main", st.stream}, {"aux", st.aux_stream}, {"aux2", st.aux2_stream}, {"overflow", st.ov_stream}};
+        size_t off = 0;
+        for (auto &x : streams) {
+            if (!x.s) continue;
+            const hipError_t q = hipStreamQuery(x.s);
+            off += (size_t)snprintf(where + off, sizeof(where) - off, "%s%s%s=%s", off ? ", " : "", x.s == waited_stream ? "*" : "", x.name,
+                                    q == hipSuccess ? "idle" : q == hipErrorNotReady ? "busy" : hipGetErrorString(q));
+            if (off >= sizeof(where)) break;
+        }
+        (void)hipGetLastError();
+    }
+    char stages[200] = "";
+    {
+        size_t off = 0;
+        const unsigned n = tl_stages.n, first = n > 4 ? n - 4 : 0;
+        const auto now = std::chrono::steady_clock::now();
+        for (unsigned i = first; i < n && off < sizeof(stages); i++) {
+            const StageRing::Rec &r = tl_stages.rec[i % StageRing::N];
+            off += (size_t)snprintf(stages + off, sizeof(stages) - off, "%s%s(%ld) -%.1fs", off ? " > " : "", r.what, r.a,
+                                    std::chrono::duration<double>(now - r.t).count());
+        }
+    }
+    fprintf(stderr, "[scanrs] device wait timed out: %s in %s (%s:%d) after %.1f s; streams: %s; last stages: %s\n", kind, func, base_name(file), line,
+            waited, where[0] ? where : "n/a", stages[0] ? stages : "none");
+    { // the whole ring on stderr
+        const unsigned n = tl_stages.n, first = n > StageRing::N ? n - StageRing::N : 0;
+        const auto now = std::chrono::steady_clock::now();
+        for (unsigned i = first; i < n; i++) {
+            const StageRing::Rec &r = tl_stages.rec[i % StageRing::N];
+            fprintf(stderr, "[scanrs]   stage %-36s %ld %ld  %.3f s ago\n", r.what, r.a, r.b, std::chrono::duration<double>(now - r.t).count());
+        }
+        fflush(stderr);
+    }
+    fail(SCANRS_ERR_DEVICE, "device wait timed out after %.1f s (sync_timeout_s): %s in %s (%s:%d); streams: %s; last stages: %s", waited, kind, func,
+         base_name(file), line, where[0] ? where : "n/a", stages[0] ? stages : "none");
+}
+void wait_stream(hipStream_t s, const char *func, const char *file, int line) {
+    double waited = 0.0;
+    const hipError_t e = poll_until([&] { return hipStreamQuery(s); }, sync_timeout_s(), &waited);
+    if (e == hipSuccess) return;
+    if (e == hipErrorNotReady) timeout_report("stream synchronisation", func, file, line, waited, s);
+    fail(SCANRS_ERR_DEVICE, "stream synchronisation failed: %s in %s (%s:%d)", hipGetErrorString(e), func, base_name(file), line);
+}
+void wait_event(hipEvent_t ev, const char *func, const char *file, int line) {
+    double waited = 0.0;
+    const hipError_t e = poll_until([&] { return hipEventQuery(ev); }, sync_timeout_s(), &waited);
+    if (e == hipSuccess) return;
+    if (e == hipErrorNotReady) timeout_report("event wait", func, file, line, waited, nullptr);
+    fail(SCANRS_ERR_DEVICE, "event wait failed: %s in %s (%s:%d)", hipGetErrorString(e), func, base_name(file), line);
+}
+void wait_device(const char *func, const char *file, int line) {
+    // the null stream of a process is ordered behind every blocking stream: querying it covers "everything queued so far"
+    wait_stream(nullptr, func, file, line);
+}
+bool wait_stream_quiet(hipStream_t s) noexcept {
+    const hipError_t e = poll_until([&] { return hipStreamQuery(s); }, sync_timeout_s(), nullptr);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess;
+}
+bool wait_event_quiet(hipEvent_t ev) noexcept {
+    const hipError_t e = poll_until([&] { return hipEventQuery(ev); }, sync_timeout_s(), nullptr);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess;
 }
 
 template <typename F>
@@ -108,7 +231,7 @@ void Profile::end(hipStream_t s) {
 void Profile::resolve() {
     for (auto &r : pending) {
         float ms = 0.f;
-        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+        if (wait_event_quiet(r.b) && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             auto &st = stats[r.name];
             st.launches++;
             st.ms += ms;
@@ -136,21 +259,21 @@ Profile::~Profile() {
 Storage::~Storage() {
     if (host_stage) (void)hipHostFree(host_stage);
     if (aux_stream) {
-        (void)hipStreamSynchronize(aux_stream);
+        (void)wait_stream_quiet(aux_stream);
         (void)hipStreamDestroy(aux_stream);
     }
     if (aux2_stream) {
-        (void)hipStreamSynchronize(aux2_stream);
+        (void)wait_stream_quiet(aux2_stream);
         (void)hipStreamDestroy(aux2_stream);
     }
     if (ov_stream) {
-        (void)hipStreamSynchronize(ov_stream);
+        (void)wait_stream_quiet(ov_stream);
         (void)hipStreamDestroy(ov_stream);
     }
     if (ev_in) (void)hipEventDestroy(ev_in);
     if (ev_ov) (void)hipEventDestroy(ev_ov);
     if (stream) {
-        (void)hipStreamSynchronize(stream);
+        (void)wait_stream_quiet(stream);
         (void)hipStreamDestroy(stream);
     }
 }
@@ -205,7 +328,7 @@ static void allreduce_any(Storage &st, void *d, uint64_t count, int dtype) {
     if (st.shard.comm) {
         comm_allreduce(st, st.shard.comm, d, count, dtype);
     } else if (st.shard.allreduce) {
-        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        SCANRS_SYNC(st.stream);
         if (st.shard.allreduce(st.shard.ctx, d, count, dtype) != 0) fail(SCANRS_ERR_DEVICE, "all-reduce callback failed");
     } else {
         fail(SCANRS_ERR_ARGUMENT, "sharded handle without a transport");
@@ -273,6 +396,7 @@ bool mat_tiles_ready(scanrs_mat *m, bool transpose) {
 
 void mat_apply(scanrs_mat *m, bool transpose, const double *dX, uint32_t ldx, uint32_t l, double *dOut, uint32_t ldo) {
     Storage &st = *m->st;
+    CurrentHandle cur(&st);
     const bool outer_is_view_row = !transpose;
     SparseCopy &cp = copy_outer_view_rows(m, outer_is_view_row);
     DevMap map = m->dev_map(outer_is_view_row);
@@ -307,7 +431,7 @@ void mat_apply(scanrs_mat *m, bool transpose, const double *dX, uint32_t ldx, ui
 static std::shared_ptr<DevBuf<double>> upload_vec(Storage &st, const double *h, size_t n) {
     auto b = std::make_shared<DevBuf<double>>(std::max<size_t>(n, 1));
     if (n) SCANRS_HIP(hipMemcpyAsync(b->p, h, n * 8, hipMemcpyHostToDevice, st.stream));
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SCANRS_SYNC(st.stream);
     return b;
 }
 
@@ -332,19 +456,24 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
     cp.n_outer = storage == SCANRS_CSR ? rows : cols;
     cp.n_inner = storage == SCANRS_CSR ? cols : rows;
     const hipMemcpyKind kind = device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    CurrentHandle cur(st.get());
     cp.indptr.alloc(cp.n_outer + 1);
-    SCANRS_HIP(hipMemcpy(cp.indptr.p, indptr, (cp.n_outer + 1) * 8, kind));
+    // a device-resident input was produced on the caller's streams: the blocking stream of the handle is ordered behind the legacy
+    // null stream (torch's default stream), anything else is the caller's to synchronise before the call
+    SCANRS_HIP(hipMemcpyAsync(cp.indptr.p, indptr, (cp.n_outer + 1) * 8, kind, st->stream));
     uint64_t first = 0, last = 0;
-    SCANRS_HIP(hipMemcpy(&first, cp.indptr.p, 8, hipMemcpyDeviceToHost));
-    SCANRS_HIP(hipMemcpy(&last, cp.indptr.p + cp.n_outer, 8, hipMemcpyDeviceToHost));
+    SCANRS_HIP(hipMemcpyAsync(&first, cp.indptr.p, 8, hipMemcpyDeviceToHost, st->stream));
+    SCANRS_HIP(hipMemcpyAsync(&last, cp.indptr.p + cp.n_outer, 8, hipMemcpyDeviceToHost, st->stream));
+    SCANRS_SYNC(st->stream);
     if (first != 0) fail(SCANRS_ERR_ARGUMENT, "indptr[0] must be 0");
     cp.nnz = last;
     if (cp.nnz && (!indices || !values)) fail(SCANRS_ERR_ARGUMENT, "null indices/values");
     cp.indices.alloc(std::max<uint64_t>(1, cp.nnz));
     cp.values.alloc(std::max<uint64_t>(1, cp.nnz));
     if (cp.nnz) {
-        SCANRS_HIP(hipMemcpy(cp.indices.p, indices, cp.nnz * 4, kind));
-        SCANRS_HIP(hipMemcpy(cp.values.p, values, cp.nnz * 4, kind));
+        SCANRS_HIP(hipMemcpyAsync(cp.indices.p, indices, cp.nnz * 4, kind, st->stream));
+        SCANRS_HIP(hipMemcpyAsync(cp.values.p, values, cp.nnz * 4, kind, st->stream));
+        if (!device_src) SCANRS_SYNC(st->stream); // the caller's host arrays may be pageable and are his again on return
     }
     if (sort_first) sort_outer_vectors(*st, cp);
     uint64_t zeros = 0, bad = 0;
@@ -368,7 +497,7 @@ static uint32_t select_kth(Storage &st, const uint32_t *d, uint64_t n_local, uin
         launch_hist12(st, d, n_local, shifts[pass], (1u << bits[pass]) - 1u, mask, prefix, hist);
         allreduce_u64(st, hist, 4096);
         SCANRS_HIP(hipMemcpyAsync(h.data(), hist, 4096 * 8, hipMemcpyDeviceToHost, st.stream));
-        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        SCANRS_SYNC(st.stream);
         const uint32_t nb = 1u << bits[pass];
         uint32_t bin = 0;
         for (; bin < nb; bin++) {
@@ -403,6 +532,7 @@ static void log_normalize_impl(scanrs_mat *m, double umi_count_sum, int log_fn, 
     if (rows_sharded(m)) fail(SCANRS_ERR_ARGUMENT, "normalisation needs the barcode (column) dimension to be the sharded one");
     Storage &st = *m->st;
     const uint64_t ncols = m->cols();
+    CurrentHandle cur(&st);
     SparseCopy &cp = copy_outer_view_rows(m, false); // outer = view cols (barcodes)
     DevMap raw;
     memset(&raw, 0, sizeof(raw));
@@ -421,7 +551,7 @@ static void log_normalize_impl(scanrs_mat *m, double umi_count_sum, int log_fn, 
     if (size_factors) {
         uint32_t *sf = st.scratch.get<uint32_t>("norm_sf", std::max<uint64_t>(1, ncols));
         if (ncols) SCANRS_HIP(hipMemcpyAsync(sf, size_factors, ncols * 4, hipMemcpyHostToDevice, st.stream));
-        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        SCANRS_SYNC(st.stream);
         norm_counts = sf;
     }
     auto scales = std::make_shared<DevBuf<double>>(std::max<uint64_t>(1, ncols));
@@ -434,13 +564,14 @@ static void log_normalize_impl(scanrs_mat *m, double umi_count_sum, int log_fn, 
     MapOp lg;
     lg.kind = log_fn;
     m->ops.push_back(lg); // .apply(log1p_fn) :177
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SCANRS_SYNC(st.stream);
 }
 
 // per-`axis` sums of mapped values: axis 1 -> per view row, axis 0 -> per view col; reduced across ranks
 // when the summed-over dimension is sharded.
 static void axis_sums(scanrs_mat *m, int axis, int mode, double *d_sum, double *d_sumsq) {
     Storage &st = *m->st;
+    CurrentHandle cur(&st);
     const bool outer_view_rows = axis == 1;
     // From the copy whose outer vectors are the SUMMED-OVER axis when the map allows it (kernels.hip, col_moments_kernel: a
     // per-outer table instead of one logarithm per nonzero) and that copy exists already; else the ordinary pass over the copy
@@ -488,6 +619,7 @@ static void scale_and_center_impl(scanrs_mat *m, int axis, const double *given_s
     if (m->off_rank) fail(SCANRS_ERR_ARGUMENT, "matrix already carries a low-rank offset");
     Storage &st = *m->st;
     const uint64_t n = axis == 1 ? m->rows() : m->cols();     // number of slices
+    CurrentHandle cur(&st);
     const uint64_t other = axis == 1 ? m->cols() : m->rows(); // local length of each slice
     double *sum = st.scratch.get<double>("mom_sum", std::max<uint64_t>(1, n));
     double *sumsq = st.scratch.get<double>("mom_sumsq", std::max<uint64_t>(1, n));
@@ -496,7 +628,7 @@ static void scale_and_center_impl(scanrs_mat *m, int axis, const double *given_s
     if (given_scaling) {
         scale_in = st.scratch.get<double>("mom_scale_in", std::max<uint64_t>(1, n));
         if (n) SCANRS_HIP(hipMemcpyAsync(scale_in, given_scaling, n * 8, hipMemcpyHostToDevice, st.stream));
-        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        SCANRS_SYNC(st.stream);
     }
     auto neg = std::make_shared<DevBuf<double>>(std::max<uint64_t>(1, n));
     auto inv = std::make_shared<DevBuf<double>>(std::max<uint64_t>(1, n));
@@ -513,7 +645,7 @@ static void scale_and_center_impl(scanrs_mat *m, int axis, const double *given_s
         set_offset_dev(m, 1, neg, ones);
     else
         set_offset_dev(m, 1, ones, neg);
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SCANRS_SYNC(st.stream);
 }
 
 static void binom_impl(scanrs_mat *m, int kind) {
@@ -534,7 +666,7 @@ static void binom_impl(scanrs_mat *m, int kind) {
     if (cols_sharded(m)) allreduce_f64(st, tot, 1);
     double total = 0.0;
     SCANRS_HIP(hipMemcpyAsync(&total, tot, 8, hipMemcpyDeviceToHost, st.stream));
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SCANRS_SYNC(st.stream);
     launch_binom_uv(st, kind, n->p, C, rowsum, R, total, pi->p, u->p, v->p);
     MapOp op;
     op.kind = kind;
@@ -543,7 +675,7 @@ static void binom_impl(scanrs_mat *m, int kind) {
     m->ops.clear();
     m->ops.push_back(op); // matrix.set_map(dev_resid_map)
     set_offset_dev(m, 1, u, v);
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SCANRS_SYNC(st.stream);
 }
 
 } // namespace scanrs
@@ -586,7 +718,7 @@ int scanrs_mat_create_adaptive(uint64_t rows, uint64_t cols, int storage, const 
         DevBuf<uint64_t> ip;
         DevBuf<uint32_t> ix, vv;
         decode_adaptive_vectors(vecs, n_vecs, n_inner, ip, ix, vv);
-        SCANRS_HIP(hipDeviceSynchronize());
+        ::scanrs::wait_device(__func__, __FILE__, __LINE__);
         create_common(rows, cols, storage, ip.p, ix.p, vv.p, true, out); // validates ordering, copies into the handle
     });
 }
@@ -688,7 +820,7 @@ static void host_axis_sums(scanrs_mat *m, int axis, int mode, std::vector<double
         s2.resize(n);
         if (n) SCANRS_HIP(hipMemcpyAsync(s2.data(), sumsq, n * 8, hipMemcpyDeviceToHost, st.stream));
     }
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SCANRS_SYNC(st.stream);
 }
 
 int scanrs_mat_center(scanrs_mat *m, int axis, const double *given_means) {
@@ -759,7 +891,7 @@ int scanrs_mat_sum_axis_u32(scanrs_mat *m, int axis, uint32_t *out) {
         uint32_t *d = st.scratch.get<uint32_t>("sum_u32", std::max<uint64_t>(1, cp.n_outer));
         launch_row_reduce(st, cp, raw, 0, d, nullptr, nullptr);
         if (cp.n_outer) SCANRS_HIP(hipMemcpyAsync(out, d, cp.n_outer * 4, hipMemcpyDeviceToHost, st.stream));
-        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        SCANRS_SYNC(st.stream);
     });
 }
 int scanrs_mat_sum_axis_f64(scanrs_mat *m, int axis, double *out) {
@@ -803,7 +935,7 @@ int scanrs_mat_to_dense(scanrs_mat *m, double *out) {
         SparseCopy &cp = copy_outer_view_rows(m, true);
         launch_densify(st, cp, m->dev_map(true), true, C, d);
         SCANRS_HIP(hipMemcpyAsync(out, d, R * C * 8, hipMemcpyDeviceToHost, st.stream));
-        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        SCANRS_SYNC(st.stream);
         if (m->off_rank) { // u.dot(&v) + mat  (low_rank_offset.rs:55-57)
             std::vector<double> u((size_t)R * m->off_rank), vt((size_t)C * m->off_rank);
             SCANRS_HIP(hipMemcpy(u.data(), m->off_u->p, u.size() * 8, hipMemcpyDeviceToHost));
@@ -823,6 +955,7 @@ static void dot_host(scanrs_mat *m, bool transpose, const double *h_in, uint32_t
     // transpose = false: out[rows x l] = A * in[cols x l].   transpose = true (rdot): lhs is l x rows, out is l x cols:
     // computed as (A^T lhs^T)^T exactly like ArrayBase::dot(&AdaptiveMat) (sqz/src/mat.rs:1124-1132).
     Storage &st = *m->st;
+    CurrentHandle cur(&st);
     const uint64_t n_in = transpose ? m->rows() : m->cols();
     const uint64_t n_out = transpose ? m->cols() : m->rows();
     if (l == 0) return;
@@ -840,12 +973,12 @@ static void dot_host(scanrs_mat *m, bool transpose, const double *h_in, uint32_t
     }
     if (n_in)
         SCANRS_HIP(hipMemcpy2DAsync(dX, (size_t)ld * 8, src, (size_t)l * 8, (size_t)l * 8, n_in, hipMemcpyHostToDevice, st.stream));
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SCANRS_SYNC(st.stream);
     mat_apply(m, transpose, dX, ld, l, dY, ld);
     std::vector<double> res((size_t)n_out * l);
     if (n_out)
         SCANRS_HIP(hipMemcpy2DAsync(res.data(), (size_t)l * 8, dY, (size_t)ld * 8, (size_t)l * 8, n_out, hipMemcpyDeviceToHost, st.stream));
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SCANRS_SYNC(st.stream);
     if (in_is_l_by_n) {
         for (uint64_t j = 0; j < n_out; j++)
             for (uint32_t i = 0; i < l; i++) h_out[(size_t)i * n_out + j] = res[j * l + i];
@@ -870,6 +1003,7 @@ int scanrs_mat_rdot(scanrs_mat *m, const double *lhs, uint32_t l, double *out) {
 static void dot_host_u32(scanrs_mat *m, bool transpose, const uint32_t *h_in, uint32_t l, uint32_t *h_out) {
     if (!map_is_raw(m) || m->off_rank) fail(SCANRS_ERR_ARGUMENT, "u32 products are defined on the raw count matrix");
     Storage &st = *m->st;
+    CurrentHandle cur(&st);
     if (st.shard.active()) fail(SCANRS_ERR_ARGUMENT, "u32 products are not sharded");
     const uint64_t n_in = transpose ? m->rows() : m->cols();
     const uint64_t n_out = transpose ? m->cols() : m->rows();
@@ -888,13 +1022,13 @@ static void dot_host_u32(scanrs_mat *m, bool transpose, const uint32_t *h_in, ui
     }
     if (n_in)
         SCANRS_HIP(hipMemcpy2DAsync(dX, (size_t)ld * 4, src, (size_t)l * 4, (size_t)l * 4, n_in, hipMemcpyHostToDevice, st.stream));
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SCANRS_SYNC(st.stream);
     SparseCopy &cp = copy_outer_view_rows(m, !transpose);
     launch_spmm_u32(st, cp, dX, ld, l, dY, ld);
     std::vector<uint32_t> res((size_t)n_out * l);
     if (n_out)
         SCANRS_HIP(hipMemcpy2DAsync(res.data(), (size_t)l * 4, dY, (size_t)ld * 4, (size_t)l * 4, n_out, hipMemcpyDeviceToHost, st.stream));
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SCANRS_SYNC(st.stream);
     if (transpose) {
         for (uint64_t j = 0; j < n_out; j++)
             for (uint32_t i = 0; i < l; i++) h_out[(size_t)i * n_out + j] = res[j * l + i];
@@ -1123,14 +1257,14 @@ int scanrs_profile_enable(scanrs_mat *m, int on) {
 int scanrs_profile_reset(scanrs_mat *m) {
     return guard([&] {
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
-        SCANRS_HIP(hipStreamSynchronize(m->st->stream));
+        SCANRS_SYNC(m->st->stream);
         m->st->prof.reset();
     });
 }
 int scanrs_profile_get(scanrs_mat *m, scanrs_kernel_stat *out, uint32_t cap, uint32_t *n) {
     return guard([&] {
         if (!m || !n) fail(SCANRS_ERR_ARGUMENT, "null argument");
-        SCANRS_HIP(hipStreamSynchronize(m->st->stream));
+        SCANRS_SYNC(m->st->stream);
         m->st->prof.resolve();
         uint32_t i = 0;
         for (auto &kv : m->st->prof.stats) {
@@ -1195,7 +1329,10 @@ int scanrs_set_global_option(const char *key, double value) {
             go.knn_ratio = (unsigned long long)std::max(2.0, value);
         else if (k == "knn_stats")
             go.knn_stats = value != 0.0;
-        else
+        else if (k == "sync_timeout_s") { // deadline of every host-side wait for the device (common.hpp, "bounded waits")
+            if (!(value > 0.0) || !std::isfinite(value)) fail(SCANRS_ERR_ARGUMENT, "sync_timeout_s must be a positive number of seconds");
+            set_sync_timeout_s(value);
+        } else
             fail(SCANRS_ERR_ARGUMENT, "unknown global option '%s'", key);
     });
 }
@@ -1244,6 +1381,9 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.device_factor = value != 0.0;
         } else if (k == "d2h_threads") {
             st.d2h_threads = (unsigned)std::max(1.0, value);
+        } else if (k == "sync_timeout_s") { // process-wide (the waits have no handle): same as scanrs_set_global_option
+            if (!(value > 0.0) || !std::isfinite(value)) fail(SCANRS_ERR_ARGUMENT, "sync_timeout_s must be a positive number of seconds");
+            set_sync_timeout_s(value);
         } else if (k == "reuse_cmax") {
             if (!(value > 0.0)) fail(SCANRS_ERR_ARGUMENT, "reuse_cmax must be positive");
             st.reuse_cmax = value;
@@ -1272,7 +1412,8 @@ int scanrs_mat_set_panel_precision(scanrs_mat *m, int precision) {
 int scanrs_mat_sync(scanrs_mat *m) {
     return guard([&] {
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
-        SCANRS_HIP(hipStreamSynchronize(m->st->stream));
+        CurrentHandle cur(m->st.get());
+        SCANRS_SYNC(m->st->stream);
     });
 }
 
@@ -1296,7 +1437,7 @@ int scanrs_mat_chol_rinv(scanrs_mat *m, const double *g, uint32_t n, uint64_t ro
         SCANRS_HIP(hipMemcpyAsync(rinv, dR, (size_t)n * n * 8, hipMemcpyDeviceToHost, st.stream));
         SCANRS_HIP(hipMemcpyAsync(ctl, dCtl, sizeof ctl, hipMemcpyDeviceToHost, st.stream));
         SCANRS_HIP(hipMemcpyAsync(info, dInfo, sizeof info, hipMemcpyDeviceToHost, st.stream));
-        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        SCANRS_SYNC(st.stream);
         if (done) *done = ctl[0];
         if (status) *status = ctl[1];
         if (err) *err = info[0];
@@ -1305,6 +1446,18 @@ int scanrs_mat_chol_rinv(scanrs_mat *m, const double *g, uint32_t n, uint64_t ro
 }
 
 // ---- host-only utilities exposed for the CPU test-suite (no device needed) --------------------------------------------
+// The bounded wait on an event that is never signalled: the library's own poll loop (poll_until + the timeout report) over a
+// query that always answers "not ready" — no HIP call is made, so it runs without a device. Returns SCANRS_ERR_DEVICE after
+// `timeout_s` with the message a real stuck wait would leave in scanrs_last_error().
+int scanrs_debug_wait_never(double timeout_s) {
+    return guard([&] {
+        if (!(timeout_s > 0.0)) fail(SCANRS_ERR_ARGUMENT, "timeout must be positive");
+        stage_mark("debug: injected wait", 1, 0);
+        double waited = 0.0;
+        const hipError_t e = poll_until([] { return hipErrorNotReady; }, timeout_s, &waited);
+        if (e == hipErrorNotReady) timeout_report("event wait (injected: never signalled)", "scanrs_debug_wait_never", __FILE__, __LINE__, waited, nullptr);
+    });
+}
 int scanrs_host_chol_upper(double *g, int n) { return chol_upper(g, n) ? 0 : SCANRS_ERR_NUMERICAL; }
 int scanrs_host_inv_upper(double *r, int n) {
     inv_upper(r, n);

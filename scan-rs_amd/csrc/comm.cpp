@@ -114,7 +114,13 @@ struct LocalGroup {
             cv.notify_all();
             return;
         }
-        cv.wait(lk, [&] { return generation != gen || aborted; });
+        // bounded like every device wait (a shard thread that died without aborting must not hold the others for ever)
+        const bool woke = cv.wait_for(lk, std::chrono::duration<double>(sync_timeout_s()), [&] { return generation != gen || aborted; });
+        if (!woke) {
+            aborted = true;
+            cv.notify_all();
+            fail(SCANRS_ERR_DEVICE, "group barrier timed out after %.1f s (sync_timeout_s): %u of %u shards arrived", sync_timeout_s(), arrived, world);
+        }
         if (generation == gen) fail(SCANRS_ERR_DEVICE, "another shard of the group failed");
     }
 };
@@ -140,11 +146,11 @@ void comm_allreduce(Storage &st, scanrs_comm *c, void *d, uint64_t count, int dt
     }
     if (c->local) {
         LocalGroup &g = *c->local;
-        SCANRS_HIP(hipStreamSynchronize(st.stream)); // my partial sums are complete
+        SCANRS_SYNC(st.stream); // my partial sums are complete
         g.ptrs[c->rank] = d;
         g.barrier(); // everybody's are, and every pointer is published
         launch_local_allreduce(st.stream, g.ptrs.data(), g.world, c->rank, count, dtype);
-        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        SCANRS_SYNC(st.stream);
         g.barrier(); // every slice has been written to every buffer
         return;
     }
@@ -196,6 +202,17 @@ int scanrs_comm_create(const uint8_t *id, uint32_t rank, uint32_t world, scanrs_
         c->world = world;
         nccl_check(rccl().CommInitRank(&c->nccl, (int)world, u, (int)rank), "ncclCommInitRank"); // on the calling thread's current device
         *out = c.release();
+        return SCANRS_OK;
+    } catch (const Failure &e) {
+        return e.code;
+    }
+}
+
+// diagnostics (CPU test-suite): one thread enters a barrier of a group of `world` shards alone
+int scanrs_debug_barrier_alone(uint32_t world) {
+    try {
+        LocalGroup g(world < 2 ? 2 : world);
+        g.barrier();
         return SCANRS_OK;
     } catch (const Failure &e) {
         return e.code;

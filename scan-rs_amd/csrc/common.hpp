@@ -32,7 +32,32 @@ namespace scanrs {
 
 // SCANRS_TRACE=1: wall-clock of host-side phases on stderr (diagnostics only)
 bool trace_on();
-void stage_mark(const char *what, long a = 0, long b = 0); // SCANRS_TRACE=2: a line on stderr, no synchronisation
+// Where the calling thread stands: kept in a small per-thread ring (always; a timed-out wait names the last ones) and printed with
+// SCANRS_TRACE=2 (a line on stderr, no synchronisation)
+void stage_mark(const char *what, long a = 0, long b = 0);
+
+// ---- bounded waits ----------------------------------------------------------------------------------------------------
+// Every host-side wait for the device goes through these: a poll (hipStreamQuery / hipEventQuery, spinning for the first
+// 200 us, then short sleeps) with a deadline — option "sync_timeout_s", default 120 s — instead of a blocking
+// hipStreamSynchronize / hipEventSynchronize: a device that never signals turns into SCANRS_ERR_DEVICE naming the wait
+// (function, file:line), the thread's last stage marks and which of the handle's streams are still busy, not into a call that
+// never returns. The *_quiet forms are for destructors and unwinding (bounded too, nothing thrown).
+struct Storage;
+void wait_stream(hipStream_t s, const char *func, const char *file, int line);
+void wait_event(hipEvent_t e, const char *func, const char *file, int line);
+void wait_device(const char *func, const char *file, int line);
+bool wait_stream_quiet(hipStream_t s) noexcept;
+bool wait_event_quiet(hipEvent_t e) noexcept;
+double sync_timeout_s();
+void set_sync_timeout_s(double s);
+// the handle whose streams a timed-out wait on this thread reports (set by the entry points that run device work)
+struct CurrentHandle {
+    const Storage *prev;
+    explicit CurrentHandle(const Storage *st);
+    ~CurrentHandle();
+};
+#define SCANRS_SYNC(stream) ::scanrs::wait_stream((stream), __func__, __FILE__, __LINE__)
+#define SCANRS_SYNC_EVENT(ev) ::scanrs::wait_event((ev), __func__, __FILE__, __LINE__)
 struct Tick {
     const char *what;
     std::chrono::steady_clock::time_point t0;
@@ -68,13 +93,22 @@ struct DevBuf {
     void alloc(size_t count) {
         release();
         n = count;
-        if (count) SCANRS_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        if (!count) return;
+        const auto t0 = std::chrono::steady_clock::now();
+        SCANRS_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > 2.0 && trace_on()) fprintf(stderr, "[scanrs trace]   hipMalloc of %.2f GB took %.1f ms\n", (double)(count * sizeof(T)) / 1e9, ms);
     }
     void ensure(size_t count) {
         if (count > n) alloc(count);
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) {
+            const auto t0 = std::chrono::steady_clock::now();
+            (void)hipFree(p);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms > 2.0 && trace_on()) fprintf(stderr, "[scanrs trace]   hipFree of %.2f GB took %.1f ms\n", (double)(n * sizeof(T)) / 1e9, ms);
+        }
         p = nullptr;
         n = 0;
     }

@@ -560,7 +560,7 @@ void launch_gram_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, c
     uint32_t *d_tiles = st.scratch.get<uint32_t>(tkey, tiles.size());
     if (st.scratch.filled.insert(tkey).second) {
         SCANRS_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice, st.stream));
-        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        SCANRS_SYNC(st.stream);
     }
     // ~2k workgroups, slices of at least 256 rows and a multiple of the staging depth
     uint64_t splits = std::max<uint64_t>(1, std::min<uint64_t>((rows + 255) / 256, (2048 + n_tiles - 1) / n_tiles));

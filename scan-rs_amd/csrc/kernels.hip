@@ -1452,7 +1452,7 @@ static void ensure_order(Storage &st, SparseCopy &cp) {
                                               st.stream));
     cp.sorted_len.resize(cp.n_outer);
     SCANRS_HIP(hipMemcpyAsync(cp.sorted_len.data(), keys_b.p, cp.n_outer * 4, hipMemcpyDeviceToHost, st.stream));
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SCANRS_SYNC(st.stream);
 }
 
 // number of leading vectors of `order` with at least `min_len` nonzeros
@@ -2275,7 +2275,7 @@ static bool col_moments_plan(Storage &st, SparseCopy &cp, const DevMap &map, int
         hipLaunchKernelGGL(max_u32_kernel, dim3(2048), dim3(256), 0, st.stream, cp.values.p, cp.nnz, d);
         uint32_t h = 0;
         SCANRS_HIP(hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, st.stream));
-        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        SCANRS_SYNC(st.stream);
         cp.max_value = std::max(h, 1u);
     }
     double x = (double)cp.max_value;
@@ -2288,7 +2288,7 @@ static bool col_moments_plan(Storage &st, SparseCopy &cp, const DevMap &map, int
             hipLaunchKernelGGL(minmax_nonneg_kernel, dim3(512), dim3(256), 0, st.stream, map.ops[i].a, cp.n_outer, d);
             unsigned long long h[3];
             SCANRS_HIP(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, st.stream));
-            SCANRS_HIP(hipStreamSynchronize(st.stream));
+            SCANRS_SYNC(st.stream);
             if (h[2]) return false;
             double amax;
             memcpy(&amax, &h[1], 8);
@@ -2420,7 +2420,7 @@ void launch_local_allreduce(hipStream_t s, void *const *bufs, uint32_t world, ui
 void SparseCopy::build_items(hipStream_t s) {
     std::vector<uint64_t> h(n_outer + 1);
     if (n_outer + 1) SCANRS_HIP(hipMemcpyAsync(h.data(), indptr.p, (n_outer + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    SCANRS_HIP(hipStreamSynchronize(s));
+    SCANRS_SYNC(s);
     std::vector<Item> its;
     std::vector<MultiRow> mr;
     its.reserve(n_outer + nnz / ITEM_NNZ + 1);
@@ -2447,7 +2447,7 @@ void SparseCopy::build_items(hipStream_t s) {
     multi.alloc(mr.size());
     if (!its.empty()) SCANRS_HIP(hipMemcpyAsync(items.p, its.data(), its.size() * sizeof(Item), hipMemcpyHostToDevice, s));
     if (!mr.empty()) SCANRS_HIP(hipMemcpyAsync(multi.p, mr.data(), mr.size() * sizeof(MultiRow), hipMemcpyHostToDevice, s));
-    SCANRS_HIP(hipStreamSynchronize(s));
+    SCANRS_SYNC(s);
 }
 
 void validate_copy(Storage &st, const SparseCopy &cp, uint64_t *zeros, uint64_t *bad) {
@@ -2458,7 +2458,7 @@ void validate_copy(Storage &st, const SparseCopy &cp, uint64_t *zeros, uint64_t 
                            cp.indices.p, cp.values.p, cp.n_inner, c.p);
     unsigned long long h[2];
     SCANRS_HIP(hipMemcpyAsync(h, c.p, sizeof(h), hipMemcpyDeviceToHost, st.stream));
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SCANRS_SYNC(st.stream);
     *zeros = h[0];
     *bad = h[1];
 }
@@ -2512,7 +2512,7 @@ void sort_outer_vectors(Storage &st, SparseCopy &cp) {
                                                    (unsigned)cp.n_outer, cp.indptr.p, cp.indptr.p + 1, 0u, end_bit, st.stream));
     SCANRS_HIP(hipMemcpyAsync(cp.indices.p, keys_out.p, cp.nnz * 4, hipMemcpyDeviceToDevice, st.stream));
     SCANRS_HIP(hipMemcpyAsync(cp.values.p, vals_out.p, cp.nnz * 4, hipMemcpyDeviceToDevice, st.stream));
-    SCANRS_HIP(hipStreamSynchronize(st.stream));
+    SCANRS_SYNC(st.stream);
 }
 
 void build_transposed_copy(Storage &st, const SparseCopy &src, SparseCopy &dst) {
@@ -2550,7 +2550,7 @@ void build_transposed_copy(Storage &st, const SparseCopy &src, SparseCopy &dst) 
         hipLaunchKernelGGL(lower_bound_kernel, grid1(dst.n_outer + 1, 256), dim3(256), 0, st.stream, kb.current(), nnz,
                            dst.n_outer, dst.indptr.p);
         SCANRS_HIP(hipGetLastError());
-        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        SCANRS_SYNC(st.stream);
     }
     dst.build_items(st.stream);
 }

@@ -93,7 +93,7 @@ void launch(const double *dq, uint32_t ldq, uint64_t n_q, const double *dp, uint
     }
     const dim3 grid((unsigned)((n_q + THREADS - 1) / THREADS)), block(THREADS);
     hipLaunchKernelGGL((knn_kernel<DMAX, THREADS>), grid, block, 0, s, q, n_q, pp.p, n_p, (uint32_t)DMAX, k, skip, p_stride, dout);
-    SCANRS_HIP(hipStreamSynchronize(s)); // the padded copies are released on return
+    SCANRS_SYNC(s); // the padded copies are released on return
 }
 
 // exhaustive search of every query against rows 0, p_stride, 2 p_stride, ... of the point set (n_sub of them); subset-local indices
@@ -523,7 +523,7 @@ bool knn_filtered(const double *dq, uint32_t ldq, uint64_t n_q, const double *dp
             }
         }
     }
-    SCANRS_HIP(hipStreamSynchronize(s));
+    SCANRS_SYNC(s);
     return true;
 }
 

@@ -149,7 +149,7 @@ static void omega_fill_device(Storage &st, uint64_t seed, uint64_t seq_rows, uin
         const std::vector<uint64_t> tab = jump_powers(d, n_pow);
         st.jump_tab.alloc(tab.size());
         SCANRS_HIP(hipMemcpyAsync(st.jump_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st.stream));
-        SCANRS_HIP(hipStreamSynchronize(st.stream));
+        SCANRS_SYNC(st.stream);
         st.jump_d = d;
         st.jump_npow = n_pow;
     }
@@ -175,13 +175,14 @@ struct Ctx {
     scanrs_mat *m;
     Storage &st;
     hipStream_t s;
+    CurrentHandle cur; // a timed-out wait inside the solver names this handle's streams
     // a solver repeats the same products many times: lets the auto path build the hybrid product's tile layout up front
-    explicit Ctx(scanrs_mat *mm) : m(mm), st(*mm->st), s(mm->st->stream) { st.tile_hint++; }
+    explicit Ctx(scanrs_mat *mm) : m(mm), st(*mm->st), s(mm->st->stream), cur(mm->st.get()) { st.tile_hint++; }
     ~Ctx() { st.tile_hint--; }
     Ctx(const Ctx &) = delete;
     Ctx &operator=(const Ctx &) = delete;
     double *dev(const char *key, size_t count) { return st.scratch.get<double>(key, count); }
-    void sync() { SCANRS_HIP(hipStreamSynchronize(s)); }
+    void sync() { SCANRS_SYNC(s); }
     void h2d(double *d, const double *h, size_t n) {
         SCANRS_HIP(hipMemcpyAsync(d, h, n * 8, hipMemcpyHostToDevice, s));
         sync(); // host staging buffers are pageable and reused
@@ -259,7 +260,7 @@ static void download_panel_staged(Ctx &c, const double *d, uint32_t ld, uint64_t
                                             row_bytes, chunk_rows(i), hipMemcpyDeviceToHost, c.s));
             SCANRS_HIP(hipEventRecord(ev[i % NS], c.s));
             if (i >= 1) {
-                SCANRS_HIP(hipEventSynchronize(ev[(i - 1) % NS]));
+                SCANRS_SYNC_EVENT(ev[(i - 1) % NS]);
                 ready.store(i, std::memory_order_release);
             }
         }
@@ -456,17 +457,19 @@ static void orth_against(Ctx &c, const double *Q, uint32_t ldq, uint32_t nprev, 
 struct DevOrth {
     int *ctl = nullptr;     // 2 ints per call: [done, status]
     double *info = nullptr; // 2 doubles per call: [max |G - I| or max |C| of the last check, shift]
-    uint32_t used = 0;
-    static constexpr uint32_t CAP = 256;
-    void init(Ctx &c) {
-        ctl = c.st.scratch.get<int>("orth_ctl", 2 * CAP);
-        info = c.st.scratch.get<double>("orth_info", 2 * CAP);
-        SCANRS_HIP(hipMemsetAsync(ctl, 0, 2 * CAP * sizeof(int), c.s));
-        SCANRS_HIP(hipMemsetAsync(info, 0, 2 * CAP * sizeof(double), c.s));
+    uint32_t used = 0, cap = 0;
+    // svd_bk draws one slot per iteration (the panel's CholeskyQR) and three per Krylov block (two rounds + the final check):
+    // 4 n_iter - 3 in all — the blocks are sized from n_iter (the reference puts no bound on it, bk_svd.rs:16-53)
+    void init(Ctx &c, uint32_t slots) {
+        cap = slots;
+        ctl = c.st.scratch.get<int>("orth_ctl", 2 * (size_t)cap);
+        info = c.st.scratch.get<double>("orth_info", 2 * (size_t)cap);
+        SCANRS_HIP(hipMemsetAsync(ctl, 0, 2 * (size_t)cap * sizeof(int), c.s));
+        SCANRS_HIP(hipMemsetAsync(info, 0, 2 * (size_t)cap * sizeof(double), c.s));
         used = 0;
     }
     uint32_t next() {
-        if (used >= CAP) fail(SCANRS_ERR_NUMERICAL, "orthonormalisation bookkeeping exhausted");
+        if (used >= cap) fail(SCANRS_ERR_NUMERICAL, "orthonormalisation bookkeeping exhausted (%u slots)", cap);
         return used++;
     }
 };
@@ -717,10 +720,10 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
         int n0 = std::uncaught_exceptions();
         ~Drain() {
             if (std::uncaught_exceptions() > n0) {
-                (void)hipStreamSynchronize(st.stream);
-                if (st.aux_stream) (void)hipStreamSynchronize(st.aux_stream);
-                if (st.aux2_stream) (void)hipStreamSynchronize(st.aux2_stream);
-                if (st.ov_stream) (void)hipStreamSynchronize(st.ov_stream);
+                (void)wait_stream_quiet(st.stream);
+                if (st.aux_stream) (void)wait_stream_quiet(st.aux_stream);
+                if (st.aux2_stream) (void)wait_stream_quiet(st.aux2_stream);
+                if (st.ov_stream) (void)wait_stream_quiet(st.ov_stream);
             }
         }
     } drain{c.st};
@@ -814,7 +817,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
     DevOrth od;
     double *cfull_d = nullptr, *coef_d = nullptr, *coef_tmp_d = nullptr;
     if (dv) {
-        od.init(c);
+        od.init(c, 4u * n_iter + 8u);
         cfull_d = c.dev("bk_cfull", (size_t)q * ldq);
         coef_d = c.dev("bk_coef", (size_t)q * ldb);
         coef_tmp_d = c.dev("bk_coef_tmp", (size_t)q * ldb);
@@ -942,7 +945,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
                 c.sync();
             else if (i >= 1) {
                 stage_mark("bk pacing wait", i - 1);
-                SCANRS_HIP(hipEventSynchronize(ev_k[i - 1].e));
+                SCANRS_SYNC_EVENT(ev_k[i - 1].e);
                 stage_mark("bk pacing done", i - 1);
             }
         } else {
@@ -971,8 +974,8 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
                     if (trace_on())
                         fprintf(stderr, "[scanrs trace] bk: device factorization %u: done %d status %d (last check %.3e, shift %.3e) -> host path\n", sl,
                                 ctl[2 * sl], ctl[2 * sl + 1], info[2 * sl], info[2 * sl + 1]);
-                    if (c.st.aux_stream) SCANRS_HIP(hipStreamSynchronize(c.st.aux_stream));
-                    if (c.st.aux2_stream) SCANRS_HIP(hipStreamSynchronize(c.st.aux2_stream));
+                    if (c.st.aux_stream) SCANRS_SYNC(c.st.aux_stream);
+                    if (c.st.aux2_stream) SCANRS_SYNC(c.st.aux2_stream);
                     return BK_RETRY_ON_HOST;
                 }
             }

@@ -415,7 +415,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     auto lap = [&](const char *what) { // SCANRS_TRACE: where a build spends its time (forces a sync per phase)
         static thread_local std::chrono::steady_clock::time_point t_prev;
         if (!trace_on()) return;
-        (void)hipStreamSynchronize(s);
+        (void)wait_stream_quiet(s);
         const auto t_now = std::chrono::steady_clock::now();
         if (what) fprintf(stderr, "[scanrs trace]   layout: %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t_now - t_prev).count());
         t_prev = t_now;
@@ -432,7 +432,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     SCANRS_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, ovc.p, ovo.p, 0ull, (size_t)n_seg + 1, rocprim::plus<unsigned long long>(), s));
     unsigned long long n_ov = 0;
     SCANRS_HIP(hipMemcpyAsync(&n_ov, ovo.p + n_seg, 8, hipMemcpyDeviceToHost, s));
-    SCANRS_HIP(hipStreamSynchronize(s));
+    SCANRS_SYNC(s);
     lap("count + scan");
     if (max_overflow > 0.0 && (double)n_ov > max_overflow * (double)cp.nnz) {
         if (trace_on())
@@ -462,7 +462,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     SCANRS_HIP(hipGetLastError());
     lap("fill");
     if (n_ov) ensure_bounds_public(st, ov);
-    SCANRS_HIP(hipStreamSynchronize(s)); // the temporaries are released on return
+    SCANRS_SYNC(s); // the temporaries are released on return
     lap("overflow bounds");
     if (trace_on())
         fprintf(stderr, "[scanrs trace] tile layout: %llu outer x %llu inner, T %u x B %u, K %u, S %u, %llu groups x %u tiles in %u parts, nnz %llu, overflow %llu (%.1f %%), positions per nonzero %.2f, %.2f GB\n",
@@ -525,7 +525,7 @@ static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &c
     }
     if (tl.ov.nnz) materialize_map_values(st, tl.ov, map, tl.ov.fvals.p);
     SCANRS_HIP(hipGetLastError());
-    if (trace_on()) (void)hipStreamSynchronize(st.stream);
+    if (trace_on()) (void)wait_stream_quiet(st.stream);
     tl.sig_n = map.n;
     for (int i = 0; i < map.n; i++) {
         tl.sig_id[i] = map.ops[i].id;

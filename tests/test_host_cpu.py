@@ -341,3 +341,44 @@ def test_sym_eig_topk_does_not_depend_on_the_thread_count():
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout)
     assert outs[0] == outs[1] == outs[2] and len(outs[0]) > 1000
+
+
+def test_bounded_wait_turns_a_never_signalled_event_into_an_error(sa, capfd):
+    """Round 3's verdict: a call that can block for ever is not a drop-in for run_pca. Every host-side wait of the library is a
+    poll with a deadline ("sync_timeout_s"); here the library's own wait loop runs on an injected event that is never signalled
+    (no device needed) and must come back with SCANRS_ERR_DEVICE within the deadline, naming the wait and the last stage."""
+    import time
+
+    t0 = time.perf_counter()
+    with pytest.raises(sa.ScanrsError) as ei:
+        sa.debug_wait_never(0.3)
+    dt = time.perf_counter() - t0
+    assert 0.3 <= dt < 1.0, dt
+    assert ei.value.code == 4  # SCANRS_ERR_DEVICE
+    msg = str(ei.value)
+    assert "timed out" in msg and "sync_timeout_s" in msg and "scanrs_debug_wait_never" in msg and "debug: injected wait" in msg, msg
+    err = capfd.readouterr().err
+    assert "device wait timed out" in err and "stage debug: injected wait" in err
+    # the option is validated
+    with pytest.raises(sa.ScanrsError):
+        sa.set_global_option("sync_timeout_s", -1.0)
+    sa.set_global_option("sync_timeout_s", 120.0)
+
+
+def test_group_barrier_of_the_single_process_form_is_bounded(sa):
+    """The barrier between the shard threads of scanrs_multi_* has the same deadline: a shard that never arrives fails the
+    others instead of holding them."""
+    import ctypes
+    import time
+
+    if not hasattr(sa._lib, "scanrs_debug_barrier_alone"):
+        pytest.skip("hook not built")
+    sa.set_global_option("sync_timeout_s", 0.3)
+    try:
+        t0 = time.perf_counter()
+        rc = sa._lib.scanrs_debug_barrier_alone(ctypes.c_uint32(2))
+        dt = time.perf_counter() - t0
+        assert rc == 4 and 0.3 <= dt < 1.5, (rc, dt)
+        assert b"group barrier timed out" in sa._lib.scanrs_last_error()
+    finally:
+        sa.set_global_option("sync_timeout_s", 120.0)
