@@ -208,6 +208,67 @@ static void need_device() {
         fail(SCANRS_ERR_DEVICE, "no gfx950 (MI355X) device is usable from this process; scanrs_amd has no CPU fallback");
 }
 
+// ---- device memory: allocation with retry, deferred frees (common.hpp) ------------------------------------------------
+namespace {
+struct Graveyard {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> dead;
+    size_t bytes = 0;
+};
+Graveyard &graveyard() {
+    static Graveyard *g = new Graveyard(); // never destroyed: handles freed by static destructors of the host program still find it
+    return *g;
+}
+std::atomic<uint64_t> g_alloc_us{0}, g_alloc_calls{0};
+} // namespace
+void device_free_later(void *p, size_t bytes) {
+    if (!p) return;
+    Graveyard &g = graveyard();
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.dead.emplace_back(p, bytes);
+    g.bytes += bytes;
+}
+void device_free_flush() noexcept {
+    Graveyard &g = graveyard();
+    std::vector<std::pair<void *, size_t>> take;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        take.swap(g.dead);
+        g.bytes = 0;
+    }
+    if (take.empty()) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t bytes = 0;
+    for (auto &d : take) {
+        (void)hipFree(d.first);
+        bytes += d.second;
+    }
+    if (trace_on())
+        fprintf(stderr, "[scanrs trace] released %zu buffers, %.2f GB, in %.2f ms\n", take.size(), (double)bytes / 1e9,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
+void *device_alloc(size_t bytes) {
+    void *p = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) { // buffers waiting for their release may be all that stands in the way
+        (void)hipGetLastError();
+        device_free_flush();
+        e = hipMalloc(&p, bytes);
+    }
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    g_alloc_us.fetch_add((uint64_t)us, std::memory_order_relaxed);
+    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fail(SCANRS_ERR_DEVICE, "hipMalloc of %.3f GB failed: %s", (double)bytes / 1e9, hipGetErrorString(e));
+    }
+    if (us > 2000.0 && trace_on()) fprintf(stderr, "[scanrs trace]   hipMalloc of %.2f GB took %.1f ms\n", (double)bytes / 1e9, us / 1e3);
+    return p;
+}
+uint64_t device_alloc_us() { return g_alloc_us.load(std::memory_order_relaxed); }
+uint64_t device_alloc_calls() { return g_alloc_calls.load(std::memory_order_relaxed); }
+
 // ---- Profile -----------------------------------------------------------------------------------
 hipEvent_t Profile::take() {
     if (!pool.empty()) {
@@ -256,7 +317,35 @@ Profile::~Profile() {
 }
 
 // ---- Storage -------------------------------------------------------------------------------------
+struct Storage::SideBuild {
+    std::thread th;
+    const SparseCopy *target = nullptr;
+    hipStream_t stream = nullptr;
+    int code = SCANRS_OK;
+    std::string err;
+    double ms = 0.0;
+};
+void Storage::side_join_if(const SparseCopy *target) {
+    if (!side || (target && side->target != target)) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    SideBuild *sb = side;
+    side = nullptr;
+    if (sb->th.joinable()) sb->th.join();
+    if (sb->stream) (void)hipStreamDestroy(sb->stream);
+    t_side_wait_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    const int code = sb->code;
+    const std::string err = sb->err;
+    if (trace_on()) fprintf(stderr, "[scanrs trace] side build: %.3f ms on the helper thread\n", sb->ms);
+    delete sb;
+    if (code != SCANRS_OK && std::uncaught_exceptions() == 0) fail(code, "%s", err.c_str());
+}
 Storage::~Storage() {
+    if (side) {
+        try {
+            side_join_if(nullptr);
+        } catch (const Failure &) {
+        }
+    }
     if (host_stage) (void)hipHostFree(host_stage);
     if (aux_stream) {
         (void)wait_stream_quiet(aux_stream);
@@ -313,6 +402,7 @@ hipStream_t Storage::ov() {
 SparseCopy &Storage::copy_with_outer_rows(bool outer_rows) {
     const bool primary_outer_rows = storage == SCANRS_CSR;
     if (outer_rows == primary_outer_rows) return primary;
+    side_join_if(&other); // a helper thread may be building it right now
     if (!has_other) {
         build_transposed_copy(*this, primary, other);
         has_other = true;
@@ -394,11 +484,64 @@ bool mat_tiles_ready(scanrs_mat *m, bool transpose) {
     return cp.tiles != nullptr && (m->st->spmm_path == 3 || (m->st->spmm_path == 0 && m->st->tile_auto && m->st->panel_precision == 0));
 }
 
+// A solver alternates V x and V^T y. What the SECOND product of its first iteration needs — the transposed copy when it does not
+// exist yet, and that orientation's tile layout when the auto path will take it — is built by a helper thread on a stream of its
+// own while the main thread builds the first product's layout and runs the first pass (the only call Cell Ranger ever makes is the
+// first one on a fresh handle, tools/src/bin/cmd.rs:61-70: serially these builds were more than half of it). The helper touches
+// nothing but the copy it builds; whoever needs that copy joins the helper first (side_join_if).
+void prepare_second_orientation(scanrs_mat *m, bool transpose_second) {
+    Storage &st = *m->st;
+    if (st.side || !st.side_build) return;
+    const bool outer_rows = (!transpose_second) != m->transposed; // the base-matrix dimension the second product's outer vectors run over
+    const bool is_primary = outer_rows == (st.storage == SCANRS_CSR);
+    SparseCopy &cp = is_primary ? st.primary : st.other;
+    const bool need_copy = !is_primary && !st.has_other;
+    const bool want_tiles = st.spmm_path == 0 && st.tile_auto && st.panel_precision == 0 && st.tile_hint > 0 &&
+                            st.primary.nnz >= std::max<uint64_t>(st.blocked_min_nnz, 1ull << 24) && !(cp.tiles != nullptr);
+    if (!need_copy && !want_tiles) return;
+    if (st.primary.nnz < (1ull << 22)) return; // small matrices: the builds take less than starting a thread
+    int dev = 0;
+    SCANRS_HIP(hipGetDevice(&dev));
+    auto *sb = new Storage::SideBuild();
+    sb->target = &cp;
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&sb->stream, hipStreamNonBlocking, least) != hipSuccess) {
+        (void)hipGetLastError();
+        delete sb;
+        return; // no helper: the main thread builds on demand as before
+    }
+    st.side = sb;
+    Storage *stp = &st;
+    sb->th = std::thread([stp, sb, dev, need_copy, want_tiles] {
+        const auto t0 = std::chrono::steady_clock::now();
+        try {
+            SCANRS_HIP(hipSetDevice(dev));
+            CurrentHandle cur(stp);
+            SparseCopy &target = *const_cast<SparseCopy *>(sb->target);
+            if (need_copy) {
+                build_transposed_copy(*stp, stp->primary, stp->other, sb->stream);
+                stp->has_other = true;
+            }
+            if (want_tiles) (void)tile_layout_build_auto(*stp, target, sb->stream);
+            wait_stream(sb->stream, "side build", __FILE__, __LINE__);
+        } catch (const Failure &e) {
+            sb->code = e.code;
+            sb->err = g_err; // this thread's message buffer
+        } catch (const std::exception &e) {
+            sb->code = SCANRS_ERR_DEVICE;
+            sb->err = std::string("side build: ") + e.what();
+        }
+        sb->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    });
+}
+
 void mat_apply(scanrs_mat *m, bool transpose, const double *dX, uint32_t ldx, uint32_t l, double *dOut, uint32_t ldo) {
     Storage &st = *m->st;
     CurrentHandle cur(&st);
     const bool outer_is_view_row = !transpose;
     SparseCopy &cp = copy_outer_view_rows(m, outer_is_view_row);
+    st.side_join_if(&cp); // its tile layout may be in the making
     DevMap map = m->dev_map(outer_is_view_row);
     const double *off_a = nullptr, *off_w = nullptr;
     // A map that ENDS in a ScaleAxis indexed by the inner position — the per-gene 1/sigma when cells are the outer
@@ -441,6 +584,7 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
     if (!out) fail(SCANRS_ERR_ARGUMENT, "null output handle");
     *out = nullptr;
     need_device();
+    jump_tables_prefetch(); // the GF(2) tables of the seeded start panel (solver.cpp): ~10 ms of one host core, off the first PCA's path
     if (storage != SCANRS_CSR && storage != SCANRS_CSC) fail(SCANRS_ERR_ARGUMENT, "storage must be 0 (CSR) or 1 (CSC)");
     if (!indptr) fail(SCANRS_ERR_ARGUMENT, "null indptr");
     if (rows > 0xFFFFFFFFull || cols > 0xFFFFFFFFull) fail(SCANRS_ERR_SHAPE, "dimensions must fit in u32 (AdaptiveVec limit)");
@@ -481,6 +625,7 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
     if (bad) fail(SCANRS_ERR_ARGUMENT, "indices must be in range and strictly ascending within each outer vector (%llu violations)", (unsigned long long)bad);
     if (zeros) compact_nonzeros(*st, cp);
     cp.build_items(st->stream);
+    device_free_flush(); // the stream is idle here
     auto *m = new scanrs_mat();
     m->st = st;
     *out = m;
@@ -722,7 +867,10 @@ int scanrs_mat_create_adaptive(uint64_t rows, uint64_t cols, int storage, const 
         create_common(rows, cols, storage, ip.p, ix.p, vv.p, true, out); // validates ordering, copies into the handle
     });
 }
-void scanrs_mat_free(scanrs_mat *m) { delete m; }
+void scanrs_mat_free(scanrs_mat *m) {
+    delete m;
+    device_free_flush(); // the handle's buffers (when this was the last view of its storage): their streams were drained by the destructor
+}
 
 int scanrs_mat_view(const scanrs_mat *m, scanrs_mat **out) {
     return guard([&] {
@@ -1135,6 +1283,7 @@ int scanrs_pca_bk(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t n_ite
         if (!m || !s) fail(SCANRS_ERR_ARGUMENT, "null argument");
         stage_mark("pca_bk enter");
         pca_bk(m, k, k_multiplier, n_iter, seed, omega, snoop, u, s, v);
+        device_free_flush(); // results delivered: the device is idle
         stage_mark("pca_bk leave");
     });
 }
@@ -1143,6 +1292,7 @@ int scanrs_pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_i
     return guard([&] {
         if (!m || !s) fail(SCANRS_ERR_ARGUMENT, "null argument");
         pca_rand(m, k, l_multiplier, n_iter, seed, omega, u, s, v);
+        device_free_flush();
     });
 }
 int scanrs_pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t max_iter, const double *v0, const scanrs_snoop *snoop,
@@ -1150,6 +1300,7 @@ int scanrs_pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t max_iter, 
     return guard([&] {
         if (!m || !u || !s || !v) fail(SCANRS_ERR_ARGUMENT, "null argument");
         pca_irlba(m, nu, tol, max_iter, v0, snoop, u, s, v, mprod);
+        device_free_flush();
     });
 }
 int scanrs_pca_result_device(scanrs_mat *m, const double **d_u, uint32_t *ld_u, const double **d_v, uint32_t *ld_v, uint32_t *k) {
@@ -1351,6 +1502,13 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.tile_t = (uint32_t)value;
         } else if (k == "tile_b") {
             st.tile_b = (uint32_t)value;
+        } else if (k == "side_build") {
+            st.side_build = value != 0.0;
+        } else if (k == "tile_builder") {
+            st.tile_builder = value != 0.0;
+        } else if (k == "tile_build_waves") {
+            if (!(value >= 0.0) || value > 32.0) fail(SCANRS_ERR_ARGUMENT, "tile_build_waves must be in 0..32");
+            st.tile_build_waves = (uint32_t)value;
         } else if (k == "ov_tile_kb") {
             st.ov_tile_bytes = (size_t)std::max(0.0, value) << 10;
         } else if (k == "tile_max_overflow") {
@@ -1398,6 +1556,18 @@ int scanrs_mat_get_counter(scanrs_mat *m, const char *key, uint64_t *value) {
         const std::string k(key);
         if (k == "bk_host_retries")
             *value = m->st->bk_host_retries;
+        else if (k == "t_layout_us") // first-call accounting: host time of the calling thread in tile layout builds ...
+            *value = m->st->t_layout_us;
+        else if (k == "t_side_wait_us") // ... waiting for the helper thread that builds the second orientation
+            *value = m->st->t_side_wait_us;
+        else if (k == "t_start_panel_us") // ... in the seeded start panel (first call: the generator's jump tables)
+            *value = m->st->t_start_panel_us;
+        else if (k == "t_delivery_us") // ... delivering U and V to the caller's host arrays
+            *value = m->st->t_delivery_us;
+        else if (k == "t_alloc_us") // ... in hipMalloc, process-wide
+            *value = device_alloc_us();
+        else if (k == "alloc_calls")
+            *value = device_alloc_calls();
         else
             fail(SCANRS_ERR_ARGUMENT, "unknown counter '%s'", key);
     });
@@ -1414,6 +1584,7 @@ int scanrs_mat_sync(scanrs_mat *m) {
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
         CurrentHandle cur(m->st.get());
         SCANRS_SYNC(m->st->stream);
+        device_free_flush();
     });
 }
 

@@ -70,6 +70,17 @@ struct Tick {
 };
 
 // ---- device memory ------------------------------------------------------------------
+// hipFree waits for the whole device (a buffer dropped while a 20 ms sparse pass runs holds the host for those 20 ms), and VRAM
+// that was just freed is scrubbed in the background: an allocation right behind a large free waits for the scrubber (0.24 s
+// per 8 GB, profiles/microbench/alloc_probe2). So buffers are never freed in the middle of a call: release() hands the pointer
+// to a process-wide list that is emptied where the device is known to be idle (end of create / a solver / scanrs_mat_sync /
+// scanrs_mat_free) — or when an allocation fails for lack of memory, which then tries again.
+void device_free_later(void *p, size_t bytes);
+void device_free_flush() noexcept;
+void *device_alloc(size_t bytes); // hipMalloc with the retry above; throws Failure(SCANRS_ERR_DEVICE)
+uint64_t device_alloc_us();
+uint64_t device_alloc_calls();
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -94,21 +105,15 @@ struct DevBuf {
         release();
         n = count;
         if (!count) return;
-        const auto t0 = std::chrono::steady_clock::now();
-        SCANRS_HIP(hipMalloc((void **)&p, count * sizeof(T)));
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (ms > 2.0 && trace_on()) fprintf(stderr, "[scanrs trace]   hipMalloc of %.2f GB took %.1f ms\n", (double)(count * sizeof(T)) / 1e9, ms);
+        // 64 bytes of slack behind every buffer: kernels that read a vector in aligned 16-byte chunks (tile_assign_wave_kernel) look up
+        // to two chunks past the end of the last vector
+        p = static_cast<T *>(device_alloc(count * sizeof(T) + 64));
     }
     void ensure(size_t count) {
         if (count > n) alloc(count);
     }
     void release() {
-        if (p) {
-            const auto t0 = std::chrono::steady_clock::now();
-            (void)hipFree(p);
-            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (ms > 2.0 && trace_on()) fprintf(stderr, "[scanrs trace]   hipFree of %.2f GB took %.1f ms\n", (double)(n * sizeof(T)) / 1e9, ms);
-        }
+        if (p) device_free_later(p, n * sizeof(T) + 64);
         p = nullptr;
         n = 0;
     }
@@ -246,6 +251,12 @@ struct Storage {
     hipStream_t ov_stream = nullptr; // the gather over the overflow part of a tile layout runs here, beside the tile kernel (tiles.hip)
     hipEvent_t ev_in = nullptr, ev_ov = nullptr;
     hipStream_t ov();
+    // Side build (round 4): the copy and the tile layout that the SECOND product of a solver needs are made by a helper thread on a
+    // stream of its own while the main thread prepares and runs the first product (capi.cpp, prepare_second_orientation)
+    struct SideBuild;
+    SideBuild *side = nullptr;
+    void side_join_if(const SparseCopy *target); // waits for the helper when it is working on `target` (nullptr: whatever it does); rethrows its failure
+    uint64_t t_side_wait_us = 0, t_layout_us = 0, t_start_panel_us = 0, t_delivery_us = 0; // first-call accounting (scanrs_mat_get_counter)
     Scratch scratch;
     // GF(2) jump tables of the device-side seeded-panel generator (solver.cpp / omega_jump_kernel)
     DevBuf<uint64_t> jump_tab;
@@ -276,6 +287,9 @@ struct Storage {
     uint32_t tile_k = 2, tile_s = 32;     // hybrid product: record positions per (outer vector, visit), outer vectors per wave
     uint32_t tile_ku = 1;                 // ... unit positions among them (0 or 1; used with tile_k 2): count-1 nonzeros, added without a weight
     uint32_t tile_t = 48, tile_b = 4;     // ... panel rows per tile (<= 24 tile_k) and tile buffers in the LDS ring (tile_t * tile_b <= 192)
+    int side_build = 1;                   // solvers: the second product's copy / tile layout on a helper thread beside the first pass (0: built on demand by the caller's thread)
+    int tile_builder = 1;                 // layout builder: 1 = wave-level (a lane per vector, visits in lock-step, rows written whole; default shape only), 0 = per-thread walk
+    uint32_t tile_build_waves = 16;       // ... its waves per CU (0: whatever fits)
     size_t ov_tile_bytes = 0;             // hybrid product: panel slice per step of the overflow gather (0 = twice l2_tile_bytes)
     double tile_max_overflow = 0.35;      // auto path: an orientation whose layout would leave more than this share of the nonzeros to the overflow gather stays on the gather kernels
     int tile_auto = 1;                    // auto path may use the hybrid product (0: only spmm_path 3 does)
@@ -363,6 +377,9 @@ void launch_spmm_u32(Storage &st, const SparseCopy &cp, const uint32_t *X, uint3
 bool spmm_tiles_ok(const Storage &st, const SparseCopy &cp, uint32_t ldx, uint32_t l);
 bool tile_shape_ok(uint32_t K, uint32_t S, uint32_t T, uint32_t B);
 bool spmm_tiles_auto(Storage &st, SparseCopy &cp, const DevMap &map);
+// the structure of the layout (no weights) when the auto path would take it for this copy: built on stream s; false when the copy
+// is not eligible or its layout is not worth having (then remembered in cp.tile_rejected_shape)
+bool tile_layout_build_auto(Storage &st, SparseCopy &cp, hipStream_t s);
 void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l, double *out,
                        uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw);
 // per-outer-vector reductions. mode 0: sum of raw u32 counts; 1: sum of mapped values; 2: sum and sum of squares.
@@ -397,13 +414,13 @@ void launch_u32_to_scale(Storage &st, const uint32_t *counts, uint64_t n, double
 void launch_hist12(Storage &st, const uint32_t *v, uint64_t n, uint32_t shift, uint32_t digit_mask, uint32_t prefix_mask,
                    uint32_t prefix, unsigned long long *hist);
 void launch_sum_f64(Storage &st, const double *x, uint64_t n, double *out);
-void validate_copy(Storage &st, const SparseCopy &cp, uint64_t *zeros, uint64_t *bad);
+void validate_copy(Storage &st, SparseCopy &cp, uint64_t *zeros, uint64_t *bad);
 void launch_densify(Storage &st, const SparseCopy &cp, const DevMap &map, bool outer_is_view_row, uint64_t cols_v,
                     double *out);
 void launch_binom_uv(Storage &st, int kind, const double *n, uint64_t ncols, const double *rowsum, uint64_t nrows,
                      double total, double *pi, double *u, double *v);
 // build `dst` = transpose of `src` (stable: inner vectors keep ascending outer order)
-void build_transposed_copy(Storage &st, const SparseCopy &src, SparseCopy &dst);
+void build_transposed_copy(Storage &st, const SparseCopy &src, SparseCopy &dst, hipStream_t stream = nullptr);
 // drop stored zeros, compact (device). Returns new nnz.
 void compact_nonzeros(Storage &st, SparseCopy &cp);
 
@@ -429,11 +446,13 @@ int pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, ui
 int pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t max_iter, const double *v0, const scanrs_snoop *snoop,
               double *u, double *s, double *v, uint32_t *mprod);
 void omega_fill(uint64_t seed, uint64_t count, double *out);
+void jump_tables_prefetch(); // starts the background computation of the start panel generator's jump tables (once per process)
 
 // operator-level helpers shared by capi.cpp and solver.cpp
 // out[rows_v x l] = V * X  (transpose: out[cols_v x l] = V^T * X), offsets and shard reduction included.
 void mat_apply(scanrs_mat *m, bool transpose, const double *dX, uint32_t ldx, uint32_t l, double *dOut, uint32_t ldo);
 bool mat_tiles_ready(scanrs_mat *m, bool transpose);
+void prepare_second_orientation(scanrs_mat *m, bool transpose_second);
 void sort_outer_vectors(Storage &st, SparseCopy &cp);
 void launch_scale_rows(Storage &st, const double *X, uint32_t ldx, uint64_t rows, uint32_t l, const double *a, double *Xs);
 // knn.hip

@@ -1286,21 +1286,50 @@ __global__ void sum_f64_kernel(const double *__restrict__ x, uint64_t n, double 
 }
 
 // transpose helpers
-__global__ void pack_outer_kernel(const uint64_t *__restrict__ indptr, uint64_t n_outer,
-                                  const uint32_t *__restrict__ values, uint64_t nnz,
-                                  unsigned long long *__restrict__ packed) {
+// packed[p] = (outer id << 32) | count: one wave per work item (a run of at most ITEM_NNZ nonzeros of one outer vector), so the
+// outer id is known without a search and the nonzeros stream (a binary search in indptr per nonzero took 17 ms at 10^9)
+__global__ __launch_bounds__(256) void pack_outer_kernel(const Item *__restrict__ items, uint32_t n_items, const uint32_t *__restrict__ values,
+                                                         unsigned long long *__restrict__ packed) {
+    const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (wid >= n_items) return;
+    const Item it = items[wid];
+    const unsigned long long hi = (unsigned long long)it.row << 32;
+    for (uint32_t k = lane; k < it.len; k += 64u) packed[it.start + k] = hi | values[it.start + k];
+}
+// One 64-bit sort key per nonzero when (inner index, outer id, count) fit together: key = inner << (ob + cb) | outer << cb | count,
+// sorted on the inner bits only (stable: ascending outer ids inside an inner vector are kept). 8 bytes per nonzero and pass instead
+// of the 12 of a (u32 key, u64 value) pair sort, and two 8 GB buffers instead of 24 GB of temporaries at 10^9 nonzeros.
+__global__ __launch_bounds__(256) void pack_key_kernel(const Item *__restrict__ items, uint32_t n_items, const uint32_t *__restrict__ indices,
+                                                       const uint32_t *__restrict__ values, uint32_t ob, uint32_t cb,
+                                                       unsigned long long *__restrict__ keys) {
+    const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (wid >= n_items) return;
+    const Item it = items[wid];
+    const unsigned long long mid = (unsigned long long)it.row << cb;
+    for (uint32_t k = lane; k < it.len; k += 64u)
+        keys[it.start + k] = ((unsigned long long)indices[it.start + k] << (ob + cb)) | mid | values[it.start + k];
+}
+__global__ void unpack_key_kernel(const unsigned long long *__restrict__ keys, uint64_t nnz, uint32_t ob, uint32_t cb, uint32_t *__restrict__ ind,
+                                  uint32_t *__restrict__ val) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nnz) return;
-    // upper_bound(indptr, p) - 1
-    uint64_t lo = 0, hi = n_outer;
+    const unsigned long long x = keys[p];
+    ind[p] = (uint32_t)((x >> cb) & ((1ull << ob) - 1ull));
+    val[p] = (uint32_t)(x & ((1ull << cb) - 1ull));
+}
+__global__ void lower_bound_key_kernel(const unsigned long long *__restrict__ keys, uint64_t nnz, uint64_t n_inner, uint32_t shift,
+                                       uint64_t *__restrict__ indptr) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_inner) return;
+    uint64_t lo = 0, hi = nnz;
     while (lo < hi) {
-        const uint64_t mid = (lo + hi + 1) >> 1;
-        if (indptr[mid] <= p)
-            lo = mid;
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((keys[mid] >> shift) < i)
+            lo = mid + 1;
         else
-            hi = mid - 1;
+            hi = mid;
     }
-    packed[p] = ((unsigned long long)lo << 32) | values[p];
+    indptr[i] = lo;
 }
 __global__ void unpack_kernel(const unsigned long long *__restrict__ packed, uint64_t nnz, uint32_t *__restrict__ ind,
                               uint32_t *__restrict__ val) {
@@ -1324,22 +1353,55 @@ __global__ void lower_bound_kernel(const uint32_t *__restrict__ keys, uint64_t n
     }
     indptr[i] = lo;
 }
-// validation: count stored zeros and non-ascending neighbours
-__global__ void validate_kernel(const uint64_t *__restrict__ indptr, uint64_t n_outer,
-                                const uint32_t *__restrict__ indices, const uint32_t *__restrict__ values,
-                                uint64_t n_inner, unsigned long long *__restrict__ counters) {
+// Validation as two passes that both stream: (a) over the nonzeros, 4 per thread: stored zeros, indices out of range, and
+// DESCENTS — positions whose index is not above its predecessor's, wherever they are; (b) over the outer vectors: a descent at the
+// first nonzero of a vector is no violation (it compares with the previous vector's last index) and is taken off again, and
+// indptr itself must not decrease. violations = out of range + descents - descents at vector starts + decreasing indptr entries.
+// (One thread per outer vector walking its nonzeros, the round-1 form, read every line a dozen times: 45 ms at 10^9 nonzeros.)
+__global__ __launch_bounds__(256) void validate_stream_kernel(const uint32_t *__restrict__ indices, const uint32_t *__restrict__ values, uint64_t nnz,
+                                                              uint64_t n_inner, unsigned long long *__restrict__ counters) {
+    unsigned long long zeros = 0, bad = 0;
+    uint32_t vmax = 0;
+    const uint4 *I4 = reinterpret_cast<const uint4 *>(indices), *V4 = reinterpret_cast<const uint4 *>(values);
+    const uint64_t n4 = (nnz + 3) / 4; // the arrays are padded (DevBuf): the last chunk may be read whole
+    for (uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n4; c += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 ix = I4[c], vv = V4[c];
+        const uint32_t prev = c ? indices[c * 4 - 1] : 0u;
+        const uint32_t i[4] = {ix.x, ix.y, ix.z, ix.w}, v[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t p = c * 4 + k;
+            if (p >= nnz) break;
+            zeros += v[k] == 0u;
+            vmax = v[k] > vmax ? v[k] : vmax;
+            bad += (uint64_t)i[k] >= n_inner;
+            if (p > 0) bad += i[k] <= (k ? i[k - 1] : prev);
+        }
+    }
+    // wave sums, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        zeros += __shfl_down(zeros, off);
+        bad += __shfl_down(bad, off);
+        const uint32_t o = __shfl_down(vmax, off);
+        vmax = o > vmax ? o : vmax;
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (zeros) atomicAdd(&counters[0], zeros);
+        if (bad) atomicAdd(&counters[1], bad);
+        atomicMax(&counters[3], (unsigned long long)vmax); // the largest count: bounds the mapped values (col_moments_kernel) and sizes the transposed copy's sort key
+    }
+}
+__global__ void validate_starts_kernel(const uint64_t *__restrict__ indptr, uint64_t n_outer, const uint32_t *__restrict__ indices, uint64_t nnz,
+                                       unsigned long long *__restrict__ counters) {
     const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n_outer) return;
-    unsigned long long zeros = 0, bad = 0;
     const uint64_t a = indptr[o], b = indptr[o + 1];
-    if (b < a) bad++;
-    for (uint64_t p = a; p < b; p++) {
-        if (values[p] == 0) zeros++;
-        if (indices[p] >= n_inner) bad++;
-        if (p > a && indices[p] <= indices[p - 1]) bad++;
+    if (b < a || b > nnz) {
+        atomicAdd(&counters[1], 1ull);
+        return;
     }
-    if (zeros) atomicAdd(&counters[0], zeros);
-    if (bad) atomicAdd(&counters[1], bad);
+    // the first nonzero of a non-empty vector that follows another nonzero: a descent there was counted by the streaming pass
+    if (b > a && a > 0 && indices[a] <= indices[a - 1]) atomicAdd(&counters[2], 1ull);
 }
 
 // =============================================================================================
@@ -1414,12 +1476,12 @@ static void launch_spmm_t(Storage &st, const SparseCopy &cp, const DevMap &map, 
 }
 
 // the table of per-outer-vector offsets at multiples of 1024 inner positions; returns the number of base tiles
-static uint32_t ensure_bounds(Storage &st, SparseCopy &cp) {
+static uint32_t ensure_bounds(Storage &st, SparseCopy &cp, hipStream_t s = nullptr) {
     const uint32_t nb = (uint32_t)((cp.n_inner + (1ull << BT_SHIFT) - 1) >> BT_SHIFT);
     if (cp.bounds.n != cp.n_outer * (nb + 1)) {
         cp.bounds.alloc(cp.n_outer * (nb + 1));
         const uint64_t n = cp.n_outer * (nb + 1);
-        hipLaunchKernelGGL(build_bounds_kernel, grid1(n, 256), dim3(256), 0, st.stream, cp.indptr.p, cp.indices.p, cp.n_outer,
+        hipLaunchKernelGGL(build_bounds_kernel, grid1(n, 256), dim3(256), 0, s ? s : st.stream, cp.indptr.p, cp.indices.p, cp.n_outer,
                            nb, cp.bounds.p);
     }
     return nb;
@@ -1720,7 +1782,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     }
 }
 
-uint32_t ensure_bounds_public(Storage &st, SparseCopy &cp) { return ensure_bounds(st, cp); }
+uint32_t ensure_bounds_public(Storage &st, SparseCopy &cp, hipStream_t s) { return ensure_bounds(st, cp, s); }
 
 // fout[p] = the whole chain of `map` at nonzero p of `cp` (tiles.hip: weights of the overflow part)
 void materialize_map_values(Storage &st, SparseCopy &cp, const DevMap &map, double *fout) {
@@ -1933,7 +1995,7 @@ void launch_spmm_u32(Storage &st, const SparseCopy &cp, const uint32_t *X, uint3
     launch_spmm_t<uint32_t>(st, cp, map, X, ldx, l, out, ldo, nullptr, 0, nullptr, 0);
 }
 
-static uint32_t ensure_bounds(Storage &st, SparseCopy &cp);
+static uint32_t ensure_bounds(Storage &st, SparseCopy &cp, hipStream_t s);
 
 // Should the moments pass of normalize() keep the mapped values for the gather products? Not when the b-wide products of this
 // copy will run through the hybrid tile product, which keeps its own weights: 8 B per nonzero and 1.7 ms of stores per
@@ -2313,7 +2375,7 @@ static bool col_moments_plan(Storage &st, SparseCopy &cp, const DevMap &map, int
     s2 = std::ldexp(1.0, e2);
     return true;
 }
-static uint32_t ensure_bounds(Storage &st, SparseCopy &cp);
+static uint32_t ensure_bounds(Storage &st, SparseCopy &cp, hipStream_t s);
 // out_sum[i] (and out_sumsq[i]) over the outer vectors of cp, per INNER position i. false: not eligible (nothing was launched).
 bool launch_col_moments(Storage &st, SparseCopy &cp, const DevMap &map, int mode, double *out_sum, double *out_sumsq) {
     if (mode != 1 && mode != 2) return false;
@@ -2417,50 +2479,101 @@ void launch_local_allreduce(hipStream_t s, void *const *bufs, uint32_t world, ui
     SCANRS_HIP(hipGetLastError());
 }
 
-void SparseCopy::build_items(hipStream_t s) {
-    std::vector<uint64_t> h(n_outer + 1);
-    if (n_outer + 1) SCANRS_HIP(hipMemcpyAsync(h.data(), indptr.p, (n_outer + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    SCANRS_SYNC(s);
-    std::vector<Item> its;
-    std::vector<MultiRow> mr;
-    its.reserve(n_outer + nnz / ITEM_NNZ + 1);
-    uint32_t slab = 0;
-    for (uint64_t o = 0; o < n_outer; o++) {
-        const uint64_t a = h[o], b = h[o + 1];
-        const uint64_t len = b - a;
-        if (len <= ITEM_NNZ) {
-            its.push_back(Item{a, (uint32_t)o, (uint32_t)len, NO_SLAB, 0});
-        } else {
-            const uint32_t pieces = (uint32_t)((len + ITEM_NNZ - 1) / ITEM_NNZ);
-            mr.push_back(MultiRow{(uint32_t)o, slab, pieces, 0});
-            for (uint32_t k = 0; k < pieces; k++) {
-                const uint64_t s0 = a + (uint64_t)k * ITEM_NNZ;
-                const uint64_t ln = std::min<uint64_t>(ITEM_NNZ, b - s0);
-                its.push_back(Item{s0, (uint32_t)o, (uint32_t)ln, slab++, 0});
-            }
-        }
+// Work items of the gather kernels, built on the device: per outer vector the number of pieces (1, or ceil(len / ITEM_NNZ) for a
+// long vector, which also gets a MultiRow and slab rows), two exclusive scans, one fill pass — the host only reads the three
+// totals (it used to walk indptr on one core: 8 MB down, a loop over every vector, 24 MB of items up, ~15 ms at 10^6 cells).
+__global__ void item_count_kernel(const uint64_t *__restrict__ indptr, uint64_t n_outer, unsigned long long *__restrict__ pieces,
+                                  unsigned long long *__restrict__ multi_slab) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o > n_outer) return;
+    if (o == n_outer) { // the scans run over n_outer + 1 entries: the last one receives the totals
+        pieces[o] = 0;
+        multi_slab[o] = 0;
+        return;
     }
-    n_items = (uint32_t)its.size();
-    n_multi = (uint32_t)mr.size();
-    n_slab = slab;
-    items.alloc(its.size());
-    multi.alloc(mr.size());
-    if (!its.empty()) SCANRS_HIP(hipMemcpyAsync(items.p, its.data(), its.size() * sizeof(Item), hipMemcpyHostToDevice, s));
-    if (!mr.empty()) SCANRS_HIP(hipMemcpyAsync(multi.p, mr.data(), mr.size() * sizeof(MultiRow), hipMemcpyHostToDevice, s));
-    SCANRS_SYNC(s);
+    const uint64_t len = indptr[o + 1] - indptr[o];
+    const bool multi = len > ITEM_NNZ;
+    const unsigned long long np = multi ? (len + ITEM_NNZ - 1) / ITEM_NNZ : 1ull;
+    pieces[o] = np;
+    multi_slab[o] = multi ? (1ull | (np << 32)) : 0ull; // low word: MultiRows so far, high word: slab rows so far
+}
+__global__ void item_fill_kernel(const uint64_t *__restrict__ indptr, uint64_t n_outer, const unsigned long long *__restrict__ item_off,
+                                 const unsigned long long *__restrict__ multi_slab_off, Item *__restrict__ items, MultiRow *__restrict__ multi) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_outer) return;
+    const uint64_t a = indptr[o], b = indptr[o + 1], len = b - a;
+    const uint64_t at = item_off[o];
+    if (len <= ITEM_NNZ) {
+        items[at] = Item{a, (uint32_t)o, (uint32_t)len, NO_SLAB, 0};
+        return;
+    }
+    const uint32_t pieces = (uint32_t)((len + ITEM_NNZ - 1) / ITEM_NNZ);
+    const unsigned long long ms = multi_slab_off[o];
+    const uint32_t slab0 = (uint32_t)(ms >> 32);
+    multi[(uint32_t)ms] = MultiRow{(uint32_t)o, slab0, pieces, 0};
+    for (uint32_t k = 0; k < pieces; k++) {
+        const uint64_t s0 = a + (uint64_t)k * ITEM_NNZ;
+        const uint64_t ln = b - s0 < ITEM_NNZ ? b - s0 : ITEM_NNZ;
+        items[at + k] = Item{s0, (uint32_t)o, (uint32_t)ln, slab0 + k, 0};
+    }
 }
 
-void validate_copy(Storage &st, const SparseCopy &cp, uint64_t *zeros, uint64_t *bad) {
-    DevBuf<unsigned long long> c(2);
-    SCANRS_HIP(hipMemsetAsync(c.p, 0, 2 * sizeof(unsigned long long), st.stream));
-    if (cp.n_outer)
-        hipLaunchKernelGGL(validate_kernel, grid1(cp.n_outer, 256), dim3(256), 0, st.stream, cp.indptr.p, cp.n_outer,
-                           cp.indices.p, cp.values.p, cp.n_inner, c.p);
-    unsigned long long h[2];
+void SparseCopy::build_items(hipStream_t s) {
+    n_items = n_multi = n_slab = 0;
+    if (n_outer == 0) {
+        items.alloc(0);
+        multi.alloc(0);
+        return;
+    }
+    const size_t n = (size_t)n_outer + 1;
+    DevBuf<unsigned long long> cnt(2 * n), off(2 * n);
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(item_count_kernel, grid, dim3(256), 0, s, indptr.p, n_outer, cnt.p, cnt.p + n);
+    size_t tmp_bytes = 0;
+    SCANRS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt.p, off.p, 0ull, n, rocprim::plus<unsigned long long>(), s));
+    DevBuf<char> tmp(std::max<size_t>(tmp_bytes, 16));
+    SCANRS_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, cnt.p, off.p, 0ull, n, rocprim::plus<unsigned long long>(), s));
+    SCANRS_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, cnt.p + n, off.p + n, 0ull, n, rocprim::plus<unsigned long long>(), s));
+    unsigned long long tot[2] = {0, 0};
+    SCANRS_HIP(hipMemcpyAsync(&tot[0], off.p + n_outer, 8, hipMemcpyDeviceToHost, s));
+    SCANRS_HIP(hipMemcpyAsync(&tot[1], off.p + n + n_outer, 8, hipMemcpyDeviceToHost, s));
+    SCANRS_SYNC(s);
+    if (tot[0] > 0xFFFFFFFFull) fail(SCANRS_ERR_SHAPE, "matrix needs more than 2^32 - 1 work items");
+    n_items = (uint32_t)tot[0];
+    n_multi = (uint32_t)tot[1];
+    n_slab = (uint32_t)(tot[1] >> 32);
+    items.alloc(n_items);
+    multi.alloc(n_multi);
+    hipLaunchKernelGGL(item_fill_kernel, grid, dim3(256), 0, s, indptr.p, n_outer, off.p, off.p + n, items.p, multi.p);
+    SCANRS_HIP(hipGetLastError());
+    SCANRS_SYNC(s); // the temporaries are released on return
+}
+
+void validate_copy(Storage &st, SparseCopy &cp, uint64_t *zeros, uint64_t *bad) {
+    DevBuf<unsigned long long> c(4);
+    SCANRS_HIP(hipMemsetAsync(c.p, 0, 4 * sizeof(unsigned long long), st.stream));
+    if (cp.n_outer) {
+        hipLaunchKernelGGL(validate_starts_kernel, grid1(cp.n_outer, 256), dim3(256), 0, st.stream, cp.indptr.p, cp.n_outer, cp.indices.p, cp.nnz, c.p);
+        unsigned long long h1 = 0; // a broken indptr first: the streaming pass below trusts nnz only, the later passes trust indptr
+        SCANRS_HIP(hipMemcpyAsync(&h1, c.p + 1, 8, hipMemcpyDeviceToHost, st.stream));
+        SCANRS_SYNC(st.stream);
+        if (h1) {
+            *zeros = 0;
+            *bad = h1;
+            return;
+        }
+    }
+    if (cp.nnz) {
+        const uint64_t n4 = (cp.nnz + 3) / 4;
+        const unsigned blocks = (unsigned)std::min<uint64_t>((n4 + 255) / 256, 1u << 16);
+        hipLaunchKernelGGL(validate_stream_kernel, dim3(blocks), dim3(256), 0, st.stream, cp.indices.p, cp.values.p, cp.nnz, cp.n_inner, c.p);
+    }
+    unsigned long long h[4];
     SCANRS_HIP(hipMemcpyAsync(h, c.p, sizeof(h), hipMemcpyDeviceToHost, st.stream));
     SCANRS_SYNC(st.stream);
     *zeros = h[0];
-    *bad = h[1];
+    *bad = h[1] - std::min(h[1], h[2]);
+    if (cp.nnz) cp.max_value = (uint32_t)std::max<unsigned long long>(1ull, h[3]);
 }
 
 void compact_nonzeros(Storage &st, SparseCopy &cp) {
@@ -2515,7 +2628,8 @@ void sort_outer_vectors(Storage &st, SparseCopy &cp) {
     SCANRS_SYNC(st.stream);
 }
 
-void build_transposed_copy(Storage &st, const SparseCopy &src, SparseCopy &dst) {
+void build_transposed_copy(Storage &st, const SparseCopy &src, SparseCopy &dst, hipStream_t stream) {
+    hipStream_t s = stream ? stream : st.stream;
     Tick tick("transposed copy build");
     dst.n_outer = src.n_inner;
     dst.n_inner = src.n_outer;
@@ -2525,34 +2639,54 @@ void build_transposed_copy(Storage &st, const SparseCopy &src, SparseCopy &dst) 
     dst.values.alloc(std::max<uint64_t>(1, dst.nnz));
     const uint64_t nnz = src.nnz;
     if (nnz == 0) {
-        SCANRS_HIP(hipMemsetAsync(dst.indptr.p, 0, (dst.n_outer + 1) * 8, st.stream));
-        dst.build_items(st.stream);
+        SCANRS_HIP(hipMemsetAsync(dst.indptr.p, 0, (dst.n_outer + 1) * 8, s));
+        dst.build_items(s);
         return;
     }
-    {
+    auto bits_for = [](uint64_t maxv) { // bits that hold 0 .. maxv
+        uint32_t b = 1;
+        while (b < 64 && (maxv >> b) != 0) b++;
+        return b;
+    };
+    const uint32_t ib = bits_for(src.n_inner ? src.n_inner - 1 : 0), ob = bits_for(src.n_outer ? src.n_outer - 1 : 0);
+    const uint32_t cb = src.max_value ? bits_for(src.max_value) : 32u; // max_value is known for every copy that went through validation
+    dst.max_value = src.max_value;
+    if (ib + ob + cb <= 64u) {
+        // one packed 64-bit key per nonzero, sorted on its inner-index bits (see pack_key_kernel)
+        DevBuf<unsigned long long> ka(nnz), kb2(nnz);
+        hipLaunchKernelGGL(pack_key_kernel, dim3((src.n_items + 3u) / 4u), dim3(256), 0, s, src.items.p, src.n_items, src.indices.p, src.values.p, ob, cb, ka.p);
+        rocprim::double_buffer<unsigned long long> kb(ka.p, kb2.p);
+        size_t tmp_bytes = 0;
+        SCANRS_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, kb, (size_t)nnz, ob + cb, ob + cb + ib, s));
+        DevBuf<char> tmp(std::max<size_t>(tmp_bytes, 16));
+        SCANRS_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, kb, (size_t)nnz, ob + cb, ob + cb + ib, s));
+        hipLaunchKernelGGL(unpack_key_kernel, grid1(nnz, 256), dim3(256), 0, s, kb.current(), nnz, ob, cb, dst.indices.p, dst.values.p);
+        hipLaunchKernelGGL(lower_bound_key_kernel, grid1(dst.n_outer + 1, 256), dim3(256), 0, s, kb.current(), nnz, dst.n_outer, ob + cb, dst.indptr.p);
+        SCANRS_HIP(hipGetLastError());
+        SCANRS_SYNC(s);
+    } else {
         // stable LSD radix sort of (inner index, (outer id, value)): inner vectors come out with
         // ascending outer ids, the order the reference's CSC kernel accumulates in (prod.rs:190-214).
         DevBuf<uint32_t> keys_a(nnz), keys_b(nnz);
         DevBuf<unsigned long long> vals_a(nnz), vals_b(nnz);
-        SCANRS_HIP(hipMemcpyAsync(keys_a.p, src.indices.p, nnz * 4, hipMemcpyDeviceToDevice, st.stream));
-        hipLaunchKernelGGL(pack_outer_kernel, grid1(nnz, 256), dim3(256), 0, st.stream, src.indptr.p, src.n_outer,
-                           src.values.p, nnz, vals_a.p);
+        SCANRS_HIP(hipMemcpyAsync(keys_a.p, src.indices.p, nnz * 4, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(pack_outer_kernel, dim3((src.n_items + 3u) / 4u), dim3(256), 0, s, src.items.p, src.n_items, src.values.p, vals_a.p);
         unsigned end_bit = 1;
         while (end_bit < 32 && (1ull << end_bit) < src.n_inner) end_bit++;
         rocprim::double_buffer<uint32_t> kb(keys_a.p, keys_b.p);
         rocprim::double_buffer<unsigned long long> vb(vals_a.p, vals_b.p);
         size_t tmp_bytes = 0;
-        SCANRS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kb, vb, (size_t)nnz, 0u, end_bit, st.stream));
+        SCANRS_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, kb, vb, (size_t)nnz, 0u, end_bit, s));
         DevBuf<char> tmp(std::max<size_t>(tmp_bytes, 16));
-        SCANRS_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kb, vb, (size_t)nnz, 0u, end_bit, st.stream));
-        hipLaunchKernelGGL(unpack_kernel, grid1(nnz, 256), dim3(256), 0, st.stream, vb.current(), nnz, dst.indices.p,
+        SCANRS_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, kb, vb, (size_t)nnz, 0u, end_bit, s));
+        hipLaunchKernelGGL(unpack_kernel, grid1(nnz, 256), dim3(256), 0, s, vb.current(), nnz, dst.indices.p,
                            dst.values.p);
-        hipLaunchKernelGGL(lower_bound_kernel, grid1(dst.n_outer + 1, 256), dim3(256), 0, st.stream, kb.current(), nnz,
+        hipLaunchKernelGGL(lower_bound_kernel, grid1(dst.n_outer + 1, 256), dim3(256), 0, s, kb.current(), nnz,
                            dst.n_outer, dst.indptr.p);
         SCANRS_HIP(hipGetLastError());
-        SCANRS_SYNC(st.stream);
+        SCANRS_SYNC(s);
     }
-    dst.build_items(st.stream);
+    dst.build_items(s);
 }
 
 } // namespace scanrs

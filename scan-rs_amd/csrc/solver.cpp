@@ -14,7 +14,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -135,6 +137,19 @@ static std::vector<uint64_t> jump_powers(uint64_t d, int n_pow) {
     return out;
 }
 
+// The tables depend on (d, n_pow) only and cost ~10 ms of one host core: computed once per process, by a background thread that
+// the first handle creation starts (scanrs_mat_create*), for n_pow up to JUMP_NPOW_SHARED — panels of up to 2^26 x 512 draws; a
+// prefix of the table serves every smaller panel.
+constexpr uint64_t JUMP_D = 512;
+constexpr int JUMP_NPOW_SHARED = 26;
+namespace {
+std::once_flag g_jump_once;
+std::shared_future<std::vector<uint64_t>> g_jump_future;
+}
+void jump_tables_prefetch() {
+    std::call_once(g_jump_once, [] { g_jump_future = std::async(std::launch::async, [] { return jump_powers(JUMP_D, JUMP_NPOW_SHARED); }).share(); });
+}
+
 // Fill a device panel with the seeded Uniform(-1, 1) stream: `out` holds the (seq_rows x seq_cols) row-major
 // sequence, or its transpose, with leading dimension ld.
 static void omega_fill_device(Storage &st, uint64_t seed, uint64_t seq_rows, uint64_t seq_cols, double *out, uint32_t ld,
@@ -145,10 +160,18 @@ static void omega_fill_device(Storage &st, uint64_t seed, uint64_t seq_rows, uin
     const uint64_t streams = (total + d - 1) / d;
     int n_pow = 1;
     while ((1ull << n_pow) < streams) n_pow++;
-    if (st.jump_d != d || st.jump_npow < n_pow) { // tables depend only on (d, n_pow): built once per handle
-        const std::vector<uint64_t> tab = jump_powers(d, n_pow);
-        st.jump_tab.alloc(tab.size());
-        SCANRS_HIP(hipMemcpyAsync(st.jump_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st.stream));
+    if (st.jump_d != d || st.jump_npow < n_pow) { // tables depend only on (d, n_pow): uploaded once per handle
+        std::vector<uint64_t> own;
+        const std::vector<uint64_t> *tab = &own;
+        if (d == JUMP_D && n_pow <= JUMP_NPOW_SHARED) {
+            jump_tables_prefetch();
+            tab = &g_jump_future.get(); // [k][256][4]: the first n_pow planes are the table of a smaller panel
+        } else {
+            own = jump_powers(d, n_pow);
+        }
+        const size_t count = (size_t)n_pow * 1024;
+        st.jump_tab.alloc(count);
+        SCANRS_HIP(hipMemcpyAsync(st.jump_tab.p, tab->data(), count * 8, hipMemcpyHostToDevice, st.stream));
         SCANRS_SYNC(st.stream);
         st.jump_d = d;
         st.jump_npow = n_pow;
@@ -690,9 +713,11 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
         c.sync();
         stage_mark("ritz factors synced");
         Tick tk("ritz: download of the factors");
+        const auto t0 = std::chrono::steady_clock::now();
         if (hS) download_panel(c, dS, ldk, ds, k, hS); // null: the caller keeps the result in HBM (scanrs_pca_result_device)
         if (hT) download_panel(c, dT, ldk, dt, k, hT);
         c.sync();
+        c.st.t_delivery_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     }
     // where the factors live on the device: side S first, side T second (the drivers map them to U / V)
     c.st.pca_dev.k = k;
@@ -720,6 +745,10 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
         int n0 = std::uncaught_exceptions();
         ~Drain() {
             if (std::uncaught_exceptions() > n0) {
+                try {
+                    st.side_join_if(nullptr); // the helper thread that builds the second orientation, if it still runs
+                } catch (const Failure &) {
+                }
                 (void)wait_stream_quiet(st.stream);
                 if (st.aux_stream) (void)wait_stream_quiet(st.aux_stream);
                 if (st.aux2_stream) (void)wait_stream_quiet(st.aux2_stream);
@@ -772,6 +801,8 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
         progress_check(snoop, 1.0);
         return SCANRS_OK;
     }
+    // the copy / tile layout of the SECOND product on a helper thread, beside everything up to the end of the first pass
+    prepare_second_orientation(m, !to_t_transpose);
     const uint32_t ldb = even_up(b), q = b * n_iter, ldq = even_up(q);
     double *P = c.dev("bk_P", (size_t)ds * ldb);
     double *Ptmp = c.dev("bk_Ptmp", (size_t)ds * ldb);
@@ -782,6 +813,11 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
 
     { // start panel: m >= n -> (n x b) as is; n > m -> reference holds (b x m), we hold its transpose
         Tick tk("bk: start panel");
+        struct Acc {
+            uint64_t &t;
+            std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+            ~Acc() { t += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+        } acc{c.st.t_start_panel_us};
         if (!omega) {
             // reference order: (n x b) row-major when m >= n, else (b x m) row-major held transposed here
             if (rows_ge)
@@ -1167,6 +1203,7 @@ int pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, ui
         }
     }
     // Q = qr(A Omega).Q   (rand_svd.rs:87 / :109)
+    prepare_second_orientation(m, !om_to_q_transpose);
     mat_apply(m, om_to_q_transpose, Om, ldl, l, Qp, ldl);
     orth_cholqr(c, Qp, tmp, ldl, l, d_q, q_sharded);
     for (uint32_t it = 0; it < n_iter; it++) { // rand_svd.rs:89-92 / :111-114

@@ -153,6 +153,179 @@ __global__ __launch_bounds__(256) void tile_assign_kernel(const uint64_t *__rest
     if (!FILL) ovc[e] = n_ov;
 }
 
+// The same assignment, one LANE per outer vector and the wave in lock-step over the visits (round 4; the default for K = 2, B = 4,
+// S = 32). The per-thread walk above reads its vector 4 bytes at a time from wherever it stands and writes 3-byte records all
+// over the layout: every 128-byte line travels from the L2 to a CU a dozen times and the record rows are patched together in
+// the L2 (157 GB of HBM traffic and 47-62 ms per launch at 10^9 nonzeros for 6 GB of output). Here
+//   * a wave owns two groups (64 vectors) and one part; visit v is worked by all lanes together: every lane takes the nonzeros
+//     of its vector that lie in tile v (the wave loops while any lane has one: about 5 trips at 1.4 nonzeros per vector and tile)
+//     and deals them to the positions of visits v .. v+2 exactly as above (same two queues, same tie rule) — but into a WINDOW of
+//     three visits held in registers; when tile v is done, the row of visit v is complete and leaves as whole 64-byte runs
+//     (32 lanes x u16 rows, 32 x u8 counts per group and position): every record is written exactly once, used or not, so the
+//     layout needs no initialisation pass;
+//   * a lane reads its vector in aligned 16-byte chunks (4 indices, 4 counts) through two chunk registers; the chunk after the
+//     current one is requested at the END of a visit and first looked at in the next one, so the wave does not stand on a load
+//     it has just issued; only a vector with more than 4-8 nonzeros in ONE tile (dense genes) waits inside a visit.
+// FILL = false counts the nonzeros no visit has room for (per vector and part), FILL = true writes records and overflow part.
+template <bool FILL, uint32_t T, uint32_t KU>
+__global__ __launch_bounds__(64) void tile_assign_wave_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                              const uint32_t *__restrict__ values, uint64_t n_outer, uint64_t n_groups, TileShape sh,
+                                                              unsigned long long *__restrict__ ovc, const unsigned long long *__restrict__ ov_off,
+                                                              uint16_t *__restrict__ prow, uint8_t *__restrict__ pcnt,
+                                                              uint32_t *__restrict__ ov_indices, uint32_t *__restrict__ ov_values) {
+    constexpr uint32_t KG = 2u - KU, B = 4u;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t item = blockIdx.x;
+    const uint64_t gp = item / sh.n_parts;
+    const uint32_t part = (uint32_t)(item - gp * sh.n_parts);
+    const uint64_t o = gp * 64u + lane;
+    const bool valid = o < n_outer;
+    const uint64_t g = gp * 2u + (lane >> 5);
+    const uint32_t q = lane & 31u;
+    const uint32_t t0 = part * sh.tpp, t1 = min(sh.nt, t0 + sh.tpp);
+    const uint64_t s = valid ? indptr[o] : 0ull, end = valid ? indptr[o + 1] : 0ull;
+    uint64_t p = s;
+    if (t0 > 0) { // first nonzero of the part
+        uint64_t lo = s, hi = end;
+        const uint64_t key = (uint64_t)t0 * T;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if ((uint64_t)indices[mid] < key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        p = lo;
+    }
+    const uint4 *I4 = reinterpret_cast<const uint4 *>(indices), *V4 = reinterpret_cast<const uint4 *>(values);
+    uint64_t ca = p >> 2; // chunk held in (ai, av); (bi, bv) holds chunk ca + 1. Reads run at most two chunks past a vector's end: the arrays are padded (DevBuf)
+    uint4 ai = I4[ca], av = V4[ca], bi = I4[ca + 1], bv = V4[ca + 1];
+    // element k of the chunk the position is in: selects only (an indexed uint4 would live in scratch memory)
+    auto pick = [](bool second, uint32_t k, uint4 a, uint4 b) {
+        const uint32_t x0 = second ? b.x : a.x, x1 = second ? b.y : a.y, x2 = second ? b.z : a.z, x3 = second ? b.w : a.w;
+        const uint32_t lo = (k & 1u) ? x1 : x0, hi = (k & 1u) ? x3 : x2;
+        return (k & 2u) ? hi : lo;
+    };
+    uint32_t vu = t0, cu = KU, vg = t0, cg = KG;
+    uint32_t w00 = 0, w01 = 0, w10 = 0, w11 = 0, w20 = 0, w21 = 0; // window: visit v + d, position j -> code | count << 16 (0: free)
+    unsigned long long n_ov = 0;
+    unsigned long long op = (FILL && valid) ? ov_off[o * sh.n_parts + part] : 0ull;
+    for (uint32_t v = t0; v < t1; v++) {
+        const uint64_t lim = (uint64_t)(v + 1u) * T; // nonzeros below it belong to tile v (everything below v T has been worked)
+        for (;;) {
+            for (;;) {
+                const uint64_t ck = p >> 2;
+                const bool inb = ck != ca;
+                const bool avail = ck <= ca + 1u;
+                const uint32_t k = (uint32_t)p & 3u;
+                const uint32_t idx = pick(inb, k, ai, bi), cnt = pick(inb, k, av, bv);
+                const bool has = p < end && avail && (uint64_t)idx < lim;
+                if (!__builtin_amdgcn_ballot_w64(has)) break;
+                if (has) {
+                    const uint32_t tau = v;
+                    const uint32_t last = min(tau + B - 2u, t1 - 1u);
+                    uint32_t au = vu, bu = cu, ag = vg, bg = cg;
+                    if (tau > au) {
+                        au = tau;
+                        bu = KU;
+                    }
+                    if (bu == 0) {
+                        au++;
+                        bu = KU;
+                    }
+                    if (tau > ag) {
+                        ag = tau;
+                        bg = KG;
+                    }
+                    if (bg == 0) {
+                        ag++;
+                        bg = KG;
+                    }
+                    const bool can_u = KU > 0 && cnt == 1u && au <= last;
+                    const bool can_g = KG > 0 && cnt <= 255u && ag <= last;
+                    if (!can_u && !can_g) {
+                        if (FILL) {
+                            ov_indices[op] = idx;
+                            ov_values[op] = cnt;
+                            op++;
+                        } else {
+                            n_ov++;
+                        }
+                    } else {
+                        const bool use_u = can_u && (!can_g || au <= ag);
+                        uint32_t vis, j;
+                        if (use_u) {
+                            vis = au;
+                            j = KU - bu;
+                            vu = au;
+                            cu = bu - 1u;
+                        } else {
+                            vis = ag;
+                            j = KU + (KG - bg);
+                            vg = ag;
+                            cg = bg - 1u;
+                        }
+                        if (FILL) {
+                            const uint32_t rec = ((tau & 3u) * T + (idx - tau * T)) | (cnt << 16);
+                            const uint32_t d = vis - v;
+                            if (d == 0u) {
+                                if (j == 0u) w00 = rec; else w01 = rec;
+                            } else if (d == 1u) {
+                                if (j == 0u) w10 = rec; else w11 = rec;
+                            } else {
+                                if (j == 0u) w20 = rec; else w21 = rec;
+                            }
+                        }
+                    }
+                    p++;
+                }
+            }
+            // a lane that ran out of chunks inside the tile (more than 4-8 nonzeros of one vector in one tile): fetch and go on
+            const uint64_t ck = p >> 2;
+            const bool starved = p < end && ck > ca + 1u;
+            if (!__builtin_amdgcn_ballot_w64(starved)) break;
+            if (starved) {
+                ca = ck;
+                ai = I4[ca];
+                av = V4[ca];
+                bi = I4[ca + 1];
+                bv = V4[ca + 1];
+            }
+        }
+        if (FILL && g < n_groups) { // the row of visit v: whole 64-byte runs per group and position
+            const uint64_t row = (g * sh.nt + v) * 64u;
+            const uint32_t e0 = w00 ? w00 : (KU > 0 ? B * T : (v & 3u) * T); // an unused unit position reads the row of zeros behind the ring,
+            const uint32_t e1 = w01 ? w01 : (v & 3u) * T;                    // an unused general one row 0 of the visit's own tile (weight 0)
+            prow[row + q] = (uint16_t)e0;
+            prow[row + 32u + q] = (uint16_t)e1;
+            pcnt[row + q] = (uint8_t)(e0 >> 16);
+            pcnt[row + 32u + q] = (uint8_t)(e1 >> 16);
+        }
+        w00 = w10;
+        w01 = w11;
+        w10 = w20;
+        w11 = w21;
+        w20 = 0;
+        w21 = 0;
+        // advance the chunk registers here, a visit ahead of their use
+        const uint64_t ck = p >> 2;
+        if (ck == ca + 1u) {
+            ai = bi;
+            av = bv;
+            ca = ck;
+            bi = I4[ca + 1];
+            bv = V4[ca + 1];
+        } else if (ck > ca + 1u) {
+            ca = ck;
+            ai = I4[ca];
+            av = V4[ca];
+            bi = I4[ca + 1];
+            bv = V4[ca + 1];
+        }
+    }
+    if (!FILL && valid) ovc[o * sh.n_parts + part] = n_ov;
+}
+
 // An unused general position reads a row that is certainly in the ring at its visit — row 0 of the visit's own tile — with
 // weight 0; an unused unit position (no weight) reads the row of zeros that the kernel keeps behind the ring (row B T).
 __global__ void tile_init_rows_kernel(uint16_t *__restrict__ prow, uint64_t n_rec, TileShape sh) {
@@ -371,7 +544,7 @@ struct TileLayout {
 
 void tile_layout_free(TileLayout *t) { delete t; }
 
-uint32_t ensure_bounds_public(Storage &st, SparseCopy &cp); // kernels.hip
+uint32_t ensure_bounds_public(Storage &st, SparseCopy &cp, hipStream_t s); // kernels.hip
 void materialize_map_values(Storage &st, SparseCopy &cp, const DevMap &map, double *fout); // kernels.hip
 
 // unit positions exist for K = 2 only (one unit + one general position per visit)
@@ -382,7 +555,7 @@ bool tile_shape_ok(uint32_t K, uint32_t S, uint32_t T, uint32_t B) {
 
 // max_overflow > 0: give up (nullptr) when more than that share of the nonzeros would land in the overflow part — known after the
 // counting pass, before anything large is allocated.
-TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_overflow) {
+TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_overflow, hipStream_t stream = nullptr) {
     Tick tick("tile layout build");
     if (!tile_shape_ok(st.tile_k, st.tile_s, st.tile_t, st.tile_b))
         fail(SCANRS_ERR_ARGUMENT, "unsupported tile shape K=%u S=%u T=%u B=%u", st.tile_k, st.tile_s, st.tile_t, st.tile_b);
@@ -407,7 +580,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     parts = std::min<uint32_t>(parts, std::max<uint32_t>(1u, sh.nt / 16u));
     sh.tpp = (sh.nt + parts - 1) / parts;
     sh.n_parts = (sh.nt + sh.tpp - 1) / sh.tpp;
-    hipStream_t s = st.stream;
+    hipStream_t s = stream ? stream : st.stream;
     const uint64_t n_rec = tl->n_groups * sh.nt * sh.nset * 64u;
     if (n_rec == 0) return tl.release();
     if (tl->n_groups * sh.nt > 0xFFFFFFFFull || (sh.nset & (sh.nset - 1u))) fail(SCANRS_ERR_SHAPE, "matrix too large for the tile layout's 32-bit visit index");
@@ -424,8 +597,26 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     DevBuf<unsigned long long> ovc(n_seg + 1), ovo(n_seg + 1);
     SCANRS_HIP(hipMemsetAsync(ovc.p + n_seg, 0, 8, s));
     const dim3 grid((unsigned)((n_seg + 255) / 256));
-    hipLaunchKernelGGL((tile_assign_kernel<false>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, cp.n_outer, sh, ovc.p,
-                       (const unsigned long long *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    // the wave-level builder serves the default shape; other shapes (experiments) keep the per-thread walk
+    const bool wave_builder = st.tile_builder != 0 && sh.K == 2u && sh.B == 4u && sh.S == 32u && sh.T == 48u && sh.nset == 1u;
+    const uint64_t n_witems = ((tl->n_groups + 1) / 2) * sh.n_parts;
+    if (wave_builder && n_witems > 0x7FFFFFFFull) fail(SCANRS_ERR_SHAPE, "matrix too large for the tile layout builder's grid");
+    // waves per CU of the builder: its lanes read 64 different places of the matrix, so the lines in flight (2 x 128 B per lane) of
+    // all resident waves must fit the L2 or they come from HBM several times; a dummy LDS allocation per wave caps the occupancy
+    const size_t wb_lds = st.tile_build_waves ? std::min<size_t>(65536, TL_LDS / st.tile_build_waves) : 0;
+    if (wave_builder) {
+        if (sh.KU)
+            hipLaunchKernelGGL((tile_assign_wave_kernel<false, 48, 1>), dim3((unsigned)n_witems), dim3(64), wb_lds, s, cp.indptr.p, cp.indices.p, cp.values.p,
+                               cp.n_outer, tl->n_groups, sh, ovc.p, (const unsigned long long *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr,
+                               (uint32_t *)nullptr, (uint32_t *)nullptr);
+        else
+            hipLaunchKernelGGL((tile_assign_wave_kernel<false, 48, 0>), dim3((unsigned)n_witems), dim3(64), wb_lds, s, cp.indptr.p, cp.indices.p, cp.values.p,
+                               cp.n_outer, tl->n_groups, sh, ovc.p, (const unsigned long long *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr,
+                               (uint32_t *)nullptr, (uint32_t *)nullptr);
+    } else {
+        hipLaunchKernelGGL((tile_assign_kernel<false>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, cp.n_outer, sh, ovc.p,
+                           (const unsigned long long *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    }
     size_t tmp_bytes = 0;
     SCANRS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, ovc.p, ovo.p, 0ull, (size_t)n_seg + 1, rocprim::plus<unsigned long long>(), s));
     DevBuf<char> tmp(std::max<size_t>(tmp_bytes, 16));
@@ -444,10 +635,12 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     tl->pcnt.alloc(n_rec);
     tl->pw.alloc(n_rec);
     lap("hipMalloc of records");
-    hipLaunchKernelGGL(tile_init_rows_kernel, dim3((unsigned)std::min<uint64_t>((n_rec / 4 + 255) / 256, 1u << 23)), dim3(256), 0, s, tl->prow.p, n_rec, sh);
-    SCANRS_HIP(hipMemsetAsync(tl->pcnt.p, 0, n_rec, s));
-    SCANRS_HIP(hipMemsetAsync(tl->pw.p, 0, n_rec * 8, s)); // unused positions: weight 0 for good
-    lap("init rows + counts");
+    // (the weights need no initialisation: tile_weights_kernel writes every position that is ever read, used or not)
+    if (!wave_builder) { // the per-thread walk patches records into an initialised layout; the wave builder writes every record itself
+        hipLaunchKernelGGL(tile_init_rows_kernel, dim3((unsigned)std::min<uint64_t>((n_rec / 4 + 255) / 256, 1u << 23)), dim3(256), 0, s, tl->prow.p, n_rec, sh);
+        SCANRS_HIP(hipMemsetAsync(tl->pcnt.p, 0, n_rec, s));
+        lap("init rows + counts");
+    }
     SparseCopy &ov = tl->ov;
     ov.n_outer = cp.n_outer;
     ov.n_inner = cp.n_inner;
@@ -457,11 +650,20 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     ov.indices.alloc(std::max<uint64_t>(n_ov, 1));
     ov.values.alloc(std::max<uint64_t>(n_ov, 1));
     ov.fvals.alloc(std::max<uint64_t>(n_ov, 1));
-    hipLaunchKernelGGL((tile_assign_kernel<true>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, cp.n_outer, sh,
-                       (unsigned long long *)nullptr, ovo.p, tl->prow.p, tl->pcnt.p, ov.indices.p, ov.values.p);
+    if (wave_builder) {
+        if (sh.KU)
+            hipLaunchKernelGGL((tile_assign_wave_kernel<true, 48, 1>), dim3((unsigned)n_witems), dim3(64), wb_lds, s, cp.indptr.p, cp.indices.p, cp.values.p,
+                               cp.n_outer, tl->n_groups, sh, (unsigned long long *)nullptr, ovo.p, tl->prow.p, tl->pcnt.p, ov.indices.p, ov.values.p);
+        else
+            hipLaunchKernelGGL((tile_assign_wave_kernel<true, 48, 0>), dim3((unsigned)n_witems), dim3(64), wb_lds, s, cp.indptr.p, cp.indices.p, cp.values.p,
+                               cp.n_outer, tl->n_groups, sh, (unsigned long long *)nullptr, ovo.p, tl->prow.p, tl->pcnt.p, ov.indices.p, ov.values.p);
+    } else {
+        hipLaunchKernelGGL((tile_assign_kernel<true>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, cp.n_outer, sh,
+                           (unsigned long long *)nullptr, ovo.p, tl->prow.p, tl->pcnt.p, ov.indices.p, ov.values.p);
+    }
     SCANRS_HIP(hipGetLastError());
     lap("fill");
-    if (n_ov) ensure_bounds_public(st, ov);
+    if (n_ov) ensure_bounds_public(st, ov, s);
     SCANRS_SYNC(s); // the temporaries are released on return
     lap("overflow bounds");
     if (trace_on())
@@ -830,21 +1032,20 @@ bool spmm_tiles_ok(const Storage &st, const SparseCopy &cp, uint32_t ldx, uint32
 // Auto path (spmm_path 0): the hybrid product serves a large matrix once its layout under this map exists — built when a
 // solver announces many products (Storage::tile_hint) or when the same map comes by a second time, and only if the device
 // has room for it (about 16 bytes per nonzero per orientation).
-bool spmm_tiles_auto(Storage &st, SparseCopy &cp, const DevMap &map) {
+static uint64_t tile_shape_signature(const Storage &st) {
+    return 1ull + st.tile_k + 16ull * st.tile_s + 4096ull * st.tile_t + (1ull << 24) * st.tile_b + (1ull << 32) * st.tile_ku +
+           (1ull << 34) * (uint64_t)(st.tile_max_overflow * 1000.0);
+}
+// large enough, the visit index fits, and this shape has not been found wanting for this copy before
+static bool tile_auto_candidate(const Storage &st, const SparseCopy &cp) {
     if (!st.tile_auto || cp.nnz < std::max<uint64_t>(st.blocked_min_nnz, 1ull << 24)) return false;
+    if (!tile_shape_ok(st.tile_k, st.tile_s, st.tile_t, st.tile_b)) return false;
     if (((cp.n_outer + st.tile_s - 1) / st.tile_s) * ((cp.n_inner + st.tile_t - 1) / st.tile_t) > 0xFFFFFFFFull) return false; // 32-bit visit index
-    if (cp.tiles && cp.tiles->structure_matches(st)) return true; // the weights follow the map in one streaming pass
-    const uint64_t shape_sig = 1ull + st.tile_k + 16ull * st.tile_s + 4096ull * st.tile_t + (1ull << 24) * st.tile_b + (1ull << 32) * st.tile_ku +
-                               (1ull << 34) * (uint64_t)(st.tile_max_overflow * 1000.0);
-    if (cp.tile_rejected_shape == shape_sig) return false; // this shape left too much in the overflow part (below)
-    bool seen = cp.tsig_n == map.n;
-    for (int i = 0; seen && i < map.n; i++) seen = cp.tsig_id[i] == map.ops[i].id && cp.tsig_outer[i] == map.ops[i].a_outer;
-    cp.tsig_n = map.n;
-    for (int i = 0; i < map.n; i++) {
-        cp.tsig_id[i] = map.ops[i].id;
-        cp.tsig_outer[i] = map.ops[i].a_outer;
-    }
-    if (!seen && st.tile_hint <= 0) return false;
+    return cp.tile_rejected_shape != tile_shape_signature(st);
+}
+bool tile_layout_build_auto(Storage &st, SparseCopy &cp, hipStream_t s) {
+    if (!tile_auto_candidate(st, cp)) return false;
+    if (cp.tiles && cp.tiles->structure_matches(st)) return true;
     // room: records (11 B per position: row 2, count 1, weight 8) + overflow + the build's temporaries + the partial-sum buffers, and 8 GB for the solver
     const double nt = (double)((cp.n_inner + st.tile_t - 1) / st.tile_t);
     const double need = 11.0 * 64.0 * (double)((cp.n_outer + st.tile_s - 1) / st.tile_s) * nt * ((st.tile_s + 64 / st.tile_k - 1) / (64 / st.tile_k)) +
@@ -861,13 +1062,30 @@ bool spmm_tiles_auto(Storage &st, SparseCopy &cp, const DevMap &map) {
     // gene_shape=0.1 shared_profile=1; the cell-major layout of the same matrix: 5.8 %, 19.5 ms). Such an orientation stays on
     // the gather kernels, and is not tried again until the tile shape changes.
     cp.tiles.reset();
-    TileLayout *t = tile_layout_build(st, cp, st.tile_max_overflow);
+    TileLayout *t = tile_layout_build(st, cp, st.tile_max_overflow, s);
     if (!t) {
-        cp.tile_rejected_shape = shape_sig;
+        cp.tile_rejected_shape = tile_shape_signature(st);
         return false;
     }
     cp.tiles.reset(t, tile_layout_free);
     return true;
+}
+
+bool spmm_tiles_auto(Storage &st, SparseCopy &cp, const DevMap &map) {
+    if (!tile_auto_candidate(st, cp)) return false;
+    if (cp.tiles && cp.tiles->structure_matches(st)) return true; // the weights follow the map in one streaming pass
+    bool seen = cp.tsig_n == map.n;
+    for (int i = 0; seen && i < map.n; i++) seen = cp.tsig_id[i] == map.ops[i].id && cp.tsig_outer[i] == map.ops[i].a_outer;
+    cp.tsig_n = map.n;
+    for (int i = 0; i < map.n; i++) {
+        cp.tsig_id[i] = map.ops[i].id;
+        cp.tsig_outer[i] = map.ops[i].a_outer;
+    }
+    if (!seen && st.tile_hint <= 0) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool ok = tile_layout_build_auto(st, cp, st.stream);
+    st.t_layout_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return ok;
 }
 
 void launch_gather2d_ov(Storage &st, hipStream_t s, SparseCopy &ov, const double *X, uint32_t ldx, uint32_t l, double *out, uint32_t ldo); // kernels.hip

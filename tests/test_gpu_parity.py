@@ -578,7 +578,7 @@ def test_blocked_kernel_matches_gather_and_oracle(sa, storage):
 
 
 @pytest.mark.parametrize("storage", [so.CSR, so.CSC])
-@pytest.mark.parametrize("tile_k,tile_s,tile_t,tile_b,tile_ku", [(2, 28, 48, 4, 1), (2, 32, 48, 4, 1), (2, 28, 48, 4, 0), (2, 32, 24, 8, 1), (3, 32, 64, 3, 0),
+@pytest.mark.parametrize("tile_k,tile_s,tile_t,tile_b,tile_ku", [(2, 28, 48, 4, 1), (2, 32, 48, 4, 1), (2, 32, 48, 4, 0), (2, 28, 48, 4, 0), (2, 32, 24, 8, 1), (3, 32, 64, 3, 0),
                                                                  (4, 32, 96, 2, 0), (4, 28, 40, 3, 0)])
 def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_s, tile_t, tile_b, tile_ku):
     """spmm path 3 (tiles.hip: the hybrid product — panel tiles staged through a ring of LDS buffers, K fixed record positions
@@ -620,6 +620,72 @@ def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_
                 a1, a3, ref = g1.rdot(ql), g3.rdot(ql), ref_m.rdot(ql)
                 assert_close(a3, ref, rtol=1e-10, atol=1e-9)
                 assert_close(a1, a3, rtol=1e-11, atol=1e-10)
+
+
+@pytest.mark.parametrize("tile_ku", [1, 0])
+def test_wave_level_layout_builder_equals_the_per_thread_walk(sa, tile_ku):
+    """Round 4: the tile layout of the default shape is built by tile_assign_wave_kernel (a lane per outer vector, the wave in
+    lock-step over the visits, record rows written whole) instead of one thread walking each vector. Same assignment rule, so the
+    layouts — and with them the order of every addition — must be identical: products through both builders are compared BIT FOR
+    BIT, over shapes around the group (32 / 64 vectors per wave) and tile edges, several parts, empty vectors, vectors with more
+    nonzeros in one tile than the chunk registers hold (the in-visit refill), counts above 255 and count-1 runs."""
+    rng = np.random.default_rng(91)
+    for rows, cols, fill, vmax in ((1, 1, 1.0, 3), (31, 95, 0.5, 3), (33, 97, 0.9, 2), (64, 48, 1.0, 2), (65, 4800, 0.6, 4), (257, 2000, 0.05, 400),
+                                   (700, 1000, 0.03, 3), (97, 20000, 0.02, 3), (2000, 193, 0.2, 300), (300, 400, 0.004, 2), (130, 9000, 0.3, 3)):
+        dense = random_counts(rng, rows, cols, fill, vmax)
+        dense[rng.random(rows) < 0.2, :] = 0
+        dense[0, 0] = 1
+        for storage in (so.CSR, so.CSC):
+            outs = []
+            for builder in (0, 1):
+                g, _ = pair(sa, dense, storage)
+                g.set_spmm_path(3).set_option("tile_builder", builder).set_option("tile_ku", tile_ku)
+                g.compose_scale_axis(1, np.linspace(0.5, 1.5, cols)).apply(sa.FN_LOG2_1P)
+                q = np.cos(np.arange(cols * 40, dtype=np.float64)).reshape(cols, 40)
+                ql = np.sin(np.arange(rows * 24, dtype=np.float64)).reshape(24, rows)
+                outs.append((g.dot(q), g.rdot(ql)))
+            assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (rows, cols, fill, storage)
+
+
+def test_invalid_sparse_input_is_refused(sa):
+    """create validates on the device in two streaming passes (round 4): indices ascending inside a vector — a descent at the first
+    nonzero of a vector is fine — and in range, indptr not decreasing; the reference panics on such input (sprs structure checks)."""
+    ok_ip, ok_ix, ok_v = [0, 3, 3, 5], [2, 5, 9, 0, 9], [1, 2, 3, 4, 5]  # vector 2 starts below vector 0's last index: valid
+    g = sa.AdaptiveMat.from_csmat(3, 10, sa.CSR, ok_ip, ok_ix, ok_v)
+    assert np.array_equal(g.sum_axis(1, dtype=np.uint32), [6, 0, 9])
+    for ip, ix, vv in (([0, 3, 3, 5], [2, 9, 5, 0, 9], [1, 2, 3, 4, 5]),     # descent inside a vector
+                       ([0, 3, 3, 5], [2, 5, 5, 0, 9], [1, 2, 3, 4, 5]),     # duplicate inside a vector
+                       ([0, 3, 3, 5], [2, 5, 10, 0, 9], [1, 2, 3, 4, 5]),    # index out of range
+                       ([0, 3, 2, 5], [2, 5, 9, 0, 9], [1, 2, 3, 4, 5]),     # indptr decreases
+                       ([0, 3, 7, 5], [2, 5, 9, 0, 9], [1, 2, 3, 4, 5])):    # indptr beyond nnz
+        with pytest.raises(sa.ScanrsError):
+            sa.AdaptiveMat.from_csmat(3, 10, sa.CSR, ip, ix, vv)
+    # a larger one: exactly one descent hidden in 10^5 nonzeros, at a chunk boundary of the streaming pass
+    rng = np.random.default_rng(5)
+    m = _synth(500, 4000, 0.05, 3)
+    ip, ix, vv = m.indptr.astype(np.uint64), m.indices.astype(np.uint32), m.data.astype(np.uint32)
+    sa.AdaptiveMat.from_csmat(500, 4000, sa.CSR, ip, ix, vv)
+    for pos in (4, 4097):
+        r = int(np.searchsorted(ip, pos, side="right") - 1)
+        if ip[r] < pos:  # not the first nonzero of its vector: swapping with the predecessor is a violation
+            bad = ix.copy()
+            bad[pos - 1], bad[pos] = bad[pos], bad[pos - 1]
+            with pytest.raises(sa.ScanrsError):
+                sa.AdaptiveMat.from_csmat(500, 4000, sa.CSR, ip, bad, vv)
+
+
+def test_bksvd_with_many_iterations(sa):
+    """the device-side factor bookkeeping drew 4 n_iter - 3 slots from a fixed block of 256 and failed valid inputs
+    with n_iter >= 65 (the reference puts no bound on n_iter, bk_svd.rs:16-53)."""
+    m = _synth(3000, 700, 0.08, 11)
+    k = 3
+    g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+    g = sa.normalize(g, sa.Normalization.CellRanger)
+    u, s, v = sa.BkSvd(k_multiplier=2.0, n_iter=70).run_pca(g, k)  # q = 6 * 70 = 420 <= 700
+    dense = g.to_dense()
+    s_ref = np.linalg.svd(dense, compute_uv=False)[:k]
+    assert np.max(np.abs(s - s_ref) / s_ref) < 1e-9
+    assert g.counter("bk_host_retries") in (0, 1)  # whichever path served it, it did not fail
 
 
 def test_auto_path_leaves_a_dense_orientation_to_the_gather_kernels(sa):
