@@ -344,12 +344,20 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *                       factorization does not converge within the queued passes); 0: host factorizations
  *   "d2h_threads" (4)   host threads that empty the pinned ring of a large result download
  *   "reuse_cmax" (1e5)  svd_bk: coefficient bound above which a projection column is recomputed directly
+ *   "side_build" (1)    scanrs_normalize and the solvers start a helper thread (own stream) that builds what the SECOND product of
+ *                       a solver iteration needs — the transposed copy of the matrix and that orientation's tile layout — beside the
+ *                       normalisation passes and the first product; 0: built on demand by the calling thread
+ *   "tile_builder" (1)  1: wave-level builder of the tile layout (default tile shape); 0: per-thread walk (reference form)
+ *   "tile_build_waves" (16)  waves per CU of that builder (0: as many as fit)
  *   "sync_timeout_s" (120)  PROCESS-WIDE (same as scanrs_set_global_option): deadline of every host-side wait for the device
  * Unknown keys return SCANRS_ERR_ARGUMENT. The only environment variables the library reads are the diagnostics
  * SCANRS_TRACE and SCANRS_TRACE_EIG (phase timings on stderr). */
 int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value);
 /* Event counters of the handle (diagnostics): "bk_host_retries" = svd_bk calls whose device-side factorizations did not
- * converge within the queued passes and that were run again with host factorizations. */
+ * converge within the queued passes and that were run again with host factorizations. First-call accounting, host microseconds of
+ * the calling thread since the handle was made: "t_layout_us" (tile layout builds), "t_side_wait_us" (waiting for the helper
+ * thread of "side_build"), "t_start_panel_us", "t_delivery_us" (U, V to host arrays); process-wide: "t_alloc_us" / "alloc_calls"
+ * (hipMalloc). */
 int scanrs_mat_get_counter(scanrs_mat *m, const char *key, uint64_t *value);
 /* Process-wide options of the entry points that take no handle:
  *   "h5_threads" (8)               threads that inflate the chunks of a large filtered HDF5 read
@@ -363,8 +371,19 @@ int scanrs_mat_get_counter(scanrs_mat *m, const char *key, uint64_t *value);
  *                                  stages and which of the handle's streams (main / aux / aux2 / overflow) still had work; the
  *                                  same report and the whole stage ring go to stderr. The handle must then be freed (its queued
  *                                  work never finished); start over in a fresh process — a process whose device stopped
- *                                  answering cannot be repaired from inside, and must not exec() another program either. */
+ *                                  answering cannot be repaired from inside, and must not exec() another program either.
+ *   "device_cache_fraction" (0.5)  device blocks of 1 MB and more that the library releases are kept for its next allocation of about
+ *                                  their size, up to this share of the device's memory, instead of going back to the driver (VRAM
+ *                                  that was just freed is scrubbed in the background; an allocation that lands on it waits:
+ *                                  seconds for the tens of GB of a handle). 0: no cache. See scanrs_release_cached_memory. */
 int scanrs_set_global_option(const char *key, double value);
+/* Optional: loads the library's device code, starts the one-off host-side table computation of the seeded start panels and
+ * touches the runtime paths the first call would otherwise initialise (~30-60 ms on MI355X): call it at program start to
+ * keep that out of the first scanrs_mat_create / normalize / PCA. Everything works without it. */
+int scanrs_init(void);
+/* Gives the cached device blocks (see "device_cache_fraction") back to the driver / reports how much is cached. */
+int scanrs_release_cached_memory(void);
+int scanrs_cached_memory_bytes(uint64_t *bytes);
 /* Arithmetic of the large sparse products: 0 (default) = f64 throughout, the reference's arithmetic; 1 = opt-in fast
  * mode: the dense panel is rounded to f32 before it is gathered (half the on-chip bytes per nonzero), products and
  * sums stay f64. Singular values / loadings then agree with the f64 path to ~1e-7 relative, not to rounding. */

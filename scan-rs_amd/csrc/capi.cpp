@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -208,62 +209,137 @@ static void need_device() {
         fail(SCANRS_ERR_DEVICE, "no gfx950 (MI355X) device is usable from this process; scanrs_amd has no CPU fallback");
 }
 
-// ---- device memory: allocation with retry, deferred frees (common.hpp) ------------------------------------------------
+// ---- device memory: allocation with retry, deferred frees, block cache (common.hpp) ------------------------------------
 namespace {
-struct Graveyard {
-    std::mutex mu;
-    std::vector<std::pair<void *, size_t>> dead;
-    size_t bytes = 0;
+struct Block {
+    void *p;
+    size_t size; // what hipMalloc was asked for
+    int dev;
 };
-Graveyard &graveyard() {
-    static Graveyard *g = new Graveyard(); // never destroyed: handles freed by static destructors of the host program still find it
+struct DeviceMemory {
+    std::mutex mu;
+    std::vector<void *> dead;                           // released by their owners, waiting for a point where the device is idle
+    std::map<void *, std::pair<size_t, int>> live;      // every block handed out: pointer -> (size, device)
+    std::multimap<std::pair<int, size_t>, void *> idle; // cached blocks by (device, size)
+    size_t idle_bytes = 0;
+    double cache_fraction = 0.5; // of the device's memory; 0: no cache (every released block goes back to the driver)
+};
+DeviceMemory &devmem() {
+    static DeviceMemory *g = new DeviceMemory(); // never destroyed: handles freed by static destructors of the host program still find it
     return *g;
 }
 std::atomic<uint64_t> g_alloc_us{0}, g_alloc_calls{0};
+constexpr size_t CACHE_MIN = 1u << 20; // smaller blocks go straight back
+size_t round_block(size_t bytes) { return bytes >= CACHE_MIN ? (bytes + (2u << 20) - 1) & ~((size_t)(2u << 20) - 1) : bytes; }
 } // namespace
-void device_free_later(void *p, size_t bytes) {
+void device_free_later(void *p, size_t) {
     if (!p) return;
-    Graveyard &g = graveyard();
+    DeviceMemory &g = devmem();
     std::lock_guard<std::mutex> lk(g.mu);
-    g.dead.emplace_back(p, bytes);
-    g.bytes += bytes;
+    g.dead.push_back(p);
 }
+// Released blocks of 1 MB and more are kept for the next allocation of about their size instead of going back to the driver:
+// VRAM that was just freed is scrubbed in the background and an allocation that lands on it waits for the scrubber — seconds for
+// the tens of GB a handle holds (the second and third handle of one process took 2.4 / 4.1 s for their first PCA instead of 0.4).
+// At most `device_cache_fraction` (default one half) of the device's memory is kept; scanrs_release_cached_memory() and a failed
+// allocation empty the cache.
 void device_free_flush() noexcept {
-    Graveyard &g = graveyard();
-    std::vector<std::pair<void *, size_t>> take;
+    DeviceMemory &g = devmem();
+    std::vector<Block> to_free;
     {
         std::lock_guard<std::mutex> lk(g.mu);
-        take.swap(g.dead);
-        g.bytes = 0;
+        if (g.dead.empty()) return;
+        size_t cap = 0;
+        if (g.cache_fraction > 0.0) {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess) cap = (size_t)((double)tot * g.cache_fraction);
+        }
+        for (void *p : g.dead) {
+            auto it = g.live.find(p);
+            if (it == g.live.end()) continue; // not ours (cannot happen)
+            const Block b{p, it->second.first, it->second.second};
+            g.live.erase(it);
+            if (b.size >= CACHE_MIN && g.idle_bytes + b.size <= cap) {
+                g.idle.emplace(std::make_pair(b.dev, b.size), p);
+                g.idle_bytes += b.size;
+            } else {
+                to_free.push_back(b);
+            }
+        }
+        g.dead.clear();
     }
-    if (take.empty()) return;
+    if (to_free.empty()) return;
     const auto t0 = std::chrono::steady_clock::now();
     size_t bytes = 0;
-    for (auto &d : take) {
-        (void)hipFree(d.first);
-        bytes += d.second;
+    for (auto &b : to_free) {
+        (void)hipFree(b.p);
+        bytes += b.size;
     }
     if (trace_on())
-        fprintf(stderr, "[scanrs trace] released %zu buffers, %.2f GB, in %.2f ms\n", take.size(), (double)bytes / 1e9,
+        fprintf(stderr, "[scanrs trace] released %zu buffers, %.2f GB, in %.2f ms\n", to_free.size(), (double)bytes / 1e9,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 }
+void device_cache_release() noexcept {
+    device_free_flush();
+    DeviceMemory &g = devmem();
+    std::vector<void *> take;
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        for (auto &kv : g.idle) take.push_back(kv.second);
+        g.idle.clear();
+        g.idle_bytes = 0;
+    }
+    for (void *p : take) (void)hipFree(p);
+}
+void device_cache_set_fraction(double f) {
+    DeviceMemory &g = devmem();
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        g.cache_fraction = f;
+    }
+    if (f <= 0.0) device_cache_release();
+}
+size_t device_cache_bytes() {
+    DeviceMemory &g = devmem();
+    std::lock_guard<std::mutex> lk(g.mu);
+    return g.idle_bytes;
+}
 void *device_alloc(size_t bytes) {
+    DeviceMemory &g = devmem();
+    const size_t want = round_block(bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (want >= CACHE_MIN) { // a cached block of this size, or up to 1/8 larger
+        std::lock_guard<std::mutex> lk(g.mu);
+        auto it = g.idle.lower_bound(std::make_pair(dev, want));
+        if (it != g.idle.end() && it->first.first == dev && it->first.second <= want + want / 8) {
+            void *p = it->second;
+            g.live[p] = std::make_pair(it->first.second, dev);
+            g.idle_bytes -= it->first.second;
+            g.idle.erase(it);
+            return p;
+        }
+    }
     void *p = nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) { // buffers waiting for their release may be all that stands in the way
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) { // cached blocks and buffers waiting for their release may be all that stands in the way
         (void)hipGetLastError();
-        device_free_flush();
-        e = hipMalloc(&p, bytes);
+        device_cache_release();
+        e = hipMalloc(&p, want);
     }
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     g_alloc_us.fetch_add((uint64_t)us, std::memory_order_relaxed);
     g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        fail(SCANRS_ERR_DEVICE, "hipMalloc of %.3f GB failed: %s", (double)bytes / 1e9, hipGetErrorString(e));
+        fail(SCANRS_ERR_DEVICE, "hipMalloc of %.3f GB failed: %s", (double)want / 1e9, hipGetErrorString(e));
     }
-    if (us > 2000.0 && trace_on()) fprintf(stderr, "[scanrs trace]   hipMalloc of %.2f GB took %.1f ms\n", (double)bytes / 1e9, us / 1e3);
+    if (us > 2000.0 && trace_on()) fprintf(stderr, "[scanrs trace]   hipMalloc of %.2f GB took %.1f ms\n", (double)want / 1e9, us / 1e3);
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        g.live[p] = std::make_pair(want, dev);
+    }
     return p;
 }
 uint64_t device_alloc_us() { return g_alloc_us.load(std::memory_order_relaxed); }
@@ -489,14 +565,16 @@ bool mat_tiles_ready(scanrs_mat *m, bool transpose) {
 // own while the main thread builds the first product's layout and runs the first pass (the only call Cell Ranger ever makes is the
 // first one on a fresh handle, tools/src/bin/cmd.rs:61-70: serially these builds were more than half of it). The helper touches
 // nothing but the copy it builds; whoever needs that copy joins the helper first (side_join_if).
-void prepare_second_orientation(scanrs_mat *m, bool transpose_second) {
+// normalize() starts it already (solver_follows): the one thing a caller does with a scaled and centred matrix is a PCA, and the
+// helper then also runs beside the normalisation passes ("side_build" 0: nothing is built before a product asks for it).
+void prepare_second_orientation(scanrs_mat *m, bool transpose_second, bool solver_follows) {
     Storage &st = *m->st;
     if (st.side || !st.side_build) return;
     const bool outer_rows = (!transpose_second) != m->transposed; // the base-matrix dimension the second product's outer vectors run over
     const bool is_primary = outer_rows == (st.storage == SCANRS_CSR);
     SparseCopy &cp = is_primary ? st.primary : st.other;
     const bool need_copy = !is_primary && !st.has_other;
-    const bool want_tiles = st.spmm_path == 0 && st.tile_auto && st.panel_precision == 0 && st.tile_hint > 0 &&
+    const bool want_tiles = st.spmm_path == 0 && st.tile_auto && st.panel_precision == 0 && (st.tile_hint > 0 || solver_follows) &&
                             st.primary.nnz >= std::max<uint64_t>(st.blocked_min_nnz, 1ull << 24) && !(cp.tiles != nullptr);
     if (!need_copy && !want_tiles) return;
     if (st.primary.nnz < (1ull << 22)) return; // small matrices: the builds take less than starting a thread
@@ -837,6 +915,22 @@ int scanrs_device_available(void) {
     }
 }
 const char *scanrs_version(void) { return "scanrs_amd 0.1.0 (gfx950)"; }
+int scanrs_init(void) {
+    return guard([&] {
+        need_device();
+        jump_tables_prefetch();
+        library_warm_up();
+    });
+}
+int scanrs_release_cached_memory(void) {
+    return guard([&] { device_cache_release(); });
+}
+int scanrs_cached_memory_bytes(uint64_t *bytes) {
+    return guard([&] {
+        if (!bytes) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        *bytes = device_cache_bytes();
+    });
+}
 
 int scanrs_mat_create(uint64_t rows, uint64_t cols, int storage, const uint64_t *indptr, const uint32_t *indices,
                       const uint32_t *values, scanrs_mat **out) {
@@ -1230,9 +1324,16 @@ int scanrs_log1p_normalize_fixed_point(scanrs_mat *m, int log_fn, uint32_t base,
         scale_and_center_impl(m, 1, nullptr);
     });
 }
+// which product a solver runs second on this view: svd_bk / svd_rand start with A x when rows >= cols (bk_svd.rs:89, rand_svd.rs:86)
+static void prefetch_for_pca(scanrs_mat *m) {
+    const uint64_t Mg = rows_sharded(m) ? m->st->shard.outer_global : m->rows(), Ng = cols_sharded(m) ? m->st->shard.outer_global : m->cols();
+    prepare_second_orientation(m, Mg >= Ng, true);
+}
+
 int scanrs_normalize(scanrs_mat *m, int normalization, const uint32_t *size_factors) {
     return guard([&] { // normalize / normalize_with_size_factor, scan-rs/src/normalization.rs:46-102
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        if (normalization >= SCANRS_NORM_CELLRANGER && normalization <= SCANRS_NORM_LOG_TRANSFORM) prefetch_for_pca(m);
         switch (normalization) {
         case SCANRS_NORM_CELLRANGER:
             log_normalize_impl(m, -1.0, OP_LOG2_1P, nullptr);
@@ -1480,7 +1581,10 @@ int scanrs_set_global_option(const char *key, double value) {
             go.knn_ratio = (unsigned long long)std::max(2.0, value);
         else if (k == "knn_stats")
             go.knn_stats = value != 0.0;
-        else if (k == "sync_timeout_s") { // deadline of every host-side wait for the device (common.hpp, "bounded waits")
+        else if (k == "device_cache_fraction") { // share of the device's memory that released blocks may occupy while they wait for reuse
+            if (!(value >= 0.0) || value > 1.0) fail(SCANRS_ERR_ARGUMENT, "device_cache_fraction must be in [0, 1]");
+            device_cache_set_fraction(value);
+        } else if (k == "sync_timeout_s") { // deadline of every host-side wait for the device (common.hpp, "bounded waits")
             if (!(value > 0.0) || !std::isfinite(value)) fail(SCANRS_ERR_ARGUMENT, "sync_timeout_s must be a positive number of seconds");
             set_sync_timeout_s(value);
         } else

@@ -78,6 +78,10 @@ struct Tick {
 void device_free_later(void *p, size_t bytes);
 void device_free_flush() noexcept;
 void *device_alloc(size_t bytes); // hipMalloc with the retry above; throws Failure(SCANRS_ERR_DEVICE)
+void device_cache_release() noexcept;
+void device_cache_set_fraction(double f);
+size_t device_cache_bytes();
+void library_warm_up(); // kernels.hip: loads every code object of the library (one empty launch per translation unit)
 uint64_t device_alloc_us();
 uint64_t device_alloc_calls();
 
@@ -452,7 +456,7 @@ void jump_tables_prefetch(); // starts the background computation of the start p
 // out[rows_v x l] = V * X  (transpose: out[cols_v x l] = V^T * X), offsets and shard reduction included.
 void mat_apply(scanrs_mat *m, bool transpose, const double *dX, uint32_t ldx, uint32_t l, double *dOut, uint32_t ldo);
 bool mat_tiles_ready(scanrs_mat *m, bool transpose);
-void prepare_second_orientation(scanrs_mat *m, bool transpose_second);
+void prepare_second_orientation(scanrs_mat *m, bool transpose_second, bool solver_follows = false);
 void sort_outer_vectors(Storage &st, SparseCopy &cp);
 void launch_scale_rows(Storage &st, const double *X, uint32_t ldx, uint64_t rows, uint32_t l, const double *a, double *Xs);
 // knn.hip

@@ -301,4 +301,9 @@ uint64_t decode_adaptive_vectors(const scanrs_adaptive_vec *vecs, uint64_t n_vec
     return total;
 }
 
+// scanrs_init(): one empty launch per translation unit makes the runtime load this file's code object now instead of inside the
+// first real call
+__global__ void warm_decode_kernel() {}
+void warm_decode(hipStream_t s) { hipLaunchKernelGGL(warm_decode_kernel, dim3(1), dim3(64), 0, s); }
+
 } // namespace scanrs

@@ -2689,4 +2689,27 @@ void build_transposed_copy(Storage &st, const SparseCopy &src, SparseCopy &dst, 
     dst.build_items(s);
 }
 
+// scanrs_init(): one empty launch per translation unit makes the runtime load this file's code object now instead of inside the
+// first real call
+__global__ void warm_kernels_kernel() {}
+void warm_kernels(hipStream_t s) { hipLaunchKernelGGL(warm_kernels_kernel, dim3(1), dim3(64), 0, s); }
+
+void warm_dense(hipStream_t s);
+void warm_decode(hipStream_t s);
+void warm_knn(hipStream_t s);
+void warm_tiles(hipStream_t s);
+void library_warm_up() {
+    hipStream_t s = nullptr;
+    SCANRS_HIP(hipStreamCreate(&s));
+    warm_kernels(s);
+    warm_dense(s);
+    warm_decode(s);
+    warm_knn(s);
+    warm_tiles(s);
+    const hipError_t e = hipGetLastError();
+    SCANRS_SYNC(s);
+    (void)hipStreamDestroy(s);
+    if (e != hipSuccess) fail(SCANRS_ERR_DEVICE, "warm-up launch failed: %s", hipGetErrorString(e));
+}
+
 } // namespace scanrs
