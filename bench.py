@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--cpu-cells", type=int, default=16000, help="cells of the 1-core CPU-baseline sample")
     ap.add_argument("--cpu-cells-all", type=int, default=100000, help="cells of the all-core CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-heavy-tailed", action="store_true", help="skip the second, clearly labelled measurement on the heavy-tailed gene profile")
     ap.add_argument("--no-host-delivery", action="store_true", help="leave U and V in HBM in every step (value is then the device-resident rate)")
     ap.add_argument("--f32-panels", action="store_true",
                     help="opt-in fast mode: gathered panels rounded to f32, f64 sums (NOT the headline configuration)")
@@ -473,6 +474,40 @@ def main():
         barrier()
         irlba_ms, irlba_mprod = (time.perf_counter() - t0) * 1e3, int(mp.value)
 
+    # ---- the same step on a heavy-tailed gene profile (NOT the headline) ----------------------------------------------------------
+    # SURVEY.md §8d's synthetic has a nearly flat gene popularity; a real 10x matrix has a few thousand genes detected in most cells and
+    # most genes in almost none (sqz/src/lib.rs:5-8). tools/pass_bench.py's model of that (Gamma(0.1) gene rates, one profile shared by
+    # all clusters: ~2 900 genes above 10 % detection holding 3/4 of the nonzeros) at the same shape and density, same step.
+    heavy = None
+    if world == 1 and not args.no_heavy_tailed:
+        dbg("heavy-tailed profile")
+        hip_, hix_, hvv_ = synth_counts_torch(args.cells, args.genes, args.density, args.seed, dev, gene_shape=0.1, shared_profile=1.0)
+        per_gene = torch.bincount(hix_.long(), minlength=args.genes).float() / args.cells
+        hmat = sa.AdaptiveMat.from_device(args.genes, args.cells, sa.CSC, hip_.data_ptr(), hix_.data_ptr(), hvv_.data_ptr())
+        h_nnz = int(hip_[-1].item())
+        del hip_, hix_, hvv_
+
+        def hstep():
+            hmat.reset_map()
+            sa.normalize(hmat, sa.Normalization.CellRanger)
+            return bk.run_pca(hmat, args.k) if not args.no_host_delivery else bk.run_pca_device(hmat, args.k)
+
+        hstep()
+        hstep()
+        torch.cuda.synchronize()
+        hmat.sync()
+        t0 = time.perf_counter()
+        for _ in range(max(1, min(args.steps, 5))):
+            hstep()
+        hmat.sync()
+        h_ms = (time.perf_counter() - t0) / max(1, min(args.steps, 5)) * 1e3
+        heavy = {"ms_per_step": round(h_ms, 2), "cells_per_s": round(args.cells / (h_ms * 1e-3), 1), "nnz": h_nnz,
+                 "genes_detected_in_over_10pct_of_cells": int((per_gene > 0.1).sum()),
+                 "their_share_of_the_nonzeros": round(float(per_gene[per_gene > 0.1].sum() / per_gene.sum()), 3),
+                 "model": "tools/pass_bench.py gene_shape=0.1 shared_profile=1 (Gamma(0.1) gene rates shared by all clusters), same cells x genes x density, same step"}
+        del hmat
+        torch.cuda.empty_cache()
+
     # ---- roofline of the dominant kernel -------------------------------------------------------------------
     roof = None
     if prof:
@@ -598,6 +633,8 @@ def main():
                 "first_call_cells_per_s": round(args.cells / t_setup, 1),
                 "first_call_includes": "handle creation from device-resident arrays (copy, validation, work items), normalize, PCA with host delivery; inside: the transposed (gene-major) copy and the tile layouts of the hybrid product (both orientations). Not included: scanrs_init (library_init_s)",
                 "first_call_breakdown_ms": first_breakdown,
+                "heavy_tailed_ms_per_step": heavy["ms_per_step"] if heavy else None,
+                "heavy_tailed_profile": heavy,
                 "library_init_s": round(t_init, 3),
                 "resident_bytes_per_nonzero": round(mem_after_first / max(1, nnz_local), 1) if mem_after_first else None,
                 "datagen_s": round(t_gen, 2),

@@ -1608,6 +1608,14 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.tile_b = (uint32_t)value;
         } else if (k == "side_build") {
             st.side_build = value != 0.0;
+        } else if (k == "tile_split") {
+            st.tile_split = value != 0.0;
+        } else if (k == "tile_split_x") {
+            if (!(value > 0.05) || value > 16.0) fail(SCANRS_ERR_ARGUMENT, "tile_split_x must be in (0.05, 16]");
+            st.tile_split_x = value;
+        } else if (k == "tile_split_min") {
+            if (!(value >= 0.0) || value > 16.0) fail(SCANRS_ERR_ARGUMENT, "tile_split_min must be in [0, 16]");
+            st.tile_split_min = value;
         } else if (k == "tile_builder") {
             st.tile_builder = value != 0.0;
         } else if (k == "tile_build_waves") {

@@ -292,6 +292,9 @@ struct Storage {
     uint32_t tile_ku = 1;                 // ... unit positions among them (0 or 1; used with tile_k 2): count-1 nonzeros, added without a weight
     uint32_t tile_t = 48, tile_b = 4;     // ... panel rows per tile (<= 24 tile_k) and tile buffers in the LDS ring (tile_t * tile_b <= 192)
     int side_build = 1;                   // solvers: the second product's copy / tile layout on a helper thread beside the first pass (0: built on demand by the caller's thread)
+    int tile_split = 1;                   // tile layout: slots per outer vector from its density (several for dense vectors, none — all overflow — for very sparse ones); 0: one slot per vector
+    double tile_split_x = 1.8;            // ... nonzeros per panel tile a slot is sized for
+    double tile_split_min = 0.5;          // ... vectors below this many nonzeros per tile get no slot
     int tile_builder = 1;                 // layout builder: 1 = wave-level (a lane per vector, visits in lock-step, rows written whole; default shape only), 0 = per-thread walk
     uint32_t tile_build_waves = 16;       // ... its waves per CU (0: whatever fits)
     size_t ov_tile_bytes = 0;             // hybrid product: panel slice per step of the overflow gather (0 = twice l2_tile_bytes)

@@ -153,33 +153,164 @@ __global__ __launch_bounds__(256) void tile_assign_kernel(const uint64_t *__rest
     if (!FILL) ovc[e] = n_ov;
 }
 
-// The same assignment, one LANE per outer vector and the wave in lock-step over the visits (round 4; the default for K = 2, B = 4,
-// S = 32). The per-thread walk above reads its vector 4 bytes at a time from wherever it stands and writes 3-byte records all
+// ---- slots: the outer vectors as the layout sees them ----------------------------------------------------------------------
+// A slot owns K record positions per visit — right for a vector with 1-2 nonzeros per panel tile. Real count matrices are not like
+// that in the gene-major orientation: a few thousand genes are detected in 10-90 % of the cells (5-40 nonzeros per 48-cell tile)
+// and most of the others in well under 1 % — with one slot per vector the dense genes overflow (70 % of the nonzeros on
+// tools/pass_bench.py's heavy-tailed model) while the sparse ones are all padding. So a vector gets as many slots as its density
+// asks for: with x = (its nonzeros) T / n_inner expected nonzeros per tile, V = round(x / x_target) slots, at least one; its
+// nonzeros are dealt to its V slots round-robin in storage order (slot r takes positions s + r, s + r + V, ... of the vector), each
+// slot then runs the same first-come-first-served assignment as a vector of its own; V = 0 below x_min: all of the vector goes to
+// the overflow part (two positions per visit for a third of a nonzero cost more than its row gathers). The product kernel sees
+// n_slots independent "outer vectors"; tile_finish_kernel adds the slots of a vector.
+__global__ void tile_mult_kernel(const uint64_t *__restrict__ indptr, uint64_t n_outer, double tiles_inv, double x_target, double x_min,
+                                 uint32_t v_max, uint32_t *__restrict__ mult) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o > n_outer) return;
+    if (o == n_outer) {
+        mult[o] = 0;
+        return;
+    }
+    const double x = (double)(indptr[o + 1] - indptr[o]) * tiles_inv; // expected nonzeros per tile
+    uint32_t v = 1;
+    if (x_target > 0.0) {
+        if (x < x_min)
+            v = 0;
+        else {
+            const double q = floor(x / x_target + 0.5);
+            v = q < 1.0 ? 1u : q > (double)v_max ? v_max : (uint32_t)q;
+        }
+    }
+    mult[o] = v;
+}
+__global__ void tile_slotvec_kernel(const uint32_t *__restrict__ slot_first, uint64_t n_outer, uint32_t *__restrict__ slot_vec) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_outer) return;
+    for (uint32_t sidx = slot_first[o]; sidx < slot_first[o + 1]; sidx++) slot_vec[sidx] = (uint32_t)o;
+}
+// vectors without a slot: their nonzeros of every part are overflow (count, then copy)
+template <bool FILL>
+__global__ void tile_slotless_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices, const uint32_t *__restrict__ values,
+                                     const uint32_t *__restrict__ slot_first, uint64_t n_outer, TileShape sh, unsigned long long *__restrict__ ovc,
+                                     const unsigned long long *__restrict__ ov_off, uint32_t *__restrict__ ov_indices, uint32_t *__restrict__ ov_values) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_outer * sh.n_parts) return;
+    const uint64_t o = e / sh.n_parts;
+    if (slot_first[o + 1] != slot_first[o]) return;
+    const uint32_t part = (uint32_t)(e - o * sh.n_parts);
+    const uint64_t k0 = (uint64_t)part * sh.tpp * sh.T, k1 = (uint64_t)min(sh.nt, (part + 1u) * sh.tpp) * sh.T;
+    const uint64_t s = indptr[o], end = indptr[o + 1];
+    auto lower = [&](uint64_t key) {
+        uint64_t lo = s, hi = end;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if ((uint64_t)indices[mid] < key)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        return lo;
+    };
+    const uint64_t a = lower(k0), b = lower(k1);
+    if (!FILL) {
+        ovc[e] = b - a;
+    } else {
+        unsigned long long op = ov_off[e];
+        for (uint64_t p = a; p < b; p++, op++) {
+            ov_indices[op] = indices[p];
+            ov_values[op] = values[p];
+        }
+    }
+}
+
+// The same assignment, one LANE per slot and the wave in lock-step over the visits (round 4; the default for K = 2, B = 4, S = 32).
+// The per-thread walk above reads its vector 4 bytes at a time from wherever it stands and writes 3-byte records all
 // over the layout: every 128-byte line travels from the L2 to a CU a dozen times and the record rows are patched together in
 // the L2 (157 GB of HBM traffic and 47-62 ms per launch at 10^9 nonzeros for 6 GB of output). Here
-//   * a wave owns two groups (64 vectors) and one part; visit v is worked by all lanes together: every lane takes the nonzeros
-//     of its vector that lie in tile v (the wave loops while any lane has one: about 5 trips at 1.4 nonzeros per vector and tile)
+//   * a wave owns two groups (64 slots) and one part; visit v is worked by all lanes together: every lane takes the nonzeros
+//     of its slot that lie in tile v (the wave loops while any lane has one: about 5 trips at 1.4 nonzeros per slot and tile)
 //     and deals them to the positions of visits v .. v+2 exactly as above (same two queues, same tie rule) — but into a WINDOW of
 //     three visits held in registers; when tile v is done, the row of visit v is complete and leaves as whole 64-byte runs
 //     (32 lanes x u16 rows, 32 x u8 counts per group and position): every record is written exactly once, used or not, so the
 //     layout needs no initialisation pass;
-//   * a lane reads its vector in aligned 16-byte chunks (4 indices, 4 counts) through two chunk registers; the chunk after the
-//     current one is requested at the END of a visit and first looked at in the next one, so the wave does not stand on a load
-//     it has just issued; only a vector with more than 4-8 nonzeros in ONE tile (dense genes) waits inside a visit.
-// FILL = false counts the nonzeros no visit has room for (per vector and part), FILL = true writes records and overflow part.
+//   * a wave whose slots own at most every 4th nonzero of their vector (V <= 4: the usual case) reads in aligned 16-byte chunks (4 indices, 4 counts)
+//     through two chunk registers per lane; the chunk after the current one is requested at the END of a visit and first looked
+//     at in the next one, so the wave does not stand on a load it has just issued; only a slot with more than 4-8 nonzeros in ONE
+//     tile waits inside a visit. A wave with split vectors walks element by element with the next element requested one step ahead.
+// FILL = false counts the nonzeros no visit has room for (per vector and part), FILL = true writes records and overflow part
+// (the overflow nonzeros of a split vector land in its segment in arrival order of its lanes: tile_layout_build sorts those segments).
+struct AssignState {
+    uint32_t vu, cu, vg, cg;
+    uint32_t w00, w01, w10, w11, w20, w21; // window: visit v + d, position j -> code | count << 16 (0: free)
+};
+template <bool FILL, uint32_t T, uint32_t KU>
+__device__ __forceinline__ bool tile_assign_one(AssignState &a, uint32_t v, uint32_t t1, uint32_t idx, uint32_t cnt) {
+    constexpr uint32_t KG = 2u - KU, B = 4u;
+    const uint32_t tau = v;
+    const uint32_t last = min(tau + B - 2u, t1 - 1u);
+    uint32_t au = a.vu, bu = a.cu, ag = a.vg, bg = a.cg;
+    if (tau > au) {
+        au = tau;
+        bu = KU;
+    }
+    if (bu == 0) {
+        au++;
+        bu = KU;
+    }
+    if (tau > ag) {
+        ag = tau;
+        bg = KG;
+    }
+    if (bg == 0) {
+        ag++;
+        bg = KG;
+    }
+    const bool can_u = KU > 0 && cnt == 1u && au <= last;
+    const bool can_g = KG > 0 && cnt <= 255u && ag <= last;
+    if (!can_u && !can_g) return false; // overflow
+    const bool use_u = can_u && (!can_g || au <= ag);
+    uint32_t vis, j;
+    if (use_u) {
+        vis = au;
+        j = KU - bu;
+        a.vu = au;
+        a.cu = bu - 1u;
+    } else {
+        vis = ag;
+        j = KU + (KG - bg);
+        a.vg = ag;
+        a.cg = bg - 1u;
+    }
+    if (FILL) {
+        const uint32_t rec = ((tau & 3u) * T + (idx - tau * T)) | (cnt << 16);
+        const uint32_t d = vis - v;
+        if (d == 0u) {
+            if (j == 0u) a.w00 = rec; else a.w01 = rec;
+        } else if (d == 1u) {
+            if (j == 0u) a.w10 = rec; else a.w11 = rec;
+        } else {
+            if (j == 0u) a.w20 = rec; else a.w21 = rec;
+        }
+    }
+    return true;
+}
 template <bool FILL, uint32_t T, uint32_t KU>
 __global__ __launch_bounds__(64) void tile_assign_wave_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
-                                                              const uint32_t *__restrict__ values, uint64_t n_outer, uint64_t n_groups, TileShape sh,
+                                                              const uint32_t *__restrict__ values, const uint32_t *__restrict__ slot_vec,
+                                                              const uint32_t *__restrict__ slot_first, uint64_t n_slots, uint64_t n_groups, TileShape sh,
                                                               unsigned long long *__restrict__ ovc, const unsigned long long *__restrict__ ov_off,
-                                                              uint16_t *__restrict__ prow, uint8_t *__restrict__ pcnt,
-                                                              uint32_t *__restrict__ ov_indices, uint32_t *__restrict__ ov_values) {
+                                                              unsigned long long *__restrict__ ov_cursor, uint16_t *__restrict__ prow,
+                                                              uint8_t *__restrict__ pcnt, uint32_t *__restrict__ ov_indices, uint32_t *__restrict__ ov_values) {
     constexpr uint32_t KG = 2u - KU, B = 4u;
     const uint32_t lane = threadIdx.x;
     const uint64_t item = blockIdx.x;
     const uint64_t gp = item / sh.n_parts;
     const uint32_t part = (uint32_t)(item - gp * sh.n_parts);
-    const uint64_t o = gp * 64u + lane;
-    const bool valid = o < n_outer;
+    const uint64_t slot = gp * 64u + lane;
+    const bool valid = slot < n_slots;
+    const uint64_t o = valid ? slot_vec[slot] : 0ull;
+    const uint32_t sf = valid ? slot_first[o] : 0u;
+    const uint32_t V = valid ? slot_first[o + 1] - sf : 1u, r = valid ? (uint32_t)slot - sf : 0u;
     const uint64_t g = gp * 2u + (lane >> 5);
     const uint32_t q = lane & 31u;
     const uint32_t t0 = part * sh.tpp, t1 = min(sh.nt, t0 + sh.tpp);
@@ -197,94 +328,87 @@ __global__ __launch_bounds__(64) void tile_assign_wave_kernel(const uint64_t *__
         }
         p = lo;
     }
-    const uint4 *I4 = reinterpret_cast<const uint4 *>(indices), *V4 = reinterpret_cast<const uint4 *>(values);
-    uint64_t ca = p >> 2; // chunk held in (ai, av); (bi, bv) holds chunk ca + 1. Reads run at most two chunks past a vector's end: the arrays are padded (DevBuf)
-    uint4 ai = I4[ca], av = V4[ca], bi = I4[ca + 1], bv = V4[ca + 1];
-    // element k of the chunk the position is in: selects only (an indexed uint4 would live in scratch memory)
-    auto pick = [](bool second, uint32_t k, uint4 a, uint4 b) {
-        const uint32_t x0 = second ? b.x : a.x, x1 = second ? b.y : a.y, x2 = second ? b.z : a.z, x3 = second ? b.w : a.w;
-        const uint32_t lo = (k & 1u) ? x1 : x0, hi = (k & 1u) ? x3 : x2;
-        return (k & 2u) ? hi : lo;
-    };
-    uint32_t vu = t0, cu = KU, vg = t0, cg = KG;
-    uint32_t w00 = 0, w01 = 0, w10 = 0, w11 = 0, w20 = 0, w21 = 0; // window: visit v + d, position j -> code | count << 16 (0: free)
+    if (V > 1u) p += (r + V - (uint32_t)((p - s) % V)) % V; // this slot's first position of the part: p = s + r (mod V)
+    const uint64_t e = o * sh.n_parts + part;
+    AssignState a{t0, KU, t0, KG, 0, 0, 0, 0, 0, 0};
     unsigned long long n_ov = 0;
-    unsigned long long op = (FILL && valid) ? ov_off[o * sh.n_parts + part] : 0ull;
-    for (uint32_t v = t0; v < t1; v++) {
-        const uint64_t lim = (uint64_t)(v + 1u) * T; // nonzeros below it belong to tile v (everything below v T has been worked)
-        for (;;) {
+    unsigned long long op = (FILL && valid && V == 1u) ? ov_off[e] : 0ull;
+    auto overflow = [&](uint32_t idx, uint32_t cnt) {
+        if (FILL) {
+            const unsigned long long at = V == 1u ? op++ : atomicAdd(&ov_cursor[e], 1ull);
+            ov_indices[at] = idx;
+            ov_values[at] = cnt;
+        } else {
+            n_ov++;
+        }
+    };
+    auto emit = [&](uint32_t v) { // the row of visit v: whole 64-byte runs per group and position
+        if (FILL && g < n_groups) {
+            const uint64_t row = (g * sh.nt + v) * 64u;
+            const uint32_t e0 = a.w00 ? a.w00 : (KU > 0 ? B * T : (v & 3u) * T); // an unused unit position reads the row of zeros behind the ring,
+            const uint32_t e1 = a.w01 ? a.w01 : (v & 3u) * T;                    // an unused general one row 0 of the visit's own tile (weight 0)
+            prow[row + q] = (uint16_t)e0;
+            prow[row + 32u + q] = (uint16_t)e1;
+            pcnt[row + q] = (uint8_t)(e0 >> 16);
+            pcnt[row + 32u + q] = (uint8_t)(e1 >> 16);
+        }
+        a.w00 = a.w10;
+        a.w01 = a.w11;
+        a.w10 = a.w20;
+        a.w11 = a.w21;
+        a.w20 = 0;
+        a.w21 = 0;
+    };
+    if (!__builtin_amdgcn_ballot_w64(valid && V > 4u)) {
+        // ---- every slot of the wave is a whole vector or one of at most 4 of its vector (the next element of a slot is then in the
+        // current chunk or the one behind it): chunked reads ----
+        const uint4 *I4 = reinterpret_cast<const uint4 *>(indices), *V4 = reinterpret_cast<const uint4 *>(values);
+        uint64_t ca = p >> 2; // chunk held in (ai, av); (bi, bv) holds chunk ca + 1. Reads run at most two chunks past a vector's end: the arrays are padded (DevBuf)
+        uint4 ai = I4[ca], av = V4[ca], bi = I4[ca + 1], bv = V4[ca + 1];
+        // element k of the chunk the position is in: selects only (an indexed uint4 would live in scratch memory)
+        auto pick = [](bool second, uint32_t k, uint4 x, uint4 y) {
+            const uint32_t x0 = second ? y.x : x.x, x1 = second ? y.y : x.y, x2 = second ? y.z : x.z, x3 = second ? y.w : x.w;
+            const uint32_t lo = (k & 1u) ? x1 : x0, hi = (k & 1u) ? x3 : x2;
+            return (k & 2u) ? hi : lo;
+        };
+        for (uint32_t v = t0; v < t1; v++) {
+            const uint64_t lim = (uint64_t)(v + 1u) * T; // nonzeros below it belong to tile v (everything below v T has been worked)
             for (;;) {
+                for (;;) {
+                    const uint64_t ck = p >> 2;
+                    const bool inb = ck != ca;
+                    const bool avail = ck <= ca + 1u;
+                    const uint32_t k = (uint32_t)p & 3u;
+                    const uint32_t idx = pick(inb, k, ai, bi), cnt = pick(inb, k, av, bv);
+                    const bool has = p < end && avail && (uint64_t)idx < lim;
+                    if (!__builtin_amdgcn_ballot_w64(has)) break;
+                    if (has) {
+                        if (!tile_assign_one<FILL, T, KU>(a, v, t1, idx, cnt)) overflow(idx, cnt);
+                        p += V;
+                    }
+                }
+                // a lane that ran out of chunks inside the tile (more than 4-8 nonzeros of one vector in one tile): fetch and go on
                 const uint64_t ck = p >> 2;
-                const bool inb = ck != ca;
-                const bool avail = ck <= ca + 1u;
-                const uint32_t k = (uint32_t)p & 3u;
-                const uint32_t idx = pick(inb, k, ai, bi), cnt = pick(inb, k, av, bv);
-                const bool has = p < end && avail && (uint64_t)idx < lim;
-                if (!__builtin_amdgcn_ballot_w64(has)) break;
-                if (has) {
-                    const uint32_t tau = v;
-                    const uint32_t last = min(tau + B - 2u, t1 - 1u);
-                    uint32_t au = vu, bu = cu, ag = vg, bg = cg;
-                    if (tau > au) {
-                        au = tau;
-                        bu = KU;
-                    }
-                    if (bu == 0) {
-                        au++;
-                        bu = KU;
-                    }
-                    if (tau > ag) {
-                        ag = tau;
-                        bg = KG;
-                    }
-                    if (bg == 0) {
-                        ag++;
-                        bg = KG;
-                    }
-                    const bool can_u = KU > 0 && cnt == 1u && au <= last;
-                    const bool can_g = KG > 0 && cnt <= 255u && ag <= last;
-                    if (!can_u && !can_g) {
-                        if (FILL) {
-                            ov_indices[op] = idx;
-                            ov_values[op] = cnt;
-                            op++;
-                        } else {
-                            n_ov++;
-                        }
-                    } else {
-                        const bool use_u = can_u && (!can_g || au <= ag);
-                        uint32_t vis, j;
-                        if (use_u) {
-                            vis = au;
-                            j = KU - bu;
-                            vu = au;
-                            cu = bu - 1u;
-                        } else {
-                            vis = ag;
-                            j = KU + (KG - bg);
-                            vg = ag;
-                            cg = bg - 1u;
-                        }
-                        if (FILL) {
-                            const uint32_t rec = ((tau & 3u) * T + (idx - tau * T)) | (cnt << 16);
-                            const uint32_t d = vis - v;
-                            if (d == 0u) {
-                                if (j == 0u) w00 = rec; else w01 = rec;
-                            } else if (d == 1u) {
-                                if (j == 0u) w10 = rec; else w11 = rec;
-                            } else {
-                                if (j == 0u) w20 = rec; else w21 = rec;
-                            }
-                        }
-                    }
-                    p++;
+                const bool starved = p < end && ck > ca + 1u;
+                if (!__builtin_amdgcn_ballot_w64(starved)) break;
+                if (starved) {
+                    ca = ck;
+                    ai = I4[ca];
+                    av = V4[ca];
+                    bi = I4[ca + 1];
+                    bv = V4[ca + 1];
                 }
             }
-            // a lane that ran out of chunks inside the tile (more than 4-8 nonzeros of one vector in one tile): fetch and go on
+            emit(v);
+            // advance the chunk registers here, a visit ahead of their use
             const uint64_t ck = p >> 2;
-            const bool starved = p < end && ck > ca + 1u;
-            if (!__builtin_amdgcn_ballot_w64(starved)) break;
-            if (starved) {
+            if (ck == ca + 1u) {
+                ai = bi;
+                av = bv;
+                ca = ck;
+                bi = I4[ca + 1];
+                bv = V4[ca + 1];
+            } else if (ck > ca + 1u) {
                 ca = ck;
                 ai = I4[ca];
                 av = V4[ca];
@@ -292,38 +416,37 @@ __global__ __launch_bounds__(64) void tile_assign_wave_kernel(const uint64_t *__
                 bv = V4[ca + 1];
             }
         }
-        if (FILL && g < n_groups) { // the row of visit v: whole 64-byte runs per group and position
-            const uint64_t row = (g * sh.nt + v) * 64u;
-            const uint32_t e0 = w00 ? w00 : (KU > 0 ? B * T : (v & 3u) * T); // an unused unit position reads the row of zeros behind the ring,
-            const uint32_t e1 = w01 ? w01 : (v & 3u) * T;                    // an unused general one row 0 of the visit's own tile (weight 0)
-            prow[row + q] = (uint16_t)e0;
-            prow[row + 32u + q] = (uint16_t)e1;
-            pcnt[row + q] = (uint8_t)(e0 >> 16);
-            pcnt[row + 32u + q] = (uint8_t)(e1 >> 16);
-        }
-        w00 = w10;
-        w01 = w11;
-        w10 = w20;
-        w11 = w21;
-        w20 = 0;
-        w21 = 0;
-        // advance the chunk registers here, a visit ahead of their use
-        const uint64_t ck = p >> 2;
-        if (ck == ca + 1u) {
-            ai = bi;
-            av = bv;
-            ca = ck;
-            bi = I4[ca + 1];
-            bv = V4[ca + 1];
-        } else if (ck > ca + 1u) {
-            ca = ck;
-            ai = I4[ca];
-            av = V4[ca];
-            bi = I4[ca + 1];
-            bv = V4[ca + 1];
+    } else {
+        // ---- split vectors among the slots: every lane steps through its own positions (stride V), the next element requested one
+        // step ahead; the V lanes of a vector read neighbouring elements, so their loads share cache lines ----
+        const uint64_t last_el = end ? end - 1 : 0; // reads are clamped into the vector (lanes past their end are masked by p < end)
+        uint32_t ci = indices[p < end ? p : last_el], cc = values[p < end ? p : last_el];
+        uint64_t pn = p + V;
+        uint32_t ni = indices[pn < end ? pn : last_el], nc = values[pn < end ? pn : last_el];
+        for (uint32_t v = t0; v < t1; v++) {
+            const uint64_t lim = (uint64_t)(v + 1u) * T;
+            for (;;) {
+                const bool has = p < end && (uint64_t)ci < lim;
+                if (!__builtin_amdgcn_ballot_w64(has)) break;
+                if (has) {
+                    if (!tile_assign_one<FILL, T, KU>(a, v, t1, ci, cc)) overflow(ci, cc);
+                    p = pn;
+                    ci = ni;
+                    cc = nc;
+                    pn = p + V;
+                    ni = indices[pn < end ? pn : last_el];
+                    nc = values[pn < end ? pn : last_el];
+                }
+            }
+            emit(v);
         }
     }
-    if (!FILL && valid) ovc[o * sh.n_parts + part] = n_ov;
+    if (!FILL && valid) {
+        if (V == 1u)
+            ovc[e] = n_ov;
+        else if (n_ov)
+            atomicAdd(&ovc[e], n_ov);
+    }
 }
 
 // An unused general position reads a row that is certainly in the ring at its visit — row 0 of the visit's own tile — with
@@ -350,7 +473,7 @@ __global__ void tile_init_rows_kernel(uint16_t *__restrict__ prow, uint64_t n_re
 // Unit mode: the stored weight is w / (uo[outer] * vi[inner]) — the kernel works on panel rows scaled by vi and scales a
 // vector's sum by uo at the end.
 __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t *__restrict__ prow, const uint8_t *__restrict__ pcnt,
-                                                           double *__restrict__ pw, uint64_t n_rec, uint64_t n_outer, TileShape sh, DevMap map,
+                                                           double *__restrict__ pw, uint64_t n_rec, const uint32_t *__restrict__ slot_vec, uint64_t n_slots, TileShape sh, DevMap map,
                                                            const double *__restrict__ uo, const double *__restrict__ vi, uint32_t skip,
                                                            const double *__restrict__ tab, int tab_outer, uint32_t vmajor_groups) {
     const uint32_t per_row = 64u - skip; // 64 or 32 (K = 2, one unit position)
@@ -397,7 +520,8 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t *__res
             const uint32_t b = sv & (sh.nset - 1u);
             const uint32_t gv = sv >> nset_shift;
             const uint32_t g = (uint32_t)(((double)gv + 0.5) * inv_nt), v = gv - g * sh.nt;
-            oo[u] = g * sh.S + b * sh.sps + slot; // outer positions fit 32 bits (the map's arrays are indexed by 32-bit positions)
+            const uint32_t gs = g * sh.S + b * sh.sps + slot; // slot of the layout -> the outer vector it belongs to (padding slots of the last group: unused positions only)
+            oo[u] = gs < n_slots ? slot_vec[gs] : 0u;
             const uint32_t bufi = (uint32_t)(((float)code[u] + 0.5f) * inv_T), r = code[u] - bufi * sh.T;
             const uint32_t vmod = sh.B == 4u ? (v & 3u) : v % sh.B; // the default ring has 4 buffers
             const uint32_t d = vmod >= bufi ? vmod - bufi : vmod + sh.B - bufi; // visits the nonzero waited
@@ -505,6 +629,11 @@ __global__ void tile_scale_panel_kernel(const double *__restrict__ X, uint32_t l
     Xc[e] = c < l ? vi[r] * X[r * ldx + c] : 0.0;
 }
 
+__global__ void tile_gather_slots_kernel(const double *__restrict__ per_vec, const uint32_t *__restrict__ slot_vec, uint64_t n_slots, double *__restrict__ per_slot) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_slots) per_slot[i] = per_vec[slot_vec[i]];
+}
+
 __global__ void tile_ovptr_kernel(const unsigned long long *__restrict__ ov_off, uint64_t n_outer, uint32_t n_parts,
                                   uint64_t *__restrict__ indptr) {
     const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -517,6 +646,11 @@ __global__ void tile_ovptr_kernel(const unsigned long long *__restrict__ ov_off,
 struct TileLayout {
     TileShape sh{};
     uint64_t n_groups = 0;
+    uint64_t n_slots = 0;          // "outer vectors" of the product kernel: a vector owns slot_first[o] .. slot_first[o + 1] (none: all of it is overflow)
+    uint32_t max_mult = 1;         // most slots one vector owns
+    DevBuf<uint32_t> slot_first;   // [n_outer + 1]
+    DevBuf<uint32_t> slot_vec;     // [n_slots]: the vector a slot belongs to
+    double split_x = 0.0, split_min = 0.0; // the rule the slots were made with (0: one slot per vector)
     DevBuf<uint16_t> prow; // [group][visit][set][64]: ring row of the position (16 bits: the kernel multiplies a half of a
                            // scalar register by the row pitch in one v_mad_u32_u16 — a byte would cost a scalar extract per position)
     DevBuf<uint8_t> pcnt;  // same index: the raw count (0 = unused position; counts above 255 live in the overflow part)
@@ -525,6 +659,7 @@ struct TileLayout {
     // unit mode (sh.KU > 0 and a separable map): per-outer / per-inner factors of the weight of a count-1 nonzero
     bool unit_mode = false;
     DevBuf<double> uo, vi;
+    DevBuf<double> uo_slot;   // uo by slot (what the product kernel scales a slot's sums by)
     DevBuf<double> ratio_tab; // unit mode: quotient of the weight of counts 1 .. TL_TABC per position of the side that owns the nonlinear links
     // identity of the map the weights were evaluated under (MapOp ids are never reused); -1: none yet
     int sig_n = -1;
@@ -532,7 +667,10 @@ struct TileLayout {
     int sig_outer[MAX_OPS] = {};
     double bytes() const { return (double)prow.n * 2.0 + (double)pcnt.n + (double)pw.n * 8.0 + (double)ov.nnz * 16.0 + (double)ratio_tab.n * 8.0; }
     bool structure_matches(const Storage &st) const {
-        return sh.K == st.tile_k && sh.S == st.tile_s && sh.T == st.tile_t && sh.B == st.tile_b && sh.KU == (st.tile_k == 2u && st.tile_ku ? 1u : 0u);
+        const bool splittable = st.tile_builder != 0 && sh.K == 2u && sh.B == 4u && sh.S == 32u && sh.T == 48u; // the wave-level builder's shape
+        const double want_x = splittable && st.tile_split ? st.tile_split_x : 0.0, want_min = splittable && st.tile_split ? st.tile_split_min : 0.0;
+        return sh.K == st.tile_k && sh.S == st.tile_s && sh.T == st.tile_t && sh.B == st.tile_b && sh.KU == (st.tile_k == 2u && st.tile_ku ? 1u : 0u) &&
+               split_x == want_x && split_min == want_min;
     }
     bool weights_match(const DevMap &map) const {
         if (sig_n != map.n) return false;
@@ -569,7 +707,45 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     sh.sps = 64u / sh.K;
     sh.nset = (sh.S + sh.sps - 1) / sh.sps;
     sh.nt = (uint32_t)((cp.n_inner + sh.T - 1) / sh.T);
-    tl->n_groups = (cp.n_outer + sh.S - 1) / sh.S;
+    hipStream_t s = stream ? stream : st.stream;
+    auto lap = [&](const char *what) { // SCANRS_TRACE: where a build spends its time (forces a sync per phase)
+        static thread_local std::chrono::steady_clock::time_point t_prev;
+        if (!trace_on()) return;
+        (void)wait_stream_quiet(s);
+        const auto t_now = std::chrono::steady_clock::now();
+        if (what) fprintf(stderr, "[scanrs trace]   layout: %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t_now - t_prev).count());
+        t_prev = t_now;
+    };
+    lap(nullptr);
+    // the wave-level builder serves the default shape; other shapes (experiments) keep the per-thread walk, one slot per vector
+    const bool wave_builder = st.tile_builder != 0 && sh.K == 2u && sh.B == 4u && sh.S == 32u && sh.T == 48u && sh.nset == 1u;
+    const bool split = wave_builder && st.tile_split != 0;
+    tl->split_x = split ? st.tile_split_x : 0.0;
+    tl->split_min = split ? st.tile_split_min : 0.0;
+    // ---- slots ----
+    if (cp.n_outer + 1 > 0xFFFFFFFFull) fail(SCANRS_ERR_SHAPE, "matrix too large for the tile layout's 32-bit slot index");
+    DevBuf<uint32_t> mult(cp.n_outer + 1);
+    tl->slot_first.alloc(cp.n_outer + 1);
+    hipLaunchKernelGGL(tile_mult_kernel, grid_1d(cp.n_outer + 1), dim3(256), 0, s, cp.indptr.p, cp.n_outer, (double)sh.T / (double)std::max<uint64_t>(1, cp.n_inner),
+                       tl->split_x, tl->split_min, sh.S, mult.p);
+    size_t tmp_bytes_u = 0;
+    SCANRS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes_u, mult.p, tl->slot_first.p, 0u, (size_t)cp.n_outer + 1, rocprim::plus<uint32_t>(), s));
+    DevBuf<char> tmp_u(std::max<size_t>(tmp_bytes_u, 16));
+    SCANRS_HIP(rocprim::exclusive_scan(tmp_u.p, tmp_bytes_u, mult.p, tl->slot_first.p, 0u, (size_t)cp.n_outer + 1, rocprim::plus<uint32_t>(), s));
+    uint32_t n_slots32 = 0, *d_max = nullptr;
+    DevBuf<uint32_t> maxbuf(1);
+    d_max = maxbuf.p;
+    size_t tmp_bytes_m = 0;
+    SCANRS_HIP(rocprim::reduce(nullptr, tmp_bytes_m, mult.p, d_max, 0u, (size_t)cp.n_outer + 1, rocprim::maximum<uint32_t>(), s));
+    DevBuf<char> tmp_m(std::max<size_t>(tmp_bytes_m, 16));
+    SCANRS_HIP(rocprim::reduce(tmp_m.p, tmp_bytes_m, mult.p, d_max, 0u, (size_t)cp.n_outer + 1, rocprim::maximum<uint32_t>(), s));
+    SCANRS_HIP(hipMemcpyAsync(&n_slots32, tl->slot_first.p + cp.n_outer, 4, hipMemcpyDeviceToHost, s));
+    SCANRS_HIP(hipMemcpyAsync(&tl->max_mult, d_max, 4, hipMemcpyDeviceToHost, s));
+    SCANRS_SYNC(s);
+    tl->n_slots = n_slots32; // (a u32 scan: a sum past 2^32 would need > 2^32 vectors x 32 slots; the visit-index check below bounds it far lower)
+    tl->slot_vec.alloc(std::max<uint64_t>(tl->n_slots, 1));
+    hipLaunchKernelGGL(tile_slotvec_kernel, grid_1d(std::max<uint64_t>(cp.n_outer, 1)), dim3(256), 0, s, tl->slot_first.p, cp.n_outer, tl->slot_vec.p);
+    tl->n_groups = (tl->n_slots + sh.S - 1) / sh.S;
     // items = (workgroup of TL_NW groups, part of the tile range), dealt round-robin to one persistent workgroup per CU: about
     // 16 rounds, the part count chosen so that the last round is nearly full. A nonzero never waits across a part boundary.
     int dev = 0, n_cu = 256;
@@ -580,40 +756,35 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     parts = std::min<uint32_t>(parts, std::max<uint32_t>(1u, sh.nt / 16u));
     sh.tpp = (sh.nt + parts - 1) / parts;
     sh.n_parts = (sh.nt + sh.tpp - 1) / sh.tpp;
-    hipStream_t s = stream ? stream : st.stream;
     const uint64_t n_rec = tl->n_groups * sh.nt * sh.nset * 64u;
-    if (n_rec == 0) return tl.release();
     if (tl->n_groups * sh.nt > 0xFFFFFFFFull || (sh.nset & (sh.nset - 1u))) fail(SCANRS_ERR_SHAPE, "matrix too large for the tile layout's 32-bit visit index");
     const uint64_t n_seg = cp.n_outer * sh.n_parts;
-    auto lap = [&](const char *what) { // SCANRS_TRACE: where a build spends its time (forces a sync per phase)
-        static thread_local std::chrono::steady_clock::time_point t_prev;
-        if (!trace_on()) return;
-        (void)wait_stream_quiet(s);
-        const auto t_now = std::chrono::steady_clock::now();
-        if (what) fprintf(stderr, "[scanrs trace]   layout: %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t_now - t_prev).count());
-        t_prev = t_now;
-    };
-    lap(nullptr);
+    lap("slots");
+    // ---- count the overflow per (vector, part) ----
     DevBuf<unsigned long long> ovc(n_seg + 1), ovo(n_seg + 1);
-    SCANRS_HIP(hipMemsetAsync(ovc.p + n_seg, 0, 8, s));
+    SCANRS_HIP(hipMemsetAsync(ovc.p, 0, (n_seg + 1) * 8, s)); // the slots of a split vector add up theirs
     const dim3 grid((unsigned)((n_seg + 255) / 256));
-    // the wave-level builder serves the default shape; other shapes (experiments) keep the per-thread walk
-    const bool wave_builder = st.tile_builder != 0 && sh.K == 2u && sh.B == 4u && sh.S == 32u && sh.T == 48u && sh.nset == 1u;
     const uint64_t n_witems = ((tl->n_groups + 1) / 2) * sh.n_parts;
     if (wave_builder && n_witems > 0x7FFFFFFFull) fail(SCANRS_ERR_SHAPE, "matrix too large for the tile layout builder's grid");
     // waves per CU of the builder: its lanes read 64 different places of the matrix, so the lines in flight (2 x 128 B per lane) of
     // all resident waves must fit the L2 or they come from HBM several times; a dummy LDS allocation per wave caps the occupancy
     const size_t wb_lds = st.tile_build_waves ? std::min<size_t>(65536, TL_LDS / st.tile_build_waves) : 0;
+#define SCANRS_ASSIGN(FILLV, KUV, OVC, OFF, CUR, PROW, PCNT, OVI, OVV)                                                                          \
+    hipLaunchKernelGGL((tile_assign_wave_kernel<FILLV, 48, KUV>), dim3((unsigned)n_witems), dim3(64), wb_lds, s, cp.indptr.p, cp.indices.p, cp.values.p, \
+                       tl->slot_vec.p, tl->slot_first.p, tl->n_slots, tl->n_groups, sh, OVC, OFF, CUR, PROW, PCNT, OVI, OVV)
     if (wave_builder) {
-        if (sh.KU)
-            hipLaunchKernelGGL((tile_assign_wave_kernel<false, 48, 1>), dim3((unsigned)n_witems), dim3(64), wb_lds, s, cp.indptr.p, cp.indices.p, cp.values.p,
-                               cp.n_outer, tl->n_groups, sh, ovc.p, (const unsigned long long *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr,
-                               (uint32_t *)nullptr, (uint32_t *)nullptr);
-        else
-            hipLaunchKernelGGL((tile_assign_wave_kernel<false, 48, 0>), dim3((unsigned)n_witems), dim3(64), wb_lds, s, cp.indptr.p, cp.indices.p, cp.values.p,
-                               cp.n_outer, tl->n_groups, sh, ovc.p, (const unsigned long long *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr,
-                               (uint32_t *)nullptr, (uint32_t *)nullptr);
-    } else {
+        if (n_witems) {
+            if (sh.KU)
+                SCANRS_ASSIGN(false, 1, ovc.p, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr,
+                              (uint32_t *)nullptr, (uint32_t *)nullptr);
+            else
+                SCANRS_ASSIGN(false, 0, ovc.p, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr,
+                              (uint32_t *)nullptr, (uint32_t *)nullptr);
+        }
+        if (split && n_seg)
+            hipLaunchKernelGGL((tile_slotless_kernel<false>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, tl->slot_first.p, cp.n_outer, sh,
+                               ovc.p, (const unsigned long long *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    } else if (n_seg) {
         hipLaunchKernelGGL((tile_assign_kernel<false>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, cp.n_outer, sh, ovc.p,
                            (const unsigned long long *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     }
@@ -631,12 +802,14 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
                     (unsigned long long)cp.n_outer, (unsigned long long)cp.n_inner, 100.0 * (double)n_ov / (double)cp.nnz, 100.0 * max_overflow);
         return nullptr;
     }
-    tl->prow.alloc(n_rec);
-    tl->pcnt.alloc(n_rec);
-    tl->pw.alloc(n_rec);
+    if (n_rec) {
+        tl->prow.alloc(n_rec);
+        tl->pcnt.alloc(n_rec);
+        tl->pw.alloc(n_rec);
+    }
     lap("hipMalloc of records");
     // (the weights need no initialisation: tile_weights_kernel writes every position that is ever read, used or not)
-    if (!wave_builder) { // the per-thread walk patches records into an initialised layout; the wave builder writes every record itself
+    if (!wave_builder && n_rec) { // the per-thread walk patches records into an initialised layout; the wave builder writes every record itself
         hipLaunchKernelGGL(tile_init_rows_kernel, dim3((unsigned)std::min<uint64_t>((n_rec / 4 + 255) / 256, 1u << 23)), dim3(256), 0, s, tl->prow.p, n_rec, sh);
         SCANRS_HIP(hipMemsetAsync(tl->pcnt.p, 0, n_rec, s));
         lap("init rows + counts");
@@ -651,26 +824,51 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     ov.values.alloc(std::max<uint64_t>(n_ov, 1));
     ov.fvals.alloc(std::max<uint64_t>(n_ov, 1));
     if (wave_builder) {
-        if (sh.KU)
-            hipLaunchKernelGGL((tile_assign_wave_kernel<true, 48, 1>), dim3((unsigned)n_witems), dim3(64), wb_lds, s, cp.indptr.p, cp.indices.p, cp.values.p,
-                               cp.n_outer, tl->n_groups, sh, (unsigned long long *)nullptr, ovo.p, tl->prow.p, tl->pcnt.p, ov.indices.p, ov.values.p);
-        else
-            hipLaunchKernelGGL((tile_assign_wave_kernel<true, 48, 0>), dim3((unsigned)n_witems), dim3(64), wb_lds, s, cp.indptr.p, cp.indices.p, cp.values.p,
-                               cp.n_outer, tl->n_groups, sh, (unsigned long long *)nullptr, ovo.p, tl->prow.p, tl->pcnt.p, ov.indices.p, ov.values.p);
-    } else {
+        // the slots of a split vector take their places in the vector's overflow segment from a cursor (ovc, now a copy of the offsets)
+        if (tl->max_mult > 1u) SCANRS_HIP(hipMemcpyAsync(ovc.p, ovo.p, (n_seg + 1) * 8, hipMemcpyDeviceToDevice, s));
+        if (n_witems) {
+            if (sh.KU)
+                SCANRS_ASSIGN(true, 1, (unsigned long long *)nullptr, ovo.p, ovc.p, tl->prow.p, tl->pcnt.p, ov.indices.p, ov.values.p);
+            else
+                SCANRS_ASSIGN(true, 0, (unsigned long long *)nullptr, ovo.p, ovc.p, tl->prow.p, tl->pcnt.p, ov.indices.p, ov.values.p);
+        }
+        if (split && n_seg)
+            hipLaunchKernelGGL((tile_slotless_kernel<true>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, tl->slot_first.p, cp.n_outer, sh,
+                               (unsigned long long *)nullptr, ovo.p, ov.indices.p, ov.values.p);
+    } else if (n_seg) {
         hipLaunchKernelGGL((tile_assign_kernel<true>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, cp.n_outer, sh,
                            (unsigned long long *)nullptr, ovo.p, tl->prow.p, tl->pcnt.p, ov.indices.p, ov.values.p);
     }
+#undef SCANRS_ASSIGN
     SCANRS_HIP(hipGetLastError());
     lap("fill");
+    if (n_ov && tl->max_mult > 1u) {
+        // the overflow nonzeros of a split vector arrived in the order of its lanes: back into ascending index order (what the gather
+        // kernel's bounds table and the reference's accumulation order want) by a segmented sort over the vectors
+        if (n_ov > 0xFFFFFFFFull) fail(SCANRS_ERR_SHAPE, "overflow part of a split layout beyond 2^32-1 nonzeros is not supported");
+        DevBuf<uint32_t> ki(n_ov), vi2(n_ov);
+        unsigned end_bit = 1;
+        while (end_bit < 32u && (cp.n_inner >> end_bit) != 0) end_bit++;
+        size_t tb = 0;
+        SCANRS_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tb, ov.indices.p, ki.p, ov.values.p, vi2.p, (unsigned)n_ov, (unsigned)cp.n_outer, ov.indptr.p,
+                                                       ov.indptr.p + 1, 0u, end_bit, s));
+        DevBuf<char> tsort(std::max<size_t>(tb, 16));
+        SCANRS_HIP(rocprim::segmented_radix_sort_pairs(tsort.p, tb, ov.indices.p, ki.p, ov.values.p, vi2.p, (unsigned)n_ov, (unsigned)cp.n_outer, ov.indptr.p,
+                                                       ov.indptr.p + 1, 0u, end_bit, s));
+        SCANRS_HIP(hipMemcpyAsync(ov.indices.p, ki.p, n_ov * 4, hipMemcpyDeviceToDevice, s));
+        SCANRS_HIP(hipMemcpyAsync(ov.values.p, vi2.p, n_ov * 4, hipMemcpyDeviceToDevice, s));
+        SCANRS_SYNC(s);
+        lap("overflow sort");
+    }
     if (n_ov) ensure_bounds_public(st, ov, s);
     SCANRS_SYNC(s); // the temporaries are released on return
     lap("overflow bounds");
     if (trace_on())
-        fprintf(stderr, "[scanrs trace] tile layout: %llu outer x %llu inner, T %u x B %u, K %u, S %u, %llu groups x %u tiles in %u parts, nnz %llu, overflow %llu (%.1f %%), positions per nonzero %.2f, %.2f GB\n",
-                (unsigned long long)cp.n_outer, (unsigned long long)cp.n_inner, sh.T, sh.B, sh.K, sh.S, (unsigned long long)tl->n_groups, sh.nt,
-                sh.n_parts, (unsigned long long)cp.nnz, (unsigned long long)n_ov, 100.0 * (double)n_ov / (double)std::max<uint64_t>(1, cp.nnz),
-                ((double)cp.n_outer * sh.nt * sh.K) / (double)std::max<uint64_t>(1, cp.nnz), tl->bytes() / 1e9);
+        fprintf(stderr, "[scanrs trace] tile layout: %llu outer x %llu inner, T %u x B %u, K %u, S %u, %llu slots (most per vector %u) in %llu groups x %u tiles in %u parts, nnz %llu, overflow %llu (%.1f %%), positions per nonzero %.2f, %.2f GB\n",
+                (unsigned long long)cp.n_outer, (unsigned long long)cp.n_inner, sh.T, sh.B, sh.K, sh.S, (unsigned long long)tl->n_slots, tl->max_mult,
+                (unsigned long long)tl->n_groups, sh.nt, sh.n_parts, (unsigned long long)cp.nnz, (unsigned long long)n_ov,
+                100.0 * (double)n_ov / (double)std::max<uint64_t>(1, cp.nnz), ((double)tl->n_slots * sh.nt * sh.K) / (double)std::max<uint64_t>(1, cp.nnz),
+                tl->bytes() / 1e9);
     return tl.release();
 }
 
@@ -708,6 +906,9 @@ static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &c
         if (tl.vi.n != cp.n_inner) tl.vi.alloc(std::max<uint64_t>(cp.n_inner, 1));
         hipLaunchKernelGGL(tile_unit_factor_kernel, dim3((unsigned)((cp.n_outer + 255) / 256)), dim3(256), 0, st.stream, map, 1, nl_outer, cp.n_outer, tl.uo.p);
         hipLaunchKernelGGL(tile_unit_factor_kernel, dim3((unsigned)((cp.n_inner + 255) / 256)), dim3(256), 0, st.stream, map, 0, nl_outer, cp.n_inner, tl.vi.p);
+        if (tl.uo_slot.n != std::max<uint64_t>(tl.n_slots, 1)) tl.uo_slot.alloc(std::max<uint64_t>(tl.n_slots, 1));
+        if (tl.n_slots)
+            hipLaunchKernelGGL(tile_gather_slots_kernel, grid_1d(tl.n_slots), dim3(256), 0, st.stream, tl.uo.p, tl.slot_vec.p, tl.n_slots, tl.uo_slot.p);
         const uint64_t n_side = nl_outer ? cp.n_outer : cp.n_inner;
         if (tl.ratio_tab.n != n_side * TL_TABC) tl.ratio_tab.alloc(std::max<uint64_t>(n_side * TL_TABC, 1));
         hipLaunchKernelGGL(tile_ratio_table_kernel, grid_1d(n_side * TL_TABC), dim3(256), 0, st.stream, map, nl_outer, n_side, tl.ratio_tab.p);
@@ -722,7 +923,7 @@ static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &c
         dim3 grid((unsigned)std::min<uint64_t>((n_work + 255) / 256, 1u << 23));
         if (vmajor) grid = dim3((unsigned)((tl.n_groups * (64u - skip) + 255) / 256), vquads);
         hipLaunchKernelGGL(tile_weights_kernel, grid, dim3(256), 0, st.stream, tl.prow.p, tl.pcnt.p, tl.pw.p, n_rec,
-                           cp.n_outer, tl.sh, map, tl.unit_mode ? tl.uo.p : (const double *)nullptr, tl.unit_mode ? tl.vi.p : (const double *)nullptr, skip,
+                           tl.slot_vec.p, tl.n_slots, tl.sh, map, tl.unit_mode ? tl.uo.p : (const double *)nullptr, tl.unit_mode ? tl.vi.p : (const double *)nullptr, skip,
                            tl.unit_mode ? tl.ratio_tab.p : (const double *)nullptr, nl_outer, vmajor ? (uint32_t)tl.n_groups : 0u);
     }
     if (tl.ov.nnz) materialize_map_values(st, tl.ov, map, tl.ov.fvals.p);
@@ -978,21 +1179,32 @@ __global__ __launch_bounds__(64 * TL_NW) __attribute__((amdgpu_waves_per_eu(3, 3
     spmm_tile_body<K, S, KU>(ta, X, ldx, l, parts, ldo, part_stride, n_items);
 }
 
-// out[o, :] = sum over parts (in order) + overflow sum + LowRankOffset term  (sqz/src/low_rank_offset.rs:76-80)
+// out[o, :] = sum over the vector's slots (in order) of the sum over parts (in order) + overflow sum + LowRankOffset term
+// (sqz/src/low_rank_offset.rs:76-80)
 __global__ __launch_bounds__(256) void tile_finish_kernel(const double *__restrict__ parts, uint32_t n_parts, uint64_t part_stride,
-                                                          const double *__restrict__ ovout, uint64_t n_outer, uint32_t l, uint32_t ldp,
-                                                          uint32_t ldo, double *__restrict__ out, const double *__restrict__ off_a, uint32_t rank,
-                                                          const double *__restrict__ off_w, uint32_t ldw) {
+                                                          const uint32_t *__restrict__ slot_first, const double *__restrict__ ovout, uint64_t n_outer,
+                                                          uint32_t l, uint32_t ldp, uint32_t ldo, double *__restrict__ out, const double *__restrict__ off_a,
+                                                          uint32_t rank, const double *__restrict__ off_w, uint32_t ldw) {
     const uint32_t hp = (l + 1u) / 2u; // column pairs
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_outer * hp) return;
     const uint64_t o = e / hp;
     const uint32_t c = (uint32_t)(e % hp) * 2u;
-    d2 s = *reinterpret_cast<const d2 *>(parts + o * ldp + c);
-    for (uint32_t p = 1; p < n_parts; p++) {
-        const d2 t = *reinterpret_cast<const d2 *>(parts + (size_t)p * part_stride + o * ldp + c);
-        s.x += t.x;
-        s.y += t.y;
+    d2 s = (d2){0.0, 0.0};
+    const uint32_t s0 = slot_first[o], s1 = slot_first[o + 1];
+    for (uint32_t sl = s0; sl < s1; sl++) {
+        d2 t = *reinterpret_cast<const d2 *>(parts + (size_t)sl * ldp + c);
+        for (uint32_t p = 1; p < n_parts; p++) {
+            const d2 u = *reinterpret_cast<const d2 *>(parts + (size_t)p * part_stride + (size_t)sl * ldp + c);
+            t.x += u.x;
+            t.y += u.y;
+        }
+        if (sl == s0) {
+            s = t; // (one slot per vector: bit for bit the sum the unsplit layout gave)
+        } else {
+            s.x += t.x;
+            s.y += t.y;
+        }
     }
     if (ovout) {
         const d2 t = *reinterpret_cast<const d2 *>(ovout + o * ldp + c);
@@ -1123,11 +1335,11 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     const uint32_t wgg = (uint32_t)((tl.n_groups + TL_NW - 1) / TL_NW);
     const uint32_t n_items = wgg * sh.n_parts;
     const uint32_t grid = std::min<uint32_t>(n_items, (uint32_t)n_cu);
-    const uint64_t part_stride = cp.n_outer * (uint64_t)ldc; // partial sums and the overflow sum in compact rows of ldc columns
+    const uint64_t part_stride = std::max<uint64_t>(tl.n_slots, 1) * (uint64_t)ldc; // partial sums per slot, in compact rows of ldc columns
     double *pbuf = st.scratch.get<double>("tile_parts", (size_t)sh.n_parts * part_stride);
     double *ovout = nullptr;
     if (tl.ov.nnz) { // the overflow part through the texture path, beside the tile kernel
-        ovout = st.scratch.get<double>("tile_ovout", (size_t)part_stride);
+        ovout = st.scratch.get<double>("tile_ovout", (size_t)cp.n_outer * ldc); // the overflow sum per vector
         if (st.tile_overlap) {
             hipStream_t ovs = st.ov();
             SCANRS_HIP(hipEventRecord(st.ev_in, st.stream)); // the panel (and the scratch zero-fills) are ready
@@ -1140,7 +1352,7 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     }
     uint32_t *next_item = st.scratch.get<uint32_t>("tile_next_item", 1);
     SCANRS_HIP(hipMemsetAsync(next_item, 0, sizeof(uint32_t), st.stream));
-    TileArgs ta{tl.prow.p, tl.pw.p, tl.unit_mode ? tl.uo.p : nullptr, next_item, tl.n_groups, cp.n_outer, cp.n_inner, sh};
+    TileArgs ta{tl.prow.p, tl.pw.p, tl.unit_mode ? tl.uo_slot.p : nullptr, next_item, tl.n_groups, tl.n_slots, cp.n_inner, sh};
     // algorithmic bytes of the nonzeros this kernel works: 8 B each + indptr + the two panels
     const double bytes = (double)(cp.nnz - tl.ov.nnz) * 8.0 + (double)(cp.n_outer + 1) * 8.0 + (double)cp.n_inner * l * 8.0 + (double)cp.n_outer * l * 8.0;
     const bool long_outer = cp.n_outer >= cp.n_inner;
@@ -1149,7 +1361,8 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
                       (double)tl.n_groups * sh.nt * sh.S * sh.K * 8.0 * l);
 #define SCANRS_TILE(KK, SS, UU) launch_tile_kernel<KK, SS, UU>(st, ta, X, ldx, l, pbuf, ldc, part_stride, n_items, grid)
     const bool um = tl.unit_mode; // a layout with unit positions under a map that does not separate runs the weighted kernel
-    if (sh.K == 2 && sh.S == 32)
+    if (n_items == 0) { // every vector went to the overflow part: nothing for the tile kernel
+    } else if (sh.K == 2 && sh.S == 32)
         um ? SCANRS_TILE(2, 32, 1) : SCANRS_TILE(2, 32, 0);
     else if (sh.K == 2 && sh.S == 28)
         um ? SCANRS_TILE(2, 28, 1) : SCANRS_TILE(2, 28, 0);
@@ -1165,7 +1378,7 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     if (st.prof.on) st.prof.end(st.stream);
     if (ovout && st.tile_overlap) SCANRS_HIP(hipStreamWaitEvent(st.stream, st.ev_ov, 0));
     const uint64_t n = cp.n_outer * (uint64_t)((l + 1u) / 2u);
-    hipLaunchKernelGGL(tile_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, pbuf, sh.n_parts, part_stride, ovout,
+    hipLaunchKernelGGL(tile_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, pbuf, sh.n_parts, part_stride, tl.slot_first.p, ovout,
                        cp.n_outer, l, ldc, ldo, out, off_a, rank, off_w, ldw);
     SCANRS_HIP(hipGetLastError());
 }

@@ -47,7 +47,8 @@ def synth_counts(n_cells: int, n_genes: int, density: float, seed: int = 0, n_cl
     return m
 
 
-def synth_counts_fast(n_cells: int, n_genes: int, density: float, seed: int = 0, n_clusters: int = 20, chunk: int = 8192):
+def synth_counts_fast(n_cells: int, n_genes: int, density: float, seed: int = 0, n_clusters: int = 20, chunk: int = 8192,
+                      gene_shape: float = 0.4, shared_profile: float = 0.0):
     """The same model in its Poisson-process form, ~20x faster on the host (used for the BASELINE-size fixtures, which
     both the fixture script and the GPU test have to regenerate): gene g is present in cell c when a Poisson process
     of intensity depth_c * rate[cluster_c, g] * density / mean(rate) has at least one event, i.e. with probability
@@ -60,6 +61,12 @@ def synth_counts_fast(n_cells: int, n_genes: int, density: float, seed: int = 0,
 
     rng = np.random.default_rng(seed)
     rates = _profiles(rng, n_clusters, n_genes)
+    if gene_shape != 0.4 or shared_profile > 0.0:
+        # heavy-tailed variant (as `synth_counts_torch`): gene rates ~ Gamma(gene_shape), a part of the profile shared by all clusters —
+        # a few thousand genes detected in 10-100 % of the cells and most others in far below 1 %, as real 10x matrices have them
+        base = rng.gamma(gene_shape, 1.0, size=(1, n_genes))
+        own = rng.gamma(gene_shape, 1.0, size=(n_clusters, n_genes))
+        rates = shared_profile * base + (1.0 - shared_profile) * own
     scale = density / rates.mean()
     cum = np.cumsum(rates * scale, axis=1)  # n_clusters x n_genes
     total = cum[:, -1].copy()

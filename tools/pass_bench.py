@@ -14,7 +14,8 @@ from scanrs_amd.synth import synth_counts_torch
 
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 genes, l = 33_000, int(sys.argv[2]) if len(sys.argv) > 2 else 100
-kw = {k: float(v) for k, v in (a.split("=") for a in sys.argv[3:] if "=" in a)}  # gene_shape=0.1 shared_profile=1: a heavy-tailed model
+kw = {k: float(v) for k, v in (a.split("=") for a in sys.argv[3:] if "=" in a and not a.startswith("opt."))}  # gene_shape=0.1 shared_profile=1: a heavy-tailed model
+opts = {k[4:]: float(v) for k, v in (a.split("=") for a in sys.argv[3:] if a.startswith("opt."))}  # opt.tile_split_x=1.7: handle options
 configs = [a for a in sys.argv[3:] if "=" not in a] or ["0"]
 dev = torch.device("cuda", 0)
 ip, ix, vv = synth_counts_torch(cells, genes, 0.03, 0, dev, **kw)
@@ -34,6 +35,8 @@ for cfg in configs:
     m = sa.AdaptiveMat.from_device(genes, cells, sa.CSC, ip.data_ptr(), ix.data_ptr(), vv.data_ptr())
     m.set_spmm_path(parts[0])
     for key, val in zip(("tile_k", "tile_s", "tile_t", "tile_b", "tile_overlap", "tile_ku", "ov_tile_kb"), parts[1:]):
+        m.set_option(key, val)
+    for key, val in opts.items():
         m.set_option(key, val)
     sa.normalize(m, sa.Normalization.CellRanger)
 
