@@ -30,7 +30,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-PMC_PROFILE = "r03f_pmc_traffic.json"  # committed PMC passes (separate --pmc runs) the `traffic` field is read from
+LDS_PEAK_TBS = 78.6    # 256 CUs x 128 B/clk x 2.4 GHz: the on-chip ceiling the tile kernel's row reads run against
+PMC_PROFILE = "r04a_pmc_traffic.json"  # committed PMC passes (separate --pmc runs) the `traffic` field is read from
+KERNEL_SOURCES = ("scan-rs_amd/csrc/tiles.hip", "scan-rs_amd/csrc/kernels.hip", "scan-rs_amd/csrc/device_map.hpp")
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the sparse kernels: the committed PMC file carries the hash of the sources it was measured on, and
+    `traffic` is only quoted from it when the sources loaded now are the same (profiles/summarize.py writes it)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -46,6 +60,8 @@ def parse():
     ap.add_argument("--cpu-cells", type=int, default=16000, help="cells of the 1-core CPU-baseline sample")
     ap.add_argument("--cpu-cells-all", type=int, default=100000, help="cells of the all-core CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reserve", action="store_true", help="do not reserve device memory ahead of the handle (scanrs_reserve_device_memory)")
+    ap.add_argument("--reserve-bytes-per-nnz", type=float, default=72.0, help="size of that reserve per nonzero of the shard")
     ap.add_argument("--no-heavy-tailed", action="store_true", help="skip the second, clearly labelled measurement on the heavy-tailed gene profile")
     ap.add_argument("--no-host-delivery", action="store_true", help="leave U and V in HBM in every step (value is then the device-resident rate)")
     ap.add_argument("--f32-panels", action="store_true",
@@ -262,6 +278,13 @@ def main():
     nnz_local = int(indptr[-1].item())
     n_local = hi - lo
 
+    # One allocation ahead of the handle (scanrs_reserve_device_memory): a caller knows the size of its matrix before the first PCA.
+    # On a box whose memory another process has just freed, the driver is still scrubbing it and an allocation waits for that
+    # (profiles/microbench/alloc_probe2: 0.24 s per 8 GB) — environment, not the path measured here; config.reserve_s reports it.
+    t_r = time.perf_counter()
+    if not args.no_reserve:
+        sa.reserve_device_memory(int(args.reserve_bytes_per_nnz * nnz_local) + (2 << 30))
+    t_reserve = time.perf_counter() - t_r
     # genes x cells (Cell Ranger orientation), stored cell-major = CSC
     dbg(f"shard [{lo}, {hi}) nnz {nnz_local}: create handle")
     torch.cuda.synchronize()
@@ -327,11 +350,17 @@ def main():
         mat.set_option(key, float(val))
     bk = sa.BkSvd()  # k_multiplier 2.0, n_iter 5: the solver scan-rs-cmd uses (tools/src/bin/cmd.rs:70)
 
-    def step(download=False):
+    # U and V land in caller-allocated row-major buffers, as the boundary specifies ("outputs written into
+    # caller-allocated row-major f64 buffers"; include/scanrs_amd.h scanrs_pca_bk) — the same two arrays in every step, like a caller
+    # that keeps its result buffers; config.fresh_result_arrays_ms_per_step is the step with new arrays per call (page faults of
+    # 413 MB of untouched pages + their munmap, the Python wrapper's default)
+    out_u, out_v = np.zeros((args.genes, args.k)), np.zeros((n_local, args.k))
+
+    def step(download=False, fresh=False):
         mat.reset_map()
         sa.normalize(mat, sa.Normalization.CellRanger)
         if download:
-            return bk.run_pca(mat, args.k)
+            return bk.run_pca(mat, args.k) if fresh else bk.run_pca(mat, args.k, out=(out_u, out_v))
         s, _res = bk.run_pca_device(mat, args.k)
         return None, s, None
 
@@ -353,7 +382,7 @@ def main():
     if args.no_host_delivery:
         bk.run_pca_device(mat, args.k)
     else:
-        bk.run_pca(mat, args.k)
+        bk.run_pca(mat, args.k)  # fresh arrays: what a first call pays
     t_first["run_pca"] = time.perf_counter()
     barrier()
     t_setup = time.time() - t0
@@ -374,7 +403,7 @@ def main():
     }
     torch.cuda.empty_cache()
     sa.release_cached_memory()  # blocks the library keeps for reuse (the transposition's temporaries) are not resident data
-    mem_after_first = max(0, free_at_start - torch.cuda.mem_get_info(dev)[0])  # everything the handle keeps: both copies, layouts, scratch
+    mem_after_first = sa.device_memory_in_use()  # everything the handle keeps: both copies, layouts, scratch (the library's own count of its live buffers)
     for i in range(max(0, args.warmup - 1)):
         dbg(f"warmup {i + 1}")
         step(download=not args.no_host_delivery)
@@ -405,6 +434,14 @@ def main():
     barrier()
     events_elapsed = time.perf_counter() - t0
     mat.profile_enable(False)
+    fresh_ms = None
+    if not args.no_host_delivery:  # the same step handing out NEW host arrays every time (the Python wrapper's default form)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(download=True, fresh=True)
+        barrier()
+        fresh_ms = (time.perf_counter() - t0) / args.steps * 1e3
     dbg("reductions over ranks")
     rank_ms = [elapsed_local / args.steps * 1e3]
     if dist is not None:
@@ -490,7 +527,7 @@ def main():
         def hstep():
             hmat.reset_map()
             sa.normalize(hmat, sa.Normalization.CellRanger)
-            return bk.run_pca(hmat, args.k) if not args.no_host_delivery else bk.run_pca_device(hmat, args.k)
+            return bk.run_pca(hmat, args.k, out=(out_u, out_v)) if not args.no_host_delivery else bk.run_pca_device(hmat, args.k)
 
         hstep()
         hstep()
@@ -523,11 +560,21 @@ def main():
             with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as f:
                 pj = json.load(f)
             pm = pj["kernels"].get(name) or pj["kernels"].get(name.split("/")[0])  # the tile kernel is one class in the trace (both orientations)
-            if pm and args.cells == 1_000_000 and args.genes == 33_000 and world == 1:
+            have, want = kernel_source_hash(), pj.get("kernel_source_sha256_16")
+            if not (pm and args.cells == 1_000_000 and args.genes == 33_000 and world == 1):
+                traffic_src = f"profiles/{PMC_PROFILE} holds the headline workload on 1 GPU only"
+            elif want != have:
+                traffic_src = (f"null on purpose: profiles/{PMC_PROFILE} was measured on kernel sources {want} (commit {pj.get('commit', '?')}), the sources "
+                               f"loaded now hash to {have} - re-run tools/profile_round.sh")
+            else:
                 traffic = round(pm["hbm_bytes_per_launch_corrected"])
-                traffic_src = f"profiles/{PMC_PROFILE} (committed rocprofv3 --pmc passes of this command, commit {pj.get('commit', '?')}; NOT measured in this run)"
-        except (OSError, ValueError, KeyError):
-            traffic = None
+                traffic_src = (f"profiles/{PMC_PROFILE}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at commit {pj.get('commit', '?')}, same kernel "
+                               f"sources ({have}); not measured inside this run")
+        except (OSError, ValueError, KeyError) as e:
+            traffic, traffic_src = None, f"profiles/{PMC_PROFILE} unreadable: {e}"
+        alg_per_launch = st["algorithmic_bytes"] / max(1, st["launches"])
+        lds_per_launch = st["onchip_gather_bytes"] / max(1, st["launches"])
+        avg_s = st["total_ms"] / max(1, st["launches"]) * 1e-3
         roof = {
             "bound": "hbm",
             "kernel": name,
@@ -540,12 +587,16 @@ def main():
             "launches_per_step": st["launches"] / args.steps,
             "avg_launch_ms": round(st["total_ms"] / max(1, st["launches"]), 4),
             "algorithmic_bytes_per_launch": round(st["algorithmic_bytes"] / max(1, st["launches"])),
-            # the product is bound by the on-chip gather of panel rows (L2 -> CU), not by HBM: DESIGN.md §4.
-            # ceiling: 16.8-18.8 TB/s chip-wide for L2-resident indexed rows (MI355X_MICROARCH.md, "Indexed rows")
-            "onchip_gather": {
-                "achieved_TBps": round(st["onchip_gather_bytes"] / (st["total_ms"] * 1e-3) / 1e12, 2) if st["total_ms"] > 0 and st["onchip_gather_bytes"] else None,
-                "ceiling_TBps": 17.8,
-                "bytes_per_launch": round(st["onchip_gather_bytes"] / max(1, st["launches"])),
+            # HBM bytes the counters saw per algorithmic byte (re-reads, staging through L2 misses): the first thing to fix when >> 1
+            "wasted_traffic_ratio": round(traffic / alg_per_launch, 2) if traffic and alg_per_launch else None,
+            # the ceiling that actually binds this kernel: panel rows read from LDS (one 16-byte read per lane and record position)
+            # against the LDS bandwidth of the chip; HBM is far from it by construction (800 B of panel row per 8 B of matrix)
+            "onchip": {
+                "unit": "TB/s of LDS row reads",
+                "bytes_per_launch": round(lds_per_launch),
+                "achieved": round(lds_per_launch / avg_s / 1e12, 2) if avg_s > 0 and lds_per_launch else None,
+                "peak": LDS_PEAK_TBS,
+                "frac": round(lds_per_launch / avg_s / 1e12 / LDS_PEAK_TBS, 4) if avg_s > 0 and lds_per_launch else None,
             },
             "kernel_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
             "launches_per_step_all": {k: round(v["launches"] / args.steps, 1) for k, v in sorted(prof.items())},
@@ -624,8 +675,10 @@ def main():
                 "nnz": nnz_global,
                 "parallelism": f"cells range-partitioned by nonzeros over {world} GPU(s)" + (", one sum all-reduce per contracting product" if world > 1 else ""),
                 "transport": transport,
-                "result_delivery": ("value: every step returns U, sigma, V as host arrays (run_pca's contract); device_resident_*: the same steps with U, V "
+                "result_delivery": ("value: every step delivers U, sigma, V into caller-allocated host arrays (the C ABI's form, reused across steps); "
+                                    "fresh_result_arrays_ms_per_step: new host arrays per step; device_resident_*: the same steps with U, V "
                                     "left in HBM (scanrs_pca_result_device)") if not args.no_host_delivery else "--no-host-delivery: U, V left in HBM in every step",
+                "fresh_result_arrays_ms_per_step": round(fresh_ms, 2) if fresh_ms is not None else None,
                 "device_resident_cells_per_s": round(args.cells * args.steps / events_elapsed, 1),
                 "device_resident_ms_per_step": round(events_elapsed / args.steps * 1e3, 2),
                 "v_col_norm_err_device_result": v_col_norm_err,
@@ -636,6 +689,7 @@ def main():
                 "heavy_tailed_ms_per_step": heavy["ms_per_step"] if heavy else None,
                 "heavy_tailed_profile": heavy,
                 "library_init_s": round(t_init, 3),
+                "reserve_s": round(t_reserve, 3),
                 "resident_bytes_per_nonzero": round(mem_after_first / max(1, nnz_local), 1) if mem_after_first else None,
                 "datagen_s": round(t_gen, 2),
                 "sigma_top3": [round(float(x), 6) for x in (sig[:3] if sig is not None else [])],

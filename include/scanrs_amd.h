@@ -381,9 +381,18 @@ int scanrs_set_global_option(const char *key, double value);
  * touches the runtime paths the first call would otherwise initialise (~30-60 ms on MI355X): call it at program start to
  * keep that out of the first scanrs_mat_create / normalize / PCA. Everything works without it. */
 int scanrs_init(void);
+/* Optional: one allocation of `bytes` made now, on the calling thread's current device, from which the library carves its later
+ * large buffers (about 70 bytes per nonzero for a matrix that goes through normalize + PCA with the hybrid product). A caller who
+ * knows the size of the matrix before it is loaded takes the allocation's latency — on a device whose memory was just freed by
+ * another process the driver is still scrubbing it, and an allocation waits for that — out of the first PCA. Blocks carved from
+ * a reserve return to the library's cache, the reserve itself goes back to the driver with scanrs_release_cached_memory once
+ * none of it is in use. */
+int scanrs_reserve_device_memory(uint64_t bytes);
 /* Gives the cached device blocks (see "device_cache_fraction") back to the driver / reports how much is cached. */
 int scanrs_release_cached_memory(void);
 int scanrs_cached_memory_bytes(uint64_t *bytes);
+/* Device memory in the library's buffers right now, all handles of the process (blocks waiting in the cache not counted). */
+int scanrs_device_memory_in_use(uint64_t *bytes);
 /* Arithmetic of the large sparse products: 0 (default) = f64 throughout, the reference's arithmetic; 1 = opt-in fast
  * mode: the dense panel is rounded to f32 before it is gathered (half the on-chip bytes per nonzero), products and
  * sums stay f64. Singular values / loadings then agree with the f64 path to ~1e-7 relative, not to rounding. */

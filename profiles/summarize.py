@@ -58,6 +58,16 @@ def main():
         commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL, text=True).strip()
     except Exception:
         commit = os.environ.get("SCANRS_COMMIT", "working tree")
+    # the sources the kernels were built from: bench.py quotes `traffic` from this file only while they are unchanged
+    import hashlib
+
+    hsrc = hashlib.sha256()
+    for rel in ("scan-rs_amd/csrc/tiles.hip", "scan-rs_amd/csrc/kernels.hip", "scan-rs_amd/csrc/device_map.hpp"):
+        with open(rel, "rb") as f:
+            hsrc.update(f.read())
+    src_hash = hsrc.hexdigest()[:16]
+    if commit == "working tree" or not commit:
+        commit = os.environ.get("SCANRS_COMMIT", "working tree")
     # ---- HBM traffic ---------------------------------------------------------------------------------------------------
     tr = {}
     for cname, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
@@ -76,7 +86,7 @@ def main():
                 "--steps 1 --warmup 1 --no-cpu-baseline --no-host-delivery ; 1M x 33k, 3% nnz, k=50, MI355X. Counter unit KB; each run holds 3 PCAs "
                 "(first pass, timed step, event-recording step). 'corrected' doubles FETCH_SIZE as MI355X_MICROARCH.md section HBM "
                 "prescribes for 16-B-per-lane coalesced reads (uncalibrated for the gather pattern: an upper estimate).",
-        "commit": commit, "kernels": tr}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+        "commit": commit, "kernel_source_sha256_16": src_hash, "kernels": tr}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
     # ---- on-chip counters ----------------------------------------------------------------------------------------------
     cc = {}
     for sub in ("tcc", "sq", "tcp", "lds"):
@@ -102,7 +112,7 @@ def main():
                 "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY}, {TCP_TOTAL_CACHE_ACCESSES_sum "
                 "TCP_TCC_READ_REQ_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum}; same command as the traffic passes; averages per launch of a kernel class. "
                 "SQ_* are in quad-cycles summed over waves (MI355X_MICROARCH.md, rocprofv3 PMC slots).",
-        "commit": commit, "kernels": cc}, open(f"profiles/{tag}_pmc_counters.json", "w"), indent=1)
+        "commit": commit, "kernel_source_sha256_16": src_hash, "kernels": cc}, open(f"profiles/{tag}_pmc_counters.json", "w"), indent=1)
     # ---- kernel stats -----------------------------------------------------------------------------------------------------
     sfile, tfile = one(f"{raw}/stats/**/*_kernel_stats.csv"), one(f"{raw}/stats/**/*_kernel_trace.csv")
     if sfile and tfile:

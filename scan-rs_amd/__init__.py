@@ -538,6 +538,11 @@ def init():
     _check(_lib.scanrs_init())
 
 
+def reserve_device_memory(n_bytes: int):
+    """`scanrs_reserve_device_memory`: one allocation now that the library's later large buffers are carved from."""
+    _check(_lib.scanrs_reserve_device_memory(ctypes.c_uint64(int(n_bytes))))
+
+
 def release_cached_memory():
     """Give the device blocks the library keeps for reuse back to the driver (include/scanrs_amd.h, "device_cache_fraction")."""
     _check(_lib.scanrs_release_cached_memory())
@@ -546,6 +551,12 @@ def release_cached_memory():
 def cached_memory_bytes() -> int:
     n = ctypes.c_uint64()
     _check(_lib.scanrs_cached_memory_bytes(ctypes.byref(n)))
+    return int(n.value)
+
+
+def device_memory_in_use() -> int:
+    n = ctypes.c_uint64()
+    _check(_lib.scanrs_device_memory_in_use(ctypes.byref(n)))
     return int(n.value)
 
 
@@ -620,10 +631,19 @@ class BkSvd:
     def __init__(self, k_multiplier: float = 2.0, n_iter: int = 5):
         self.k_multiplier, self.n_iter = k_multiplier, n_iter
 
-    def run_pca(self, matrix: AdaptiveMat, k: int, omega=None, snoop: Optional[AtomicSnoop] = None, seed: int = 0):
-        """Returns (u rows x k, s k, v cols x k) — `PcaResult` (dim_red/mod.rs:47)."""
+    def run_pca(self, matrix: AdaptiveMat, k: int, omega=None, snoop: Optional[AtomicSnoop] = None, seed: int = 0, out=None):
+        """Returns (u rows x k, s k, v cols x k) — `PcaResult` (dim_red/mod.rs:47). `out=(u, v)`: the factors are written into
+        these C-contiguous float64 arrays of shape (rows, k) / (cols, k) — the C ABI's own form (caller-allocated buffers,
+        include/scanrs_amd.h) — instead of fresh ones."""
         r, c = matrix.shape()
-        u, s, v = np.zeros((r, max(k, 0))), np.zeros(max(k, 0)), np.zeros((c, max(k, 0)))
+        if out is not None:
+            u, v = out
+            for a_, shp in ((u, (r, k)), (v, (c, k))):
+                if not (isinstance(a_, np.ndarray) and a_.dtype == np.float64 and a_.flags.c_contiguous and a_.shape == shp):
+                    raise ScanrsError(6, f"out arrays must be C-contiguous float64 of shape {shp}")
+            s = np.zeros(max(k, 0))
+        else:
+            u, s, v = np.zeros((r, max(k, 0))), np.zeros(max(k, 0)), np.zeros((c, max(k, 0)))
         om = None if omega is None else _f64(omega)
         sref, _keep = _snoop_arg(snoop)
         _check(
@@ -868,7 +888,7 @@ EXPORTED_SYMBOLS = [
     "scanrs_pca_bk", "scanrs_pca_rand", "scanrs_pca_irlba", "scanrs_pca_result_device", "scanrs_knn_device", "scanrs_omega_fill", "scanrs_mat_set_shard", "scanrs_mat_set_shard_comm", "scanrs_comm_get_unique_id", "scanrs_comm_create", "scanrs_comm_free",
     "scanrs_multi_create", "scanrs_multi_free", "scanrs_multi_n_shards", "scanrs_multi_shard", "scanrs_multi_normalize", "scanrs_multi_pca_bk", "scanrs_multi_pca_rand", "scanrs_multi_pca_irlba", "scanrs_multi_log_normalize",
     "scanrs_plan_shards", "scanrs_profile_enable", "scanrs_profile_reset", "scanrs_profile_get", "scanrs_mat_sync", "scanrs_mat_set_spmm_path", "scanrs_mat_set_option", "scanrs_set_global_option", "scanrs_mat_set_panel_precision",
-    "scanrs_mat_chol_rinv", "scanrs_mat_get_counter", "scanrs_host_chol_upper", "scanrs_host_inv_upper", "scanrs_host_sym_eig", "scanrs_host_sym_eig_topk", "scanrs_debug_wait_never", "scanrs_debug_barrier_alone", "scanrs_init", "scanrs_release_cached_memory", "scanrs_cached_memory_bytes",
+    "scanrs_mat_chol_rinv", "scanrs_mat_get_counter", "scanrs_host_chol_upper", "scanrs_host_inv_upper", "scanrs_host_sym_eig", "scanrs_host_sym_eig_topk", "scanrs_debug_wait_never", "scanrs_debug_barrier_alone", "scanrs_init", "scanrs_release_cached_memory", "scanrs_cached_memory_bytes", "scanrs_reserve_device_memory", "scanrs_device_memory_in_use",
     "scanrs_h5_read_csc_matrix", "scanrs_h5_read_adaptive_csr_matrix", "scanrs_h5_read_matrix_metadata", "scanrs_h5_matrix_free",
     "scanrs_h5_matrix_shape", "scanrs_h5_matrix_arrays", "scanrs_h5_matrix_n_strings", "scanrs_h5_matrix_string", "scanrs_h5_matrix_removed",
     "scanrs_h5_read_umi_counts", "scanrs_h5_get_clustering_keys", "scanrs_h5_get_clustering", "scanrs_h5_get_differential_expression",

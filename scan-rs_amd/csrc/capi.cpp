@@ -216,10 +216,16 @@ struct Block {
     size_t size; // what hipMalloc was asked for
     int dev;
 };
+struct Reserve { // one large allocation made ahead of time (scanrs_reserve_device_memory) that later requests are carved from
+    char *base;
+    size_t size, used;
+    int dev;
+};
 struct DeviceMemory {
     std::mutex mu;
     std::vector<void *> dead;                           // released by their owners, waiting for a point where the device is idle
     std::map<void *, std::pair<size_t, int>> live;      // every block handed out: pointer -> (size, device)
+    std::vector<Reserve> reserves;                      // blocks carved from a reserve are never given back one by one: they stay in the cache
     std::multimap<std::pair<int, size_t>, void *> idle; // cached blocks by (device, size)
     size_t idle_bytes = 0;
     double cache_fraction = 0.5; // of the device's memory; 0: no cache (every released block goes back to the driver)
@@ -259,7 +265,9 @@ void device_free_flush() noexcept {
             if (it == g.live.end()) continue; // not ours (cannot happen)
             const Block b{p, it->second.first, it->second.second};
             g.live.erase(it);
-            if (b.size >= CACHE_MIN && g.idle_bytes + b.size <= cap) {
+            bool carved = false;
+            for (const Reserve &r : g.reserves) carved = carved || ((char *)p >= r.base && (char *)p < r.base + r.size);
+            if (carved || (b.size >= CACHE_MIN && g.idle_bytes + b.size <= cap)) {
                 g.idle.emplace(std::make_pair(b.dev, b.size), p);
                 g.idle_bytes += b.size;
             } else {
@@ -285,11 +293,40 @@ void device_cache_release() noexcept {
     std::vector<void *> take;
     {
         std::lock_guard<std::mutex> lk(g.mu);
-        for (auto &kv : g.idle) take.push_back(kv.second);
-        g.idle.clear();
-        g.idle_bytes = 0;
+        bool any_live_in_reserve = false;
+        for (auto &kv : g.live)
+            for (const Reserve &r : g.reserves) any_live_in_reserve = any_live_in_reserve || ((char *)kv.first >= r.base && (char *)kv.first < r.base + r.size);
+        for (auto it = g.idle.begin(); it != g.idle.end();) {
+            bool carved = false;
+            for (const Reserve &r : g.reserves) carved = carved || ((char *)it->second >= r.base && (char *)it->second < r.base + r.size);
+            if (carved && any_live_in_reserve) { // part of a reserve that is still in use: stays
+                ++it;
+                continue;
+            }
+            if (!carved) take.push_back(it->second);
+            g.idle_bytes -= it->first.second;
+            it = g.idle.erase(it);
+        }
+        if (!any_live_in_reserve) { // nothing handed out from the reserves any more: they go back whole
+            for (const Reserve &r : g.reserves) take.push_back(r.base);
+            g.reserves.clear();
+        }
     }
     for (void *p : take) (void)hipFree(p);
+}
+void device_reserve(size_t bytes) {
+    if (!bytes) return;
+    DeviceMemory &g = devmem();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    void *p = nullptr;
+    const hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fail(SCANRS_ERR_DEVICE, "reserving %.2f GB of device memory failed: %s", (double)bytes / 1e9, hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.reserves.push_back(Reserve{(char *)p, bytes, 0, dev});
 }
 void device_cache_set_fraction(double f) {
     DeviceMemory &g = devmem();
@@ -303,6 +340,13 @@ size_t device_cache_bytes() {
     DeviceMemory &g = devmem();
     std::lock_guard<std::mutex> lk(g.mu);
     return g.idle_bytes;
+}
+size_t device_live_bytes() {
+    DeviceMemory &g = devmem();
+    std::lock_guard<std::mutex> lk(g.mu);
+    size_t n = 0;
+    for (auto &kv : g.live) n += kv.second.first;
+    return n;
 }
 void *device_alloc(size_t bytes) {
     DeviceMemory &g = devmem();
@@ -319,6 +363,16 @@ void *device_alloc(size_t bytes) {
             g.idle.erase(it);
             return p;
         }
+    }
+    if (want >= CACHE_MIN) { // carve from a reserve made ahead of time
+        std::lock_guard<std::mutex> lk(g.mu);
+        for (Reserve &r : g.reserves)
+            if (r.dev == dev && r.size - r.used >= want) {
+                void *p = r.base + r.used;
+                r.used += want;
+                g.live[p] = std::make_pair(want, dev);
+                return p;
+            }
     }
     void *p = nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -925,10 +979,23 @@ int scanrs_init(void) {
 int scanrs_release_cached_memory(void) {
     return guard([&] { device_cache_release(); });
 }
+int scanrs_reserve_device_memory(uint64_t bytes) {
+    return guard([&] {
+        need_device();
+        device_reserve((size_t)bytes);
+    });
+}
 int scanrs_cached_memory_bytes(uint64_t *bytes) {
     return guard([&] {
         if (!bytes) fail(SCANRS_ERR_ARGUMENT, "null argument");
         *bytes = device_cache_bytes();
+    });
+}
+int scanrs_device_memory_in_use(uint64_t *bytes) {
+    return guard([&] {
+        if (!bytes) fail(SCANRS_ERR_ARGUMENT, "null argument");
+        device_free_flush();
+        *bytes = device_live_bytes();
     });
 }
 

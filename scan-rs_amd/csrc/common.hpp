@@ -79,8 +79,10 @@ void device_free_later(void *p, size_t bytes);
 void device_free_flush() noexcept;
 void *device_alloc(size_t bytes); // hipMalloc with the retry above; throws Failure(SCANRS_ERR_DEVICE)
 void device_cache_release() noexcept;
+void device_reserve(size_t bytes);
 void device_cache_set_fraction(double f);
 size_t device_cache_bytes();
+size_t device_live_bytes();
 void library_warm_up(); // kernels.hip: loads every code object of the library (one empty launch per translation unit)
 uint64_t device_alloc_us();
 uint64_t device_alloc_calls();
@@ -410,6 +412,7 @@ void launch_gemm_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, c
                        uint64_t rows, double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo);
 void launch_copy_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows, uint32_t l);
 void launch_fill_f64(Storage &st, double *p, uint64_t n, double v);
+void launch_fill_hash(Storage &st, double *p, uint32_t ld, uint64_t rows, uint64_t row0, uint32_t c0, uint32_t nc, uint64_t seed);
 void launch_omega_jump(Storage &st, const uint64_t *d_jpow, int n_pow, const uint64_t s[4], uint64_t d, uint64_t total, double *out,
                        uint32_t ld, uint64_t seq_cols, bool transpose);
 void launch_transpose(Storage &st, const double *src, uint64_t rows, uint64_t cols, double *dst, uint32_t ldd);

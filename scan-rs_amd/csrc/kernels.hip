@@ -2174,6 +2174,23 @@ void launch_transpose(Storage &st, const double *src, uint64_t rows, uint64_t co
                        rows, cols, dst, ldd);
     SCANRS_HIP(hipGetLastError());
 }
+// columns [c0, c0 + nc) of a panel filled with a fixed pseudo-random function of (GLOBAL row, column): every rank of a sharded
+// panel produces its own rows of the same matrix without talking to anybody (splitmix64 of the pair, mapped to (-1, 1))
+__global__ void fill_hash_kernel(double *p, uint32_t ld, uint64_t rows, uint64_t row0, uint32_t c0, uint32_t nc, uint64_t seed) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= rows * nc) return;
+    const uint64_t r = e / nc;
+    const uint32_t c = (uint32_t)(e - r * nc);
+    uint64_t z = seed + (row0 + r) * 0x9E3779B97F4A7C15ull + (uint64_t)(c0 + c) * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    p[r * ld + c0 + c] = (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+}
+void launch_fill_hash(Storage &st, double *p, uint32_t ld, uint64_t rows, uint64_t row0, uint32_t c0, uint32_t nc, uint64_t seed) {
+    if (rows == 0 || nc == 0) return;
+    hipLaunchKernelGGL(fill_hash_kernel, grid1(rows * nc, 256), dim3(256), 0, st.stream, p, ld, rows, row0, c0, nc, seed);
+}
 void launch_fill_f64(Storage &st, double *p, uint64_t n, double v) {
     if (n == 0) return;
     hipLaunchKernelGGL(fill_kernel, grid1(n, 256), dim3(256), 0, st.stream, p, n, v);

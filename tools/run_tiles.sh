@@ -1,8 +1,8 @@
-for x in 1.45 1.7 2.0; do for mn in 0.35 0.7; do
-echo "== x $x min $mn heavy"; SCANRS_TRACE=1 python tools/pass_bench.py 1000000 100 0 gene_shape=0.1 shared_profile=1 opt.tile_split_x=$x opt.tile_split_min=$mn 2>&1 | grep -E "tile layout:|pass|count|fill" 
-done; done > gpurun_out/pb_sweep_heavy.log 2>&1
-for x in 1.45 1.7 2.0 2.4; do
-echo "== x $x std"; SCANRS_TRACE=1 python tools/pass_bench.py 1000000 100 0 opt.tile_split_x=$x 2>&1 | grep -E "tile layout:|pass|count|fill"
-done > gpurun_out/pb_sweep_std.log 2>&1
-echo "== split off std"; python tools/pass_bench.py 1000000 100 0 opt.tile_split=0 2>&1 | grep -E "pass" >> gpurun_out/pb_sweep_std.log
-cat gpurun_out/pb_sweep_heavy.log gpurun_out/pb_sweep_std.log | cut -c1-250
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "rank_deficient or dense_outer or heavy_tailed" > gpurun_out/gputest_g.log 2>&1; tail -25 gpurun_out/gputest_g.log | cut -c1-220
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench_c.json 2> gpurun_out/bench_c.err; python -c "
+import json
+d=json.load(open('gpurun_out/bench_c.json'))
+c=d['config']
+print(d['value'], d['ms_per_step'], c['first_call_s'], c['device_resident_ms_per_step'], c['fresh_result_arrays_ms_per_step'], c['resident_bytes_per_nonzero'], c['heavy_tailed_ms_per_step'])
+r=d['roofline']; print(r['avg_launch_ms'], r['frac'], r['traffic'], r['traffic_source'], r['onchip'], r['wasted_traffic_ratio'])
+"; tail -3 gpurun_out/bench_c.err
