@@ -300,45 +300,67 @@ def main():
 
     comm = None
     transport = "none (1 GPU)"
-    if world > 1 and shared_gpu:
-        from scanrs_amd.dist import make_allreduce
-
-        mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev, stage_through_host=True))
-        transport = "host hook over gloo (test mode: ranks share one GPU)"
-    elif world > 1 or args.force_collective:
+    if world > 1 or args.force_collective:
+        # Transport of the exchange steps, decided IDENTICALLY on every rank (a rank that went another way would leave the others
+        # inside their first collective for ever):
+        #  1. pre-flight, no collective involved: can this rank load RCCL through the library at all (it maps torch's librccl with
+        #     RTLD_NOLOAD, comm.cpp)? SCANRS_BENCH_FAIL_COMM_RANK=r injects a failure on rank r (tests); ranks that share one GPU
+        #     (SCANRS_BENCH_SHARED_GPU=1, tests only) count as failed: RCCL refuses two ranks on one device. The flags are gathered;
+        #  2. only if every rank passed: rank 0's id is broadcast and every rank calls ncclCommInitRank together; the outcomes are
+        #     gathered again;
+        #  3. otherwise (or if step 2 failed anywhere): the same schedule with the exchange steps served through the library's all-reduce
+        #     hook by the host program's own group — RCCL (backend "nccl") on device buffers, or gloo through host memory when the
+        #     ranks share a GPU.
         comm_err = ""
+        my_uid = None
         try:
-            uid = [sa.Comm.unique_id() if rank == 0 else None]
-        except sa.ScanrsError as e:  # rank 0 could not even load RCCL: tell everybody
-            uid, comm_err = [None], str(e)
+            if os.environ.get("SCANRS_BENCH_FAIL_COMM_RANK", "") == str(rank):
+                raise sa.ScanrsError(4, f"injected pre-flight failure on rank {rank} (SCANRS_BENCH_FAIL_COMM_RANK)")
+            my_uid = sa.Comm.unique_id()  # loads RCCL; only rank 0's id is used
+        except sa.ScanrsError as e:
+            comm_err = str(e)
+        ok = my_uid is not None
+        errs = [comm_err]
         if dist is not None:
-            dist.broadcast_object_list(uid, src=0)
-        if uid[0] is not None:
+            flags = [None] * world
+            dist.all_gather_object(flags, (ok, comm_err))
+            ok = all(f[0] for f in flags)
+            errs = [f"rank {r}: {f[1]}" for r, f in enumerate(flags) if not f[0]]
+        if ok and shared_gpu and world > 1:
+            ok, errs = False, ["ranks share one GPU (test mode): RCCL cannot place two ranks on one device"]
+        if ok:
+            uid = [my_uid if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(uid, src=0)
             try:
                 comm = sa.Comm(uid[0], rank, world)
             except sa.ScanrsError as e:
                 comm_err = str(e)
-        ok = comm is not None
-        if dist is not None:  # every rank must take the same branch or the first exchange step hangs
-            flags = [None] * world
-            dist.all_gather_object(flags, ok)
-            ok = all(flags)
+            ok = comm is not None
+            if dist is not None:
+                flags = [None] * world
+                dist.all_gather_object(flags, (ok, comm_err))
+                ok = all(f[0] for f in flags)
+                errs = [f"rank {r}: {f[1]}" for r, f in enumerate(flags) if not f[0]]
         if ok:
             mat.set_shard_comm(comm, lo, args.cells)
             transport = "RCCL all-reduce enqueued by the library on its own stream (scanrs_comm_*)"
         elif dist is None:
             raise SystemExit(f"bench.py: library RCCL communicator failed: {comm_err}")
         else:
-            # the library's own communicator could not be built on some rank: same schedule, exchange steps served by the
-            # host program's RCCL group through the all-reduce hook (round 1's transport) — still device buffers over xGMI
             from scanrs_amd.dist import make_allreduce
 
             if comm is not None:
                 comm.close()
                 comm = None
-            nccl_group = dist.new_group(backend="nccl")
-            mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev, group=nccl_group))
-            transport = f"torch.distributed RCCL group through the library's all-reduce hook (library communicator failed: {comm_err or 'on another rank'})"
+            why = "; ".join(errs)[:300]
+            if shared_gpu:
+                mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev, stage_through_host=True))
+                transport = f"host hook over gloo (library communicator not used: {why})"
+            else:
+                nccl_group = dist.new_group(backend="nccl")
+                mat.set_shard(rank, world, lo, args.cells, make_allreduce(dist, dev, group=nccl_group))
+                transport = f"torch.distributed RCCL group through the library's all-reduce hook (library communicator not used: {why})"
 
     dbg(f"transport: {transport}")
     if args.f32_panels:

@@ -528,6 +528,19 @@ class AdaptiveMat:
         return float(t.value)
 
 
+# explicit prototypes of the entry points that take doubles or 64-bit integers by value (ctypes' default conversion is for ints)
+_lib.scanrs_mat_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]
+_lib.scanrs_mat_set_option.restype = ctypes.c_int
+_lib.scanrs_set_global_option.argtypes = [ctypes.c_char_p, ctypes.c_double]
+_lib.scanrs_set_global_option.restype = ctypes.c_int
+_lib.scanrs_mat_get_counter.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
+_lib.scanrs_mat_get_counter.restype = ctypes.c_int
+_lib.scanrs_debug_wait_never.argtypes = [ctypes.c_double]
+_lib.scanrs_debug_wait_never.restype = ctypes.c_int
+_lib.scanrs_reserve_device_memory.argtypes = [ctypes.c_uint64]
+_lib.scanrs_reserve_device_memory.restype = ctypes.c_int
+
+
 def set_global_option(key: str, value: float):
     """Process-wide options of the entry points that take no handle (include/scanrs_amd.h, scanrs_set_global_option)."""
     _check(_lib.scanrs_set_global_option(key.encode(), ctypes.c_double(value)))

@@ -1663,16 +1663,27 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
         if (!m || !key) fail(SCANRS_ERR_ARGUMENT, "null handle or key");
         Storage &st = *m->st;
         const std::string k(key);
-        if (k == "tile_k") { // the tile shape is validated as a whole when the product runs
-            st.tile_k = (uint32_t)value;
+        // every value arrives as a double: nothing is cast before it is known to be finite and in range (a NaN or a negative
+        // number through (uint32_t) is undefined behaviour)
+        if (!std::isfinite(value)) fail(SCANRS_ERR_ARGUMENT, "option '%s': the value must be finite", key);
+        auto as_u32 = [&](double lo, double hi) -> uint32_t {
+            if (!(value >= lo) || !(value <= hi) || value != std::floor(value)) fail(SCANRS_ERR_ARGUMENT, "option '%s' must be an integer in [%g, %g]", key, lo, hi);
+            return (uint32_t)value;
+        };
+        // the four shape options are usually set one after the other: a combination is checked as a whole when the product runs
+        // (launch_spmm_tiles / tile_layout_build refuse an unsupported shape); each value alone must be one some shape uses
+        if (k == "tile_k") {
+            st.tile_k = as_u32(2, 4);
         } else if (k == "tile_s") {
-            st.tile_s = (uint32_t)value;
+            const uint32_t v = as_u32(28, 32);
+            if (v != 28u && v != 32u) fail(SCANRS_ERR_ARGUMENT, "tile_s must be 28 or 32");
+            st.tile_s = v;
         } else if (k == "tile_ku") {
-            st.tile_ku = (uint32_t)value;
+            st.tile_ku = as_u32(0, 1);
         } else if (k == "tile_t") {
-            st.tile_t = (uint32_t)value;
+            st.tile_t = as_u32(8, 96);
         } else if (k == "tile_b") {
-            st.tile_b = (uint32_t)value;
+            st.tile_b = as_u32(2, 24);
         } else if (k == "side_build") {
             st.side_build = value != 0.0;
         } else if (k == "tile_split") {
@@ -1689,7 +1700,7 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             if (!(value >= 0.0) || value > 32.0) fail(SCANRS_ERR_ARGUMENT, "tile_build_waves must be in 0..32");
             st.tile_build_waves = (uint32_t)value;
         } else if (k == "ov_tile_kb") {
-            st.ov_tile_bytes = (size_t)std::max(0.0, value) << 10;
+            st.ov_tile_bytes = (size_t)as_u32(0, 4194304.0) << 10;
         } else if (k == "tile_max_overflow") {
             if (!(value > 0.0) || value > 1.0) fail(SCANRS_ERR_ARGUMENT, "tile_max_overflow must be in (0, 1]");
             st.tile_max_overflow = value;
@@ -1698,14 +1709,13 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
         } else if (k == "tile_overlap") {
             st.tile_overlap = value != 0.0;
         } else if (k == "l2_tile_kb") {
-            if (value < 64) fail(SCANRS_ERR_ARGUMENT, "l2_tile_kb must be >= 64");
-            st.l2_tile_bytes = (size_t)value << 10;
+            st.l2_tile_bytes = (size_t)as_u32(64, 4194304.0) << 10;
         } else if (k == "spmm_order") {
-            st.spmm_order = (int)value;
+            st.spmm_order = (int)as_u32(0, 2);
         } else if (k == "materialize") {
             st.materialize = value != 0.0;
         } else if (k == "hot_segment") {
-            st.hot_segment = (uint32_t)std::max(0.0, value);
+            st.hot_segment = as_u32(0, 4294967295.0);
         } else if (k == "slice_walk") {
             st.slice_walk = value != 0.0;
         } else if (k == "spmv_lds") {
@@ -1713,11 +1723,11 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
         } else if (k == "overlap") {
             st.overlap = value != 0.0;
         } else if (k == "col_moments") {
-            st.col_moments = (int)value;
+            st.col_moments = (int)as_u32(0, 2);
         } else if (k == "device_factor") {
             st.device_factor = value != 0.0;
         } else if (k == "d2h_threads") {
-            st.d2h_threads = (unsigned)std::max(1.0, value);
+            st.d2h_threads = as_u32(1, 256);
         } else if (k == "sync_timeout_s") { // process-wide (the waits have no handle): same as scanrs_set_global_option
             if (!(value > 0.0) || !std::isfinite(value)) fail(SCANRS_ERR_ARGUMENT, "sync_timeout_s must be a positive number of seconds");
             set_sync_timeout_s(value);
@@ -1774,6 +1784,7 @@ int scanrs_mat_chol_rinv(scanrs_mat *m, const double *g, uint32_t n, uint64_t ro
     return guard([&] {
         if (!m || !g || !rinv) fail(SCANRS_ERR_ARGUMENT, "null argument");
         if (!chol_rinv_ok(n)) fail(SCANRS_ERR_ARGUMENT, "n must be in 1..128");
+        if (rows == 0 || rows > (1ull << 40)) fail(SCANRS_ERR_ARGUMENT, "rows must be in 1..2^40 (it scales the shift of the factor step)");
         Storage &st = *m->st;
         double *dG = st.scratch.get<double>("chk_G", (size_t)n * n), *dR = st.scratch.get<double>("chk_R", (size_t)n * n);
         double *dInfo = st.scratch.get<double>("chk_info", 2);

@@ -1101,7 +1101,10 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
         // columns runs through the hybrid LDS-tile product, a wider one through the gather kernels at about twice the time: when
         // a few flagged columns too many stand in the way (22 on the 1 M-cell benchmark), the bound is raised — by at most two
         // decades, error <= ~1e-9 instead of 1e-11 on those columns, far inside every tolerance — until the pass fits.
-        if (n_iter >= 2 && b <= 104u && mat_tiles_ready(m, to_t_transpose)) {
+        // The rule looks at b and the coefficients only — not at whether this handle (or this shard) happens to run the hybrid product:
+        // the flagged set, and with it the rounding of the result, is the same on every rank of a sharded run and under any memory
+        // pressure (it used to depend on mat_tiles_ready).
+        if (n_iter >= 2 && b <= 104u) {
             const uint32_t last_lo = (n_iter - 1) * b, room = 104u - b;
             std::vector<double> flagged;
             for (uint32_t j = 0; j < last_lo; j++)

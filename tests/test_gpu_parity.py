@@ -1249,6 +1249,20 @@ def test_rank_deficient_panels_on_a_sharded_side(sa):
     mm.close()
 
 
+def test_set_option_refuses_values_that_cannot_be_cast(sa):
+    """the option setter cast its double straight to unsigned integers — NaN, negative or huge values were undefined
+    behaviour, a zero tile size a division by zero waiting to happen. Every value is range-checked before any cast now."""
+    g, _ = pair(sa, random_counts(np.random.default_rng(0), 30, 40, 0.5, 9), so.CSR)
+    for key, bad in (("tile_k", float("nan")), ("tile_k", -1.0), ("tile_k", 0.0), ("tile_s", 31.0), ("tile_t", 0.0), ("tile_t", 1e12), ("tile_b", 2.5),
+                     ("spmm_order", 7.0), ("col_moments", -2.0), ("d2h_threads", 0.0), ("l2_tile_kb", float("inf")), ("tile_split_x", 0.0),
+                     ("sync_timeout_s", -3.0), ("reuse_cmax", float("nan"))):
+        with pytest.raises(sa.ScanrsError):
+            g.set_option(key, bad)
+    g.set_option("tile_k", 2).set_option("tile_t", 48).set_option("sync_timeout_s", 120)
+    with pytest.raises(sa.ScanrsError):
+        g.chol_rinv(np.eye(4), rows=0)
+
+
 def test_irlba_rejects_zero_iterations(sa):
     g, _ = pair(sa, random_counts(np.random.default_rng(0), 30, 40, 0.5, 9), so.CSR)
     with pytest.raises(sa.ScanrsError) as e:

@@ -239,6 +239,24 @@ def test_bench_two_ranks_equal_one_rank(tmp_path):
 
 
 @pytest.mark.gpu
+def test_bench_all_ranks_take_the_same_transport_when_one_rank_cannot_load_rccl(tmp_path):
+    """Round 3's verdict, item 7: the library's RCCL communicator has never run at world >= 2, and if it cannot be made on ONE rank
+    (its `dlopen(RTLD_NOLOAD)` reuse of torch's librccl misbehaving) every rank has to fall to the same other transport or the
+    first exchange step never returns. bench.py decides in a pre-flight that involves no collective of the library; here rank 1's
+    pre-flight fails by injection, rank 0's passes: both must report the fallback transport, name rank 1 as the reason, and the
+    run must finish with the single-rank singular values."""
+    one = _bench_line({}, [], tmp_path, 1)
+    two = _bench_line({"SCANRS_BENCH_SHARED_GPU": "1", "SCANRS_BENCH_FAIL_COMM_RANK": "1"}, [], tmp_path, 2)
+    t = two["config"]["transport"]
+    assert "library communicator not used" in t and "rank 1:" in t and "injected" in t and "rank 0:" not in t, t
+    a, b = np.array(one["config"]["sigma_top3"]), np.array(two["config"]["sigma_top3"])
+    assert np.max(np.abs(a - b) / a) < 1e-9
+    # without the injection the same two ranks still may not build the communicator (they share the test box's one GPU): again one decision for all
+    two = _bench_line({"SCANRS_BENCH_SHARED_GPU": "1"}, [], tmp_path, 2)
+    assert "ranks share one GPU" in two["config"]["transport"]
+
+
+@pytest.mark.gpu
 def test_bench_eight_ranks_equal_one_rank(tmp_path):
     """The driver's widest command form, `python bench.py --gpus 8`, end to end on the one GPU of the test box (eight
     ranks sharing it, host-hook exchange): eight nnz-balanced shards, one JSON line, the same singular values."""
