@@ -29,7 +29,8 @@ def classify(name, grid):
         return "spmm_gather2d_ov/long-outer" if grid > 2_500_000 else "spmm_gather2d_ov/short-outer"
     if "spmm_gather2d_kernel" in name:
         return "spmm_gather2d_kernel<1>/long-outer" if grid > 10_000_000 else "spmm_gather2d_kernel<1>/short-outer"
-    for k in ("col_moments_kernel", "tile_weights_kernel", "tile_ratio_table_kernel", "chol_rinv_kernel", "tile_scale_panel_kernel", "tile_finish_kernel", "tile_assign_kernel", "gram_tiled_kernel", "gemm_tiled_kernel", "slice_walk_kernel<1>", "slice_walk_kernel<0>", "row_reduce2d_kernel<2>", "row_reduce_kernel<2>", "row_reduce_kernel<0>",
+    for k in ("col_moments_kernel", "tile_weights_kernel", "tile_ratio_table_kernel", "chol_rinv_kernel", "tile_scale_panel_kernel", "tile_finish_kernel", "tile_assign_wave_kernel", "tile_assign_kernel",
+              "tile_slotless_kernel", "validate_stream_kernel", "pack_key_kernel", "unpack_key_kernel", "gram_tiled_kernel", "gemm_tiled_kernel", "slice_walk_kernel<1>", "slice_walk_kernel<0>", "row_reduce2d_kernel<2>", "row_reduce_kernel<2>", "row_reduce_kernel<0>",
               "weighted_colsum_partial_kernel", "spmv2d_kernel", "spmv_lds_kernel", "gram_kernel", "gemm_nn_kernel"):
         if k in name:
             return k
@@ -66,8 +67,8 @@ def main():
         with open(rel, "rb") as f:
             hsrc.update(f.read())
     src_hash = hsrc.hexdigest()[:16]
-    if commit == "working tree" or not commit:
-        commit = os.environ.get("SCANRS_COMMIT", "working tree")
+    if os.environ.get("SCANRS_COMMIT"):
+        commit = os.environ["SCANRS_COMMIT"]
     # ---- HBM traffic ---------------------------------------------------------------------------------------------------
     tr = {}
     for cname, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
@@ -83,7 +84,7 @@ def main():
             v["hbm_bytes_per_launch_corrected"] = 2 * f + w
     json.dump({
         "_how": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --kernel-trace --output-format csv -- python3 bench.py "
-                "--steps 1 --warmup 1 --no-cpu-baseline --no-host-delivery ; 1M x 33k, 3% nnz, k=50, MI355X. Counter unit KB; each run holds 3 PCAs "
+                "--steps 1 --warmup 1 --no-cpu-baseline --no-host-delivery --no-heavy-tailed ; 1M x 33k, 3% nnz, k=50, MI355X. Counter unit KB; each run holds 3 PCAs "
                 "(first pass, timed step, event-recording step). 'corrected' doubles FETCH_SIZE as MI355X_MICROARCH.md section HBM "
                 "prescribes for 16-B-per-lane coalesced reads (uncalibrated for the gather pattern: an upper estimate).",
         "commit": commit, "kernel_source_sha256_16": src_hash, "kernels": tr}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)

@@ -1,15 +1,16 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): kernel trace + the PMC passes of the headline bench command, raw output under
 # gpurun_out/prof_$1/, then profiles/summarize.py turns it into the committed summaries profiles/$1_*.
-#   usage: tools/profile_round.sh TAG      (e.g. r02a)
+#   usage: tools/profile_round.sh TAG COMMIT     (e.g. r04a $(git rev-parse --short HEAD))
 # Counters go in their own runs (rocprofv3 --pmc with --kernel-trace only), the program directly after `--`.
 set -u
-TAG=${1:-r03f}
+TAG=${1:-r04a}
+export SCANRS_COMMIT=${2:-"working tree"}   # the build container passes $(git rev-parse --short HEAD): the GPU box has no .git
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-host-delivery"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-delivery > $OUT/stats.json 2> $OUT/stats.err
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-host-delivery --no-heavy-tailed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-delivery --no-heavy-tailed > $OUT/stats.json 2> $OUT/stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/write.json 2> $OUT/write.err
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --kernel-trace --output-format csv -d $OUT/tcc -- python3 bench.py $ARGS > $OUT/tcc.json 2> $OUT/tcc.err
