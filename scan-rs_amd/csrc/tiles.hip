@@ -36,7 +36,10 @@ namespace scanrs {
 
 namespace {
 
-constexpr uint32_t TL_NW = 8;          // waves per workgroup (2 per SIMD)
+#ifndef TL_NW_DEF
+#define TL_NW_DEF 8
+#endif
+constexpr uint32_t TL_NW = TL_NW_DEF;  // waves per workgroup (8: 2 per SIMD; 12 with the 168-register kernel: 3 per SIMD, an experiment)
 constexpr uint32_t TL_LMAX = 104;      // widest panel: 192 ring rows x 104 x 8 B = 159744 B of LDS
 constexpr uint32_t TL_LDS = 160u << 10;
 constexpr int TL_W = 6;                // LDS row reads in flight per wave
