@@ -348,7 +348,7 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *                       a solver iteration needs — the transposed copy of the matrix and that orientation's tile layout — beside the
  *                       normalisation passes and the first product; 0: built on demand by the calling thread
  *   "tile_builder" (1)  1: wave-level builder of the tile layout (default tile shape); 0: per-thread walk (reference form)
- *   "tile_build_waves" (16)  waves per CU of that builder (0: as many as fit)
+ *   "tile_build_waves" (0)   cap on the waves per CU of that builder (0: as many as fit)
  *   "sync_timeout_s" (120)  PROCESS-WIDE (same as scanrs_set_global_option): deadline of every host-side wait for the device
  * Unknown keys return SCANRS_ERR_ARGUMENT. The only environment variables the library reads are the diagnostics
  * SCANRS_TRACE and SCANRS_TRACE_EIG (phase timings on stderr). */

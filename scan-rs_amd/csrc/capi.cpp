@@ -733,6 +733,13 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
     cp.n_inner = storage == SCANRS_CSR ? cols : rows;
     const hipMemcpyKind kind = device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     CurrentHandle cur(st.get());
+    auto lap = [&, t_prev = std::chrono::steady_clock::now()](const char *what) mutable { // SCANRS_TRACE=1: the phases of a creation (each forces a sync)
+        if (!trace_on()) return;
+        (void)wait_stream_quiet(st->stream);
+        const auto t_now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[scanrs trace]   create: %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t_now - t_prev).count());
+        t_prev = t_now;
+    };
     cp.indptr.alloc(cp.n_outer + 1);
     // a device-resident input was produced on the caller's streams: the blocking stream of the handle is ordered behind the legacy
     // null stream (torch's default stream), anything else is the caller's to synchronise before the call
@@ -751,12 +758,15 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
         SCANRS_HIP(hipMemcpyAsync(cp.values.p, values, cp.nnz * 4, kind, st->stream));
         if (!device_src) SCANRS_SYNC(st->stream); // the caller's host arrays may be pageable and are his again on return
     }
+    lap("copies");
     if (sort_first) sort_outer_vectors(*st, cp);
     uint64_t zeros = 0, bad = 0;
     validate_copy(*st, cp, &zeros, &bad);
+    lap("validation");
     if (bad) fail(SCANRS_ERR_ARGUMENT, "indices must be in range and strictly ascending within each outer vector (%llu violations)", (unsigned long long)bad);
     if (zeros) compact_nonzeros(*st, cp);
     cp.build_items(st->stream);
+    lap("work items");
     device_free_flush(); // the stream is idle here
     auto *m = new scanrs_mat();
     m->st = st;

@@ -298,7 +298,7 @@ struct Storage {
     double tile_split_x = 1.8;            // ... nonzeros per panel tile a slot is sized for
     double tile_split_min = 0.5;          // ... vectors below this many nonzeros per tile get no slot
     int tile_builder = 1;                 // layout builder: 1 = wave-level (a lane per vector, visits in lock-step, rows written whole; default shape only), 0 = per-thread walk
-    uint32_t tile_build_waves = 16;       // ... its waves per CU (0: whatever fits)
+    uint32_t tile_build_waves = 0;        // ... its waves per CU through a dummy LDS allocation (0: no cap — measured the same at 8, 16, 32 and without; and a builder that asks for LDS cannot run beside the persistent tile kernel of a first pass)
     size_t ov_tile_bytes = 0;             // hybrid product: panel slice per step of the overflow gather (0 = twice l2_tile_bytes)
     double tile_max_overflow = 0.35;      // auto path: an orientation whose layout would leave more than this share of the nonzeros to the overflow gather stays on the gather kernels
     int tile_auto = 1;                    // auto path may use the hybrid product (0: only spmm_path 3 does)

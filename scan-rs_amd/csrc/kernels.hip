@@ -1378,30 +1378,48 @@ __global__ __launch_bounds__(256) void validate_stream_kernel(const uint32_t *__
             if (p > 0) bad += i[k] <= (k ? i[k - 1] : prev);
         }
     }
-    // wave sums, one atomic per wave
+    // wave sums, then one set of atomics per WORKGROUP of a grid of a few thousand (every wave of a 65 536-block grid adding to the
+    // same four words was 13 of the pass's 18 ms: same-address atomics are served one after the other)
     for (int off = 32; off > 0; off >>= 1) {
         zeros += __shfl_down(zeros, off);
         bad += __shfl_down(bad, off);
         const uint32_t o = __shfl_down(vmax, off);
         vmax = o > vmax ? o : vmax;
     }
+    __shared__ unsigned long long sz[4], sb[4];
+    __shared__ uint32_t sm[4];
+    const uint32_t w = threadIdx.x >> 6;
     if ((threadIdx.x & 63u) == 0) {
-        if (zeros) atomicAdd(&counters[0], zeros);
-        if (bad) atomicAdd(&counters[1], bad);
-        atomicMax(&counters[3], (unsigned long long)vmax); // the largest count: bounds the mapped values (col_moments_kernel) and sizes the transposed copy's sort key
+        sz[w] = zeros;
+        sb[w] = bad;
+        sm[w] = vmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long z = sz[0] + sz[1] + sz[2] + sz[3], b = sb[0] + sb[1] + sb[2] + sb[3];
+        const uint32_t m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+        if (z) atomicAdd(&counters[0], z);
+        if (b) atomicAdd(&counters[1], b);
+        atomicMax(&counters[3], (unsigned long long)m); // the largest count: bounds the mapped values (col_moments_kernel) and sizes the transposed copy's sort key
     }
 }
 __global__ void validate_starts_kernel(const uint64_t *__restrict__ indptr, uint64_t n_outer, const uint32_t *__restrict__ indices, uint64_t nnz,
                                        unsigned long long *__restrict__ counters) {
     const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= n_outer) return;
-    const uint64_t a = indptr[o], b = indptr[o + 1];
-    if (b < a || b > nnz) {
-        atomicAdd(&counters[1], 1ull);
-        return;
+    bool broken = false, start_descent = false;
+    if (o < n_outer) {
+        const uint64_t a = indptr[o], b = indptr[o + 1];
+        broken = b < a || b > nnz;
+        // the first nonzero of a non-empty vector that follows another nonzero: a descent there was counted by the streaming pass
+        start_descent = !broken && b > a && a > 0 && indices[a] <= indices[a - 1];
     }
-    // the first nonzero of a non-empty vector that follows another nonzero: a descent there was counted by the streaming pass
-    if (b > a && a > 0 && indices[a] <= indices[a - 1]) atomicAdd(&counters[2], 1ull);
+    // nearly EVERY vector start is such a descent (a cell's first gene lies below the previous cell's last one): one atomic per wave,
+    // not per vector (10^6 adds to one word took 10 ms)
+    const unsigned long long nb = __popcll(__builtin_amdgcn_ballot_w64(broken)), nd = __popcll(__builtin_amdgcn_ballot_w64(start_descent));
+    if ((threadIdx.x & 63u) == 0) {
+        if (nb) atomicAdd(&counters[1], nb);
+        if (nd) atomicAdd(&counters[2], nd);
+    }
 }
 
 // =============================================================================================
@@ -2582,7 +2600,10 @@ void validate_copy(Storage &st, SparseCopy &cp, uint64_t *zeros, uint64_t *bad) 
     }
     if (cp.nnz) {
         const uint64_t n4 = (cp.nnz + 3) / 4;
-        const unsigned blocks = (unsigned)std::min<uint64_t>((n4 + 255) / 256, 1u << 16);
+        int dev = 0, n_cu = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        const unsigned blocks = (unsigned)std::min<uint64_t>((n4 + 255) / 256, (uint64_t)n_cu * 16u);
         hipLaunchKernelGGL(validate_stream_kernel, dim3(blocks), dim3(256), 0, st.stream, cp.indices.p, cp.values.p, cp.nnz, cp.n_inner, c.p);
     }
     unsigned long long h[4];

@@ -1263,6 +1263,52 @@ def test_set_option_refuses_values_that_cannot_be_cast(sa):
         g.chol_rinv(np.eye(4), rows=0)
 
 
+def test_device_memory_cache_reserve_and_accounting(sa):
+    """Round 4's allocator (include/scanrs_amd.h: "device_cache_fraction", scanrs_reserve_device_memory): released blocks of 1 MB and
+    more wait in a cache for the next allocation of about their size, a reserve made ahead of time serves the large buffers of a
+    handle, and the library's own count of its live buffers is what bench.py reports as resident bytes."""
+    import gc
+
+    gc.collect()
+    sa.release_cached_memory()
+    base = sa.device_memory_in_use()
+    m = _synth(60_000, 3000, 0.05, 2)  # 9 M nonzeros: 36 MB per array
+    mk = lambda: sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+    g = mk()
+    held = sa.device_memory_in_use() - base
+    assert held >= 2 * 4 * m.nnz  # indices + counts at least
+    x = np.ones((m.shape[0], 4))
+    ref = g.dot(x)
+    del g
+    gc.collect()
+    assert sa.device_memory_in_use() == base
+    cached = sa.cached_memory_bytes()
+    assert cached >= 2 * 4 * m.nnz  # the two big arrays wait for reuse
+    g = mk()  # same sizes: served from the cache
+    assert sa.cached_memory_bytes() < cached
+    assert np.array_equal(g.dot(x), ref)
+    del g
+    gc.collect()
+    sa.release_cached_memory()
+    assert sa.cached_memory_bytes() == 0
+    # a reserve: the handle's large buffers are carved from it, and it goes back whole once nothing of it is in use
+    sa.reserve_device_memory(256 << 20)
+    g = mk()
+    assert np.array_equal(g.dot(x), ref)
+    sa.release_cached_memory()  # the reserve is in use: it stays
+    assert np.array_equal(g.dot(x), ref)
+    del g
+    gc.collect()
+    sa.release_cached_memory()
+    assert sa.cached_memory_bytes() == 0 and sa.device_memory_in_use() == base
+    sa.set_global_option("device_cache_fraction", 0.0)  # no cache: released blocks go straight back
+    g = mk()
+    del g
+    gc.collect()
+    assert sa.cached_memory_bytes() == 0
+    sa.set_global_option("device_cache_fraction", 0.5)
+
+
 def test_irlba_rejects_zero_iterations(sa):
     g, _ = pair(sa, random_counts(np.random.default_rng(0), 30, 40, 0.5, 9), so.CSR)
     with pytest.raises(sa.ScanrsError) as e:
