@@ -1694,6 +1694,8 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.tile_t = as_u32(8, 96);
         } else if (k == "tile_b") {
             st.tile_b = as_u32(2, 24);
+        } else if (k == "dense_side_no_lds") {
+            st.dense_side_no_lds = value != 0.0;
         } else if (k == "side_build") {
             st.side_build = value != 0.0;
         } else if (k == "tile_split") {

@@ -311,6 +311,7 @@ struct Storage {
     uint64_t blocked_min_nnz = 1ull << 22; // auto: matrices below this stay on the plain gather kernel
     int slice_walk = 1;                   // Ix1 products / moments on the short-outer copy stage the inner-indexed arrays in LDS slices
     int spmv_lds = 1;                     // Ix1 products on the long-outer copy stage the vector in LDS parts
+    int dense_side_no_lds = 0;            // dense kernels queued on the side streams use the register-only MFMA forms (they can run BESIDE the persistent tile kernel, which holds the LDS)
     int overlap = 1;                      // small dense work of the solvers on a second stream beside the sparse passes
     const int *skip_flag = nullptr;       // device flag the dense kernels launched now test first (nonzero: return at once) — set around the queued passes of a device-side orthonormalisation
     uint64_t orth_fallbacks = 0;          // orthonormalisations that ended in the host Gram-Schmidt for rank-deficient panels (solver.cpp)

@@ -2117,7 +2117,10 @@ void launch_weighted_colsum(Storage &st, const double *B, uint32_t rank, const d
 void launch_gram(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *Y, uint32_t ldy, uint32_t m,
                  uint64_t rows, double *C) {
     if (n == 0 || m == 0) return;
-    if (gram_tiled_ok(n, m, rows) && !(ldx & 1u) && !(ldy & 1u)) {
+    // work queued on a side stream runs beside the persistent tile kernel of a sparse pass, which holds all of every CU's LDS: a
+    // kernel that needs LDS waits for the end of the pass; the register-only MFMA kernels below fit the registers the tile kernel leaves
+    const bool side = st.dense_side_no_lds && ((st.aux_stream && st.stream == st.aux_stream) || (st.aux2_stream && st.stream == st.aux2_stream));
+    if (!side && gram_tiled_ok(n, m, rows) && !(ldx & 1u) && !(ldy & 1u)) {
         launch_gram_tiled(st, X, ldx, n, Y, ldy, m, rows, C);
         return;
     }
@@ -2146,7 +2149,8 @@ void launch_gemm_nn(Storage &st, const double *X, uint32_t ldx, uint32_t n, cons
                     uint32_t ldo) {
     if (rows == 0 || m == 0) return;
     if (ldx & 1u) fail(SCANRS_ERR_ARGUMENT, "gemm: ldx must be even");
-    if (gemm_tiled_ok(n, m, rows)) {
+    const bool side = st.dense_side_no_lds && ((st.aux_stream && st.stream == st.aux_stream) || (st.aux2_stream && st.stream == st.aux2_stream));
+    if (!side && gemm_tiled_ok(n, m, rows)) {
         launch_gemm_tiled(st, X, ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
         return;
     }
