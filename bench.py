@@ -30,7 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-LDS_PEAK_TBS = 78.6    # 256 CUs x 128 B/clk x 2.4 GHz: the on-chip ceiling the tile kernel's row reads run against
+LDS_PEAK_TBS = 150.0   # MI355X_MICROARCH.md, LDS: ds_read_b128 = 256 B/clk/CU, "aggregate with every CU streaming (~2.4 GHz): ~150 TB/s"
+LDS_SURVEY_TBS = 78.6  # SURVEY.md §8d's estimate (128 B/clk/CU x 256 CUs x 2.4 GHz), kept beside it
 PMC_PROFILE = "r04a_pmc_traffic.json"  # committed PMC passes (separate --pmc runs) the `traffic` field is read from
 KERNEL_SOURCES = ("scan-rs_amd/csrc/tiles.hip", "scan-rs_amd/csrc/kernels.hip", "scan-rs_amd/csrc/device_map.hpp")
 
@@ -377,6 +378,8 @@ def main():
     # that keeps its result buffers; config.fresh_result_arrays_ms_per_step is the step with new arrays per call (page faults of
     # 413 MB of untouched pages + their munmap, the Python wrapper's default)
     out_u, out_v = np.zeros((args.genes, args.k)), np.zeros((n_local, args.k))
+    out_u.fill(0.0)  # touched once here (np.zeros hands out untouched pages): the caller's buffers exist before the timed steps
+    out_v.fill(0.0)
 
     def step(download=False, fresh=False):
         mat.reset_map()
@@ -619,6 +622,7 @@ def main():
                 "achieved": round(lds_per_launch / avg_s / 1e12, 2) if avg_s > 0 and lds_per_launch else None,
                 "peak": LDS_PEAK_TBS,
                 "frac": round(lds_per_launch / avg_s / 1e12 / LDS_PEAK_TBS, 4) if avg_s > 0 and lds_per_launch else None,
+                "frac_of_survey_estimate_78.6": round(lds_per_launch / avg_s / 1e12 / LDS_SURVEY_TBS, 4) if avg_s > 0 and lds_per_launch else None,
             },
             "kernel_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
             "launches_per_step_all": {k: round(v["launches"] / args.steps, 1) for k, v in sorted(prof.items())},
