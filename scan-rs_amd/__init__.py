@@ -278,7 +278,7 @@ class AdaptiveMat:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h is not None and h.value:
+        if h is not None and h.value and _lib is not None:  # (at interpreter shutdown the module globals may be gone already)
             _lib.scanrs_mat_free(h)
             self._h = ctypes.c_void_p()
 
