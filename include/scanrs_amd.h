@@ -347,6 +347,16 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *   "side_build" (1)    scanrs_normalize and the solvers start a helper thread (own stream) that builds what the SECOND product of
  *                       a solver iteration needs — the transposed copy of the matrix and that orientation's tile layout — beside the
  *                       normalisation passes and the first product; 0: built on demand by the calling thread
+ *   "tile_split" (1)    tile layout (default tile shape): an outer vector owns as many SLOTS (units of tile_k record positions per visit)
+ *                       as its density asks for: V = round(x / tile_split_x), at least 1, at most 32, x = its expected nonzeros per
+ *                       panel tile; its nonzeros are dealt to its slots round-robin; below tile_split_min it owns none and all of it
+ *                       goes to the overflow part. Makes the layout fit real count matrices (a few thousand genes detected in most
+ *                       cells, most genes in almost none). 0: one slot per vector
+ *   "tile_split_x" (1.8), "tile_split_min" (0.5)   the two densities of that rule, in nonzeros per tile
+ *   "tile_weights_wide" (1)  the weight refresh of a unit-mode layout works four positions per thread with wide loads and stores
+ *                       (0: one position per thread; same values)
+ *   "dense_side_no_lds" (0)  experiment: dense kernels queued on the side streams use the register-only MFMA forms, which can run
+ *                       beside the persistent tile kernel (measured slower: DESIGN.md section 9)
  *   "tile_builder" (1)  1: wave-level builder of the tile layout (default tile shape); 0: per-thread walk (reference form)
  *   "tile_build_waves" (0)   cap on the waves per CU of that builder (0: as many as fit)
  *   "sync_timeout_s" (120)  PROCESS-WIDE (same as scanrs_set_global_option): deadline of every host-side wait for the device

@@ -96,12 +96,28 @@ static hipError_t poll_until(Q &&query, double timeout_s, double *waited_s) {
             std::this_thread::sleep_for(std::chrono::microseconds(el < 5e-3 ? 20 : 200));
     }
 }
+// "auto scanrs_mat_sync(scanrs_mat *)::(anonymous class)::operator()() const" -> "scanrs_mat_sync": most waits sit inside the lambda
+// an entry point hands to guard(), whose own __func__ is "operator()"
+static std::string short_func(const char *pretty) {
+    std::string s(pretty ? pretty : "?");
+    for (const char *cut : {"::(anonymous class)", "::<lambda", "::(lambda"}) {
+        const size_t at = s.find(cut);
+        if (at != std::string::npos) s.resize(at);
+    }
+    const size_t paren = s.find('(');
+    if (paren != std::string::npos) s.resize(paren);
+    const size_t sp = s.rfind(' ');
+    if (sp != std::string::npos) s = s.substr(sp + 1);
+    return s.empty() ? std::string("?") : s;
+}
 static const char *base_name(const char *file) {
     const char *b = strrchr(file, '/');
     return b ? b + 1 : file;
 }
 // message + stderr dump of a wait that ran into its deadline; `busy` = query of one named stream (may be null on the CPU test path)
-static void timeout_report(const char *kind, const char *func, const char *file, int line, double waited, hipStream_t waited_stream) {
+static void timeout_report(const char *kind, const char *pretty_func, const char *file, int line, double waited, hipStream_t waited_stream) {
+    const std::string fn = short_func(pretty_func);
+    const char *func = fn.c_str();
     char where[160] = "";
     if (tl_handle) { // which of the handle's streams still have work (hipStreamQuery never blocks)
         const Storage &st = *tl_handle;
@@ -149,14 +165,14 @@ void wait_stream(hipStream_t s, const char *func, const char *file, int line) {
     const hipError_t e = poll_until([&] { return hipStreamQuery(s); }, sync_timeout_s(), &waited);
     if (e == hipSuccess) return;
     if (e == hipErrorNotReady) timeout_report("stream synchronisation", func, file, line, waited, s);
-    fail(SCANRS_ERR_DEVICE, "stream synchronisation failed: %s in %s (%s:%d)", hipGetErrorString(e), func, base_name(file), line);
+    fail(SCANRS_ERR_DEVICE, "stream synchronisation failed: %s in %s (%s:%d)", hipGetErrorString(e), short_func(func).c_str(), base_name(file), line);
 }
 void wait_event(hipEvent_t ev, const char *func, const char *file, int line) {
     double waited = 0.0;
     const hipError_t e = poll_until([&] { return hipEventQuery(ev); }, sync_timeout_s(), &waited);
     if (e == hipSuccess) return;
     if (e == hipErrorNotReady) timeout_report("event wait", func, file, line, waited, nullptr);
-    fail(SCANRS_ERR_DEVICE, "event wait failed: %s in %s (%s:%d)", hipGetErrorString(e), func, base_name(file), line);
+    fail(SCANRS_ERR_DEVICE, "event wait failed: %s in %s (%s:%d)", hipGetErrorString(e), short_func(func).c_str(), base_name(file), line);
 }
 void wait_device(const char *func, const char *file, int line) {
     // the null stream of a process is ordered behind every blocking stream: querying it covers "everything queued so far"
@@ -1034,7 +1050,7 @@ int scanrs_mat_create_adaptive(uint64_t rows, uint64_t cols, int storage, const 
         DevBuf<uint64_t> ip;
         DevBuf<uint32_t> ix, vv;
         decode_adaptive_vectors(vecs, n_vecs, n_inner, ip, ix, vv);
-        ::scanrs::wait_device(__func__, __FILE__, __LINE__);
+        ::scanrs::wait_device(__PRETTY_FUNCTION__, __FILE__, __LINE__);
         create_common(rows, cols, storage, ip.p, ix.p, vv.p, true, out); // validates ordering, copies into the handle
     });
 }
@@ -1706,6 +1722,8 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
         } else if (k == "tile_split_min") {
             if (!(value >= 0.0) || value > 16.0) fail(SCANRS_ERR_ARGUMENT, "tile_split_min must be in [0, 16]");
             st.tile_split_min = value;
+        } else if (k == "tile_weights_wide") {
+            st.tile_weights_wide = value != 0.0;
         } else if (k == "tile_builder") {
             st.tile_builder = value != 0.0;
         } else if (k == "tile_build_waves") {

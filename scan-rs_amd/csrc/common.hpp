@@ -56,8 +56,8 @@ struct CurrentHandle {
     explicit CurrentHandle(const Storage *st);
     ~CurrentHandle();
 };
-#define SCANRS_SYNC(stream) ::scanrs::wait_stream((stream), __func__, __FILE__, __LINE__)
-#define SCANRS_SYNC_EVENT(ev) ::scanrs::wait_event((ev), __func__, __FILE__, __LINE__)
+#define SCANRS_SYNC(stream) ::scanrs::wait_stream((stream), __PRETTY_FUNCTION__, __FILE__, __LINE__)
+#define SCANRS_SYNC_EVENT(ev) ::scanrs::wait_event((ev), __PRETTY_FUNCTION__, __FILE__, __LINE__)
 struct Tick {
     const char *what;
     std::chrono::steady_clock::time_point t0;
@@ -297,6 +297,7 @@ struct Storage {
     int tile_split = 1;                   // tile layout: slots per outer vector from its density (several for dense vectors, none — all overflow — for very sparse ones); 0: one slot per vector
     double tile_split_x = 1.8;            // ... nonzeros per panel tile a slot is sized for
     double tile_split_min = 0.5;          // ... vectors below this many nonzeros per tile get no slot
+    int tile_weights_wide = 1;            // weight refresh of a unit-mode layout: four positions per thread with wide loads / stores (0: one position per thread)
     int tile_builder = 1;                 // layout builder: 1 = wave-level (a lane per vector, visits in lock-step, rows written whole; default shape only), 0 = per-thread walk
     uint32_t tile_build_waves = 0;        // ... its waves per CU through a dummy LDS allocation (0: no cap — measured the same at 8, 16, 32 and without; and a builder that asks for LDS cannot run beside the persistent tile kernel of a first pass)
     size_t ov_tile_bytes = 0;             // hybrid product: panel slice per step of the overflow gather (0 = twice l2_tile_bytes)

@@ -549,6 +549,79 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t *__res
     }
 }
 
+// The same refresh for the usual case — unit mode on the default shape (K = 2, S = 32, B = 4: weights of the 32 general positions
+// of a record row only, quotient table present) — with wide accesses: a thread owns FOUR neighbouring general positions of a row
+// (one 4-byte load of their counts, one 8-byte load of their row codes, one 16-byte load of their slots' vectors, 32 bytes of
+// weights stored) and WU rows of them; the one-position-per-thread form above moved 1-2 bytes per lane and load. The order of the
+// rows is the same: linear for a table indexed by the outer vector, visit-major (grid.y = quad of visits) for one indexed by the
+// inner position.
+template <uint32_t T>
+__global__ __launch_bounds__(256) void tile_weights_unit_kernel(const uint16_t *__restrict__ prow, const uint8_t *__restrict__ pcnt,
+                                                                double *__restrict__ pw, uint64_t n_rows, const uint32_t *__restrict__ slot_vec,
+                                                                uint64_t n_slots, uint32_t nt, DevMap map, const double *__restrict__ uo,
+                                                                const double *__restrict__ vi, const double *__restrict__ tab, int tab_outer,
+                                                                uint32_t vmajor_groups) {
+    constexpr int WU = 4;
+    const double inv_nt = 1.0 / (double)nt;
+    const float inv_T = 1.0f / (float)T;
+    const uint64_t n_quads = (n_rows + WU - 1) / WU;
+    const uint64_t n_lin = (vmajor_groups ? (uint64_t)vmajor_groups : n_quads) * 8u; // 8 threads per row: 4 general lanes each
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lin; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t gq = i >> 3;
+        const uint32_t j4 = (uint32_t)(i & 7u) * 4u; // first of this thread's four general positions = slots j4 .. j4 + 3 of the group
+        const uint64_t row0 = vmajor_groups ? gq * nt + (uint64_t)blockIdx.y * WU : gq * WU;
+        const uint64_t row_end = vmajor_groups ? (gq + 1) * nt : n_rows;
+        uint32_t cnt4[WU];
+        uint2 code4[WU];
+        bool ok[WU];
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+            ok[u] = row0 + u < row_end;
+            const uint64_t e = ((ok[u] ? row0 + u : n_rows - 1) << 6) + 32u + j4;
+            cnt4[u] = ok[u] ? *reinterpret_cast<const uint32_t *>(pcnt + e) : 0u;
+            code4[u] = *reinterpret_cast<const uint2 *>(prow + e);
+        }
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+            if (!ok[u]) continue;
+            const uint32_t gv = (uint32_t)(row0 + u);
+            const uint32_t g = (uint32_t)(((double)gv + 0.5) * inv_nt), v = gv - g * nt;
+            const uint64_t gs = (uint64_t)g * 32u + j4;
+            uint32_t oo[4] = {0u, 0u, 0u, 0u};
+            if (gs + 3u < n_slots) {
+                const uint4 sv = *reinterpret_cast<const uint4 *>(slot_vec + gs);
+                oo[0] = sv.x;
+                oo[1] = sv.y;
+                oo[2] = sv.z;
+                oo[3] = sv.w;
+            } else {
+                for (uint32_t k = 0; k < 4u; k++) oo[k] = gs + k < n_slots ? slot_vec[gs + k] : 0u; // padding slots of the last group: unused positions only
+            }
+            const uint32_t codes[4] = {code4[u].x & 0xFFFFu, code4[u].x >> 16, code4[u].y & 0xFFFFu, code4[u].y >> 16};
+            double w[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t c = (cnt4[u] >> (8 * k)) & 0xFFu;
+                const uint32_t bufi = (uint32_t)(((float)codes[k] + 0.5f) * inv_T), r = codes[k] - bufi * T;
+                const uint32_t d = ((v & 3u) - bufi) & 3u; // visits the nonzero waited (ring of 4 buffers)
+                const uint32_t in = (v - d) * T + r;
+                double x = 0.0;
+                if (c != 0u && c <= TL_TABC) {
+                    x = tab[(size_t)(tab_outer ? oo[k] : in) * TL_TABC + (c - 1u)];
+                } else if (c != 0u) {
+                    x = eval_map(map, c, oo[k], in);
+                    const double d2 = uo[oo[k]] * vi[in];
+                    x = (d2 != 0.0 && isfinite(d2)) ? x / d2 : 0.0;
+                }
+                w[k] = x;
+            }
+            double *dst = pw + ((row0 + u) << 5) + j4;
+            *reinterpret_cast<d2 *>(dst) = (d2){w[0], w[1]};
+            *reinterpret_cast<d2 *>(dst + 2) = (d2){w[2], w[3]};
+        }
+    }
+}
+
 // The factor of the weight of a count-1 nonzero that depends on one side only (outer or inner position): the chain run on
 // x = 1 with the links of the other side left out; the side that owns the links in front of the nonlinear links also owns
 // those (nl_outer). uo[o] * vi[i] == f(1, o, i) up to rounding for the chains tile_map_separable() accepts.
@@ -927,6 +1000,14 @@ static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &c
         const bool vmajor = tl.unit_mode && !nl_outer && tl.sh.nset == 1u && vquads <= 65535u && tl.n_groups <= 0xFFFFFFFFull / 64u;
         dim3 grid((unsigned)std::min<uint64_t>((n_work + 255) / 256, 1u << 23));
         if (vmajor) grid = dim3((unsigned)((tl.n_groups * (64u - skip) + 255) / 256), vquads);
+        if (skip == 32u && st.tile_weights_wide && tl.sh.K == 2u && tl.sh.S == 32u && tl.sh.B == 4u && tl.sh.T == 48u && tl.sh.nset == 1u && (!vmajor || true)) {
+            // the wide form (four positions per thread): same rows in the same order
+            const uint64_t n_rows = n_rec >> 6;
+            const uint64_t lin = (vmajor ? tl.n_groups : (n_rows + 3) / 4) * 8u;
+            dim3 g2((unsigned)std::min<uint64_t>((lin + 255) / 256, 1u << 23), vmajor ? vquads : 1u);
+            hipLaunchKernelGGL((tile_weights_unit_kernel<48>), g2, dim3(256), 0, st.stream, tl.prow.p, tl.pcnt.p, tl.pw.p, n_rows, tl.slot_vec.p, tl.n_slots,
+                               tl.sh.nt, map, tl.uo.p, tl.vi.p, tl.ratio_tab.p, nl_outer, vmajor ? (uint32_t)tl.n_groups : 0u);
+        } else
         hipLaunchKernelGGL(tile_weights_kernel, grid, dim3(256), 0, st.stream, tl.prow.p, tl.pcnt.p, tl.pw.p, n_rec,
                            tl.slot_vec.p, tl.n_slots, tl.sh, map, tl.unit_mode ? tl.uo.p : (const double *)nullptr, tl.unit_mode ? tl.vi.p : (const double *)nullptr, skip,
                            tl.unit_mode ? tl.ratio_tab.p : (const double *)nullptr, nl_outer, vmajor ? (uint32_t)tl.n_groups : 0u);

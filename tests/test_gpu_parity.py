@@ -647,6 +647,26 @@ def test_wave_level_layout_builder_equals_the_per_thread_walk(sa, tile_ku):
             assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (rows, cols, fill, storage)
 
 
+def test_wide_weight_refresh_equals_the_one_position_form(sa):
+    """The weights of a unit-mode layout are refreshed four positions per thread with wide loads and stores (round 4); the values must
+    be the ones the one-position-per-thread kernel writes: products bit for bit, both table orientations (linear and visit-major
+    order), counts above the table's 8, padding slots of the last group, parts."""
+    rng = np.random.default_rng(92)
+    for rows, cols, fill, vmax in ((33, 97, 0.9, 3), (65, 4800, 0.6, 12), (257, 2000, 0.05, 400), (700, 1000, 0.03, 3), (97, 20000, 0.02, 30), (2000, 193, 0.2, 300)):
+        dense = random_counts(rng, rows, cols, fill, vmax)
+        dense[0, 0] = 1
+        for storage in (so.CSR, so.CSC):
+            outs = []
+            for wide in (0, 1):
+                g, _ = pair(sa, dense, storage)
+                g.set_spmm_path(3).set_option("tile_weights_wide", wide)
+                g.compose_scale_axis(1, np.linspace(0.5, 1.5, cols)).apply(sa.FN_LOG2_1P).compose_scale_axis(0, np.linspace(0.7, 1.3, rows))
+                q = np.cos(np.arange(cols * 40, dtype=np.float64)).reshape(cols, 40)
+                ql = np.sin(np.arange(rows * 24, dtype=np.float64)).reshape(24, rows)
+                outs.append((g.dot(q), g.rdot(ql)))
+            assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (rows, cols, fill, storage)
+
+
 def test_invalid_sparse_input_is_refused(sa):
     """create validates on the device in two streaming passes (round 4): indices ascending inside a vector — a descent at the first
     nonzero of a vector is fine — and in range, indptr not decreasing; the reference panics on such input (sprs structure checks)."""
@@ -1307,6 +1327,52 @@ def test_device_memory_cache_reserve_and_accounting(sa):
     gc.collect()
     assert sa.cached_memory_bytes() == 0
     sa.set_global_option("device_cache_fraction", 0.5)
+
+
+def test_helper_thread_build_gives_the_same_result(sa):
+    """`side_build`: the transposed copy and the second orientation's tile layout built by a helper thread beside normalize and the
+    first product, or on demand by the calling thread — the same layouts, so the same PCA bit for bit (at a size where the auto
+    path builds layouts)."""
+    m = _synth(70_000, 9000, 0.03, 12)  # 19 M nonzeros >= 2^24
+    assert m.nnz >= (1 << 24)
+    res = []
+    for side in (1, 0):
+        g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+        g.set_option("side_build", side)
+        sa.normalize(g, sa.Normalization.CellRanger)
+        res.append(sa.BkSvd().run_pca(g, 6))
+        assert g.counter("t_layout_us") > 0  # the tile path was taken
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
+def test_a_wait_that_runs_into_its_deadline_names_the_stream_and_the_stage(sa):
+    """The bounded waits on a real device: products are queued on device-resident panels (nothing on the host side is involved),
+    then the handle is synchronised with a deadline of 20 microseconds — the wait must give up with SCANRS_ERR_DEVICE and say where it
+    stood (function, file:line, which of the handle's streams were busy, the last stages). With the deadline restored the same handle
+    drains and still computes the same numbers."""
+    import torch
+
+    m = _synth(60_000, 3000, 0.05, 2)
+    g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+    dev = torch.device("cuda", 0)
+    x = torch.ones((m.shape[0], 96), device=dev, dtype=torch.float64)
+    out = torch.zeros((m.shape[1], 96), device=dev, dtype=torch.float64)
+    g.dot_device(False, x.data_ptr(), 96, 96, out.data_ptr(), 96)
+    g.sync()
+    ref = out.clone()
+    sa.set_global_option("sync_timeout_s", 2e-5)
+    try:
+        with pytest.raises(sa.ScanrsError) as ei:
+            for _ in range(30):  # ~100 ms of queued work behind a 20 us deadline
+                g.dot_device(False, x.data_ptr(), 96, 96, out.data_ptr(), 96)
+            g.sync()
+        msg = str(ei.value)
+        assert ei.value.code == 4 and "timed out" in msg and "streams:" in msg and "main=busy" in msg and "scanrs_mat_sync" in msg, msg
+    finally:
+        sa.set_global_option("sync_timeout_s", 120.0)
+    g.sync()  # the queue drains; the handle was never broken, only the caller's patience was
+    assert bool(torch.equal(out, ref))
 
 
 def test_irlba_rejects_zero_iterations(sa):

@@ -400,3 +400,16 @@ def test_group_barrier_of_the_single_process_form_is_bounded(sa):
         assert b"group barrier timed out" in sa._lib.scanrs_last_error()
     finally:
         sa.set_global_option("sync_timeout_s", 120.0)
+
+
+def test_every_option_and_counter_is_documented_in_the_header():
+    """The option / counter keys the library accepts (capi.cpp) against the ones include/scanrs_amd.h documents: a knob nobody can
+    find is as good as an environment variable."""
+    import re
+
+    src = open(os.path.join(ROOT, "scan-rs_amd", "csrc", "capi.cpp")).read()
+    hdr = open(os.path.join(ROOT, "include", "scanrs_amd.h")).read()
+    keys = set(re.findall(r'\bk == "([a-z0-9_]+)"', src))
+    assert len(keys) > 30
+    missing = sorted(k for k in keys if f'"{k}"' not in hdr)
+    assert not missing, f"keys accepted by capi.cpp but not documented in include/scanrs_amd.h: {missing}"
