@@ -379,7 +379,9 @@ int scanrs_mat_get_counter(scanrs_mat *m, const char *key, uint64_t *value);
  *                                  with this deadline in seconds; when it passes, the call returns SCANRS_ERR_DEVICE and
  *                                  scanrs_last_error() names the wait (function, file:line), the calling thread's last solver
  *                                  stages and which of the handle's streams (main / aux / aux2 / overflow) still had work; the
- *                                  same report and the whole stage ring go to stderr. The handle must then be freed (its queued
+ *                                  same report and the whole stage ring go to stderr. Copies that were queued may still run: the
+ *                                  host buffers given to the failing call (and the device's view of the handle) must not be
+ *                                  reused or freed before the process exits. The handle must then be freed (its queued
  *                                  work never finished); start over in a fresh process — a process whose device stopped
  *                                  answering cannot be repaired from inside, and must not exec() another program either.
  *   "device_cache_fraction" (0.5)  device blocks of 1 MB and more that the library releases are kept for its next allocation of about

@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -465,30 +466,57 @@ Profile::~Profile() {
 // ---- Storage -------------------------------------------------------------------------------------
 struct Storage::SideBuild {
     std::thread th;
-    const SparseCopy *target = nullptr;
     hipStream_t stream = nullptr;
+    // what the helper makes, in this order: [copy of `first` if it does not exist] -> layout of `first` -> [copy of `second`] -> layout
+    // of `second`; a waiter needs one copy (or its layout) and waits for that stage only
+    const SparseCopy *order[2] = {nullptr, nullptr};
+    bool want_layout[2] = {false, false};
+    std::mutex mu;
+    std::condition_variable cv;
+    bool copy_done[2] = {false, false}, layout_done[2] = {false, false}; // by position in `order`
+    bool finished = false;
     int code = SCANRS_OK;
     std::string err;
     double ms = 0.0;
 };
-void Storage::side_join_if(const SparseCopy *target) {
-    if (!side || (target && side->target != target)) return;
-    const auto t0 = std::chrono::steady_clock::now();
+// Waits until the helper has finished with `target` (nullptr: with everything) and rethrows its failure. `need_layout` false: the
+// copy itself is enough (a reader of the triplet).
+void Storage::side_join_if(const SparseCopy *target, bool need_layout) {
+    if (!side) return;
     SideBuild *sb = side;
-    side = nullptr;
-    if (sb->th.joinable()) sb->th.join();
-    if (sb->stream) (void)hipStreamDestroy(sb->stream);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool all = target == nullptr;
+    {
+        std::unique_lock<std::mutex> lk(sb->mu);
+        if (target) {
+            int pos = sb->order[0] == target ? 0 : sb->order[1] == target ? 1 : -1;
+            if (pos < 0) return; // the helper does not touch this copy
+            const double dl = sync_timeout_s() * 4.0; // builds are many device waits long; each of them is bounded by itself
+            const bool ok = sb->cv.wait_for(lk, std::chrono::duration<double>(dl), [&] {
+                return sb->finished || sb->code != SCANRS_OK || (need_layout ? sb->layout_done[pos] : sb->copy_done[pos]);
+            });
+            if (!ok) fail(SCANRS_ERR_DEVICE, "the helper thread that builds the second orientation did not finish a stage within %.0f s", dl);
+            all = sb->finished || sb->code != SCANRS_OK;
+        }
+    }
+    if (all) { // the helper is done (or failed): take it down
+        side = nullptr;
+        if (sb->th.joinable()) sb->th.join();
+        if (sb->stream) (void)hipStreamDestroy(sb->stream);
+        const int code = sb->code;
+        const std::string err = sb->err;
+        if (trace_on()) fprintf(stderr, "[scanrs trace] side build: %.3f ms on the helper thread\n", sb->ms);
+        delete sb;
+        t_side_wait_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (code != SCANRS_OK && std::uncaught_exceptions() == 0) fail(code, "%s", err.c_str());
+        return;
+    }
     t_side_wait_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    const int code = sb->code;
-    const std::string err = sb->err;
-    if (trace_on()) fprintf(stderr, "[scanrs trace] side build: %.3f ms on the helper thread\n", sb->ms);
-    delete sb;
-    if (code != SCANRS_OK && std::uncaught_exceptions() == 0) fail(code, "%s", err.c_str());
 }
 Storage::~Storage() {
     if (side) {
         try {
-            side_join_if(nullptr);
+            side_join_if(nullptr, true);
         } catch (const Failure &) {
         }
     }
@@ -548,7 +576,7 @@ hipStream_t Storage::ov() {
 SparseCopy &Storage::copy_with_outer_rows(bool outer_rows) {
     const bool primary_outer_rows = storage == SCANRS_CSR;
     if (outer_rows == primary_outer_rows) return primary;
-    side_join_if(&other); // a helper thread may be building it right now
+    side_join_if(&other, false); // a helper thread may be building it right now
     if (!has_other) {
         build_transposed_copy(*this, primary, other);
         has_other = true;
@@ -640,18 +668,23 @@ bool mat_tiles_ready(scanrs_mat *m, bool transpose) {
 void prepare_second_orientation(scanrs_mat *m, bool transpose_second, bool solver_follows) {
     Storage &st = *m->st;
     if (st.side || !st.side_build) return;
-    const bool outer_rows = (!transpose_second) != m->transposed; // the base-matrix dimension the second product's outer vectors run over
-    const bool is_primary = outer_rows == (st.storage == SCANRS_CSR);
-    SparseCopy &cp = is_primary ? st.primary : st.other;
-    const bool need_copy = !is_primary && !st.has_other;
-    const bool want_tiles = st.spmm_path == 0 && st.tile_auto && st.panel_precision == 0 && (st.tile_hint > 0 || solver_follows) &&
-                            st.primary.nnz >= std::max<uint64_t>(st.blocked_min_nnz, 1ull << 24) && !(cp.tiles != nullptr);
-    if (!need_copy && !want_tiles) return;
     if (st.primary.nnz < (1ull << 22)) return; // small matrices: the builds take less than starting a thread
+    const bool second_outer_rows = (!transpose_second) != m->transposed; // the base-matrix dimension the second product's outer vectors run over
+    const bool second_is_primary = second_outer_rows == (st.storage == SCANRS_CSR);
+    SparseCopy *second = second_is_primary ? &st.primary : &st.other, *first = second_is_primary ? &st.other : &st.primary;
+    const bool tiles_wanted = st.spmm_path == 0 && st.tile_auto && st.panel_precision == 0 && (st.tile_hint > 0 || solver_follows) &&
+                              st.primary.nnz >= std::max<uint64_t>(st.blocked_min_nnz, 1ull << 24);
+    auto exists = [&](const SparseCopy *c) { return c == &st.primary || st.has_other; };
+    // the first product's layout too (the helper builds it FIRST, alone on the device, while the caller normalizes; the transposition
+    // then runs beside the first pass, which is bound by the vector pipe, not by memory) — but only from normalize on: inside a solver
+    // the caller is about to build it himself
+    const bool first_layout = tiles_wanted && solver_follows && first->tiles == nullptr;
+    const bool second_layout = tiles_wanted && second->tiles == nullptr;
+    const bool need_second_copy = !exists(second);
+    if (!first_layout && !second_layout && !need_second_copy) return;
     int dev = 0;
     SCANRS_HIP(hipGetDevice(&dev));
     auto *sb = new Storage::SideBuild();
-    sb->target = &cp;
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (hipStreamCreateWithPriority(&sb->stream, hipStreamNonBlocking, least) != hipSuccess) {
@@ -659,28 +692,53 @@ void prepare_second_orientation(scanrs_mat *m, bool transpose_second, bool solve
         delete sb;
         return; // no helper: the main thread builds on demand as before
     }
+    int n = 0;
+    if (first_layout) {
+        sb->order[n] = first;
+        sb->want_layout[n] = true;
+        n++;
+    }
+    sb->order[n] = second;
+    sb->want_layout[n] = second_layout;
     st.side = sb;
     Storage *stp = &st;
-    sb->th = std::thread([stp, sb, dev, need_copy, want_tiles] {
+    sb->th = std::thread([stp, sb, dev] {
         const auto t0 = std::chrono::steady_clock::now();
+        auto mark = [&](int pos, bool layout) {
+            std::lock_guard<std::mutex> lk(sb->mu);
+            (layout ? sb->layout_done : sb->copy_done)[pos] = true;
+            sb->cv.notify_all();
+        };
         try {
             SCANRS_HIP(hipSetDevice(dev));
             CurrentHandle cur(stp);
-            SparseCopy &target = *const_cast<SparseCopy *>(sb->target);
-            if (need_copy) {
-                build_transposed_copy(*stp, stp->primary, stp->other, sb->stream);
-                stp->has_other = true;
+            for (int pos = 0; pos < 2; pos++) {
+                SparseCopy *cp = const_cast<SparseCopy *>(sb->order[pos]);
+                if (!cp) continue;
+                if (cp == &stp->other && !stp->has_other) {
+                    build_transposed_copy(*stp, stp->primary, stp->other, sb->stream);
+                    stp->has_other = true;
+                }
+                mark(pos, false);
+                if (sb->want_layout[pos]) {
+                    (void)tile_layout_build_auto(*stp, *cp, sb->stream);
+                    wait_stream(sb->stream, "side build", __FILE__, __LINE__);
+                }
+                mark(pos, true);
             }
-            if (want_tiles) (void)tile_layout_build_auto(*stp, target, sb->stream);
-            wait_stream(sb->stream, "side build", __FILE__, __LINE__);
         } catch (const Failure &e) {
+            std::lock_guard<std::mutex> lk(sb->mu);
             sb->code = e.code;
             sb->err = g_err; // this thread's message buffer
         } catch (const std::exception &e) {
+            std::lock_guard<std::mutex> lk(sb->mu);
             sb->code = SCANRS_ERR_DEVICE;
             sb->err = std::string("side build: ") + e.what();
         }
         sb->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> lk(sb->mu);
+        sb->finished = true;
+        sb->cv.notify_all();
     });
 }
 
@@ -689,7 +747,7 @@ void mat_apply(scanrs_mat *m, bool transpose, const double *dX, uint32_t ldx, ui
     CurrentHandle cur(&st);
     const bool outer_is_view_row = !transpose;
     SparseCopy &cp = copy_outer_view_rows(m, outer_is_view_row);
-    st.side_join_if(&cp); // its tile layout may be in the making
+    st.side_join_if(&cp, true); // its tile layout may be in the making
     DevMap map = m->dev_map(outer_is_view_row);
     const double *off_a = nullptr, *off_w = nullptr;
     // A map that ENDS in a ScaleAxis indexed by the inner position — the per-gene 1/sigma when cells are the outer

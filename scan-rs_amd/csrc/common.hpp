@@ -261,7 +261,7 @@ struct Storage {
     // stream of its own while the main thread prepares and runs the first product (capi.cpp, prepare_second_orientation)
     struct SideBuild;
     SideBuild *side = nullptr;
-    void side_join_if(const SparseCopy *target); // waits for the helper when it is working on `target` (nullptr: whatever it does); rethrows its failure
+    void side_join_if(const SparseCopy *target, bool need_layout); // waits until the helper is done with `target` (its copy, or also its layout; nullptr: with everything); rethrows its failure
     uint64_t t_side_wait_us = 0, t_layout_us = 0, t_start_panel_us = 0, t_delivery_us = 0; // first-call accounting (scanrs_mat_get_counter)
     Scratch scratch;
     // GF(2) jump tables of the device-side seeded-panel generator (solver.cpp / omega_jump_kernel)

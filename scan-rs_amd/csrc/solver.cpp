@@ -808,7 +808,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
         ~Drain() {
             if (std::uncaught_exceptions() > n0) {
                 try {
-                    st.side_join_if(nullptr); // the helper thread that builds the second orientation, if it still runs
+                    st.side_join_if(nullptr, true); // the helper thread that builds the second orientation, if it still runs
                 } catch (const Failure &) {
                 }
                 (void)wait_stream_quiet(st.stream);

@@ -1340,8 +1340,11 @@ def test_helper_thread_build_gives_the_same_result(sa):
         g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
         g.set_option("side_build", side)
         sa.normalize(g, sa.Normalization.CellRanger)
-        res.append(sa.BkSvd().run_pca(g, 6))
-        assert g.counter("t_layout_us") > 0  # the tile path was taken
+        res.append(sa.BkSvd().run_pca(g, 10))  # b = 20 columns: wide enough for the tile path
+        g.profile_enable(True)
+        sa.BkSvd().run_pca(g, 10)
+        assert any(kk.startswith("spmm_tile_kernel") for kk in g.profile_get()), "the tile path was not taken"
+        g.profile_enable(False)
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a, b)
 
