@@ -29,7 +29,7 @@ def classify(name, grid):
         return "spmm_gather2d_ov/long-outer" if grid > 2_500_000 else "spmm_gather2d_ov/short-outer"
     if "spmm_gather2d_kernel" in name:
         return "spmm_gather2d_kernel<1>/long-outer" if grid > 10_000_000 else "spmm_gather2d_kernel<1>/short-outer"
-    for k in ("col_moments_kernel", "tile_weights_kernel", "tile_ratio_table_kernel", "chol_rinv_kernel", "tile_scale_panel_kernel", "tile_finish_kernel", "tile_assign_wave_kernel", "tile_assign_kernel",
+    for k in ("col_moments_kernel", "tile_weights_unit_kernel", "tile_weights_kernel", "tile_ratio_table_kernel", "chol_rinv_kernel", "tile_scale_panel_kernel", "tile_finish_kernel", "tile_assign_wave_kernel", "tile_assign_kernel",
               "tile_slotless_kernel", "validate_stream_kernel", "unpack_key_kernel", "pack_key_kernel", "gram_tiled_kernel", "gemm_tiled_kernel", "slice_walk_kernel<1>", "slice_walk_kernel<0>", "row_reduce2d_kernel<2>", "row_reduce_kernel<2>", "row_reduce_kernel<0>",
               "weighted_colsum_partial_kernel", "spmv2d_kernel", "spmv_lds_kernel", "gram_kernel", "gemm_nn_kernel"):
         if k in name:
