@@ -344,9 +344,12 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *                       factorization does not converge within the queued passes); 0: host factorizations
  *   "d2h_threads" (4)   host threads that empty the pinned ring of a large result download
  *   "reuse_cmax" (1e5)  svd_bk: coefficient bound above which a projection column is recomputed directly
- *   "side_build" (1)    scanrs_normalize and the solvers start a helper thread (own stream) that builds what the SECOND product of
- *                       a solver iteration needs — the transposed copy of the matrix and that orientation's tile layout — beside the
- *                       normalisation passes and the first product; 0: built on demand by the calling thread
+ *   "side_build" (1)    scanrs_normalize starts a helper thread (own stream) that builds what the PCA behind it needs: the first
+ *                       product's tile layout, the transposed copy of the matrix and the second orientation's layout, in that
+ *                       order, beside the normalisation passes and the solver's first product (a solver called without a
+ *                       normalize before it starts the helper for the second orientation itself); 2: the helper starts behind
+ *                       the normalisation passes instead of beside them (measured the same); 0: everything is built on demand by
+ *                       the calling thread
  *   "tile_split" (1)    tile layout (default tile shape): an outer vector owns as many SLOTS (units of tile_k record positions per visit)
  *                       as its density asks for: V = round(x / tile_split_x), at least 1, at most 32, x = its expected nonzeros per
  *                       panel tile; its nonzeros are dealt to its slots round-robin; below tile_split_min it owns none and all of it

@@ -1484,7 +1484,8 @@ static void prefetch_for_pca(scanrs_mat *m) {
 int scanrs_normalize(scanrs_mat *m, int normalization, const uint32_t *size_factors) {
     return guard([&] { // normalize / normalize_with_size_factor, scan-rs/src/normalization.rs:46-102
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
-        if (normalization >= SCANRS_NORM_CELLRANGER && normalization <= SCANRS_NORM_LOG_TRANSFORM) prefetch_for_pca(m);
+        const bool pca_next = normalization >= SCANRS_NORM_CELLRANGER && normalization <= SCANRS_NORM_LOG_TRANSFORM;
+        if (pca_next && m->st->side_build == 1) prefetch_for_pca(m); // 1: beside the normalisation passes; 2: right behind them
         switch (normalization) {
         case SCANRS_NORM_CELLRANGER:
             log_normalize_impl(m, -1.0, OP_LOG2_1P, nullptr);
@@ -1519,6 +1520,7 @@ int scanrs_normalize(scanrs_mat *m, int normalization, const uint32_t *size_fact
         default:
             fail(SCANRS_ERR_ARGUMENT, "Normalization not recognized: %d", normalization);
         }
+        if (pca_next && m->st->side_build == 2) prefetch_for_pca(m);
     });
 }
 int scanrs_mat_target_umi(const scanrs_mat *m, double *target) {
@@ -1771,7 +1773,7 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
         } else if (k == "dense_side_no_lds") {
             st.dense_side_no_lds = value != 0.0;
         } else if (k == "side_build") {
-            st.side_build = value != 0.0;
+            st.side_build = (int)as_u32(0, 2);
         } else if (k == "tile_split") {
             st.tile_split = value != 0.0;
         } else if (k == "tile_split_x") {
