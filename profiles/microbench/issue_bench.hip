@@ -108,6 +108,38 @@ __global__ void k(unsigned long long *out, int iters) {
                          : "+v"(a0), "+v"(a1)
                          : "v"(v & 1023u), "v"(r0), "v"(rb), "v"(zero)
                          : "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
+        } else if (MODE == 13) { // 64 v_fmac_f64 with the weight broadcast inside the instruction (DPP row_newbcast: lane n of every row of 16)
+            asm volatile(REP4(REP4("v_fmac_f64_dpp %0, %10, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %1, %10, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %2, %10, %8 row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %3, %10, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n")
+                              REP4("v_fmac_f64_dpp %4, %10, %8 row_newbcast:7 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %5, %10, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %6, %10, %8 row_newbcast:9 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %7, %10, %9 row_newbcast:10 row_mask:0xf bank_mask:0xf\n"))
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                         : "v"(x0), "v"(x1), "v"(a0 * 0 + 1.25));
+        } else if (MODE == 14) { // general position, new form: v_mad_u32_u16 (SGPR row) + ds_read_b128 + 2 v_fmac_f64_dpp
+            asm volatile("s_mov_b32 s24, 0x00030002\n" REP4("v_mad_u32_u16 %3, s24, %4, %2\n ds_read_b128 v[40:43], %3\n s_waitcnt lgkmcnt(3)\n v_fmac_f64_dpp %0, %6, v[44:45] row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %1, %6, v[46:47] row_newbcast:1 row_mask:0xf bank_mask:0xf\n"
+"v_mad_u32_u16 %3, s24, %4, %2 op_sel:[1,0,0,0]\n ds_read_b128 v[44:47], %3\n s_waitcnt lgkmcnt(3)\n v_fmac_f64_dpp %0, %6, v[48:49] row_newbcast:2 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %1, %6, v[50:51] row_newbcast:2 row_mask:0xf bank_mask:0xf\n"
+"v_mad_u32_u16 %3, s24, %4, %2\n ds_read_b128 v[48:51], %3\n s_waitcnt lgkmcnt(3)\n v_fmac_f64_dpp %0, %6, v[52:53] row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %1, %6, v[54:55] row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+"v_mad_u32_u16 %3, s24, %4, %2 op_sel:[1,0,0,0]\n ds_read_b128 v[52:55], %3\n s_waitcnt lgkmcnt(3)\n v_fmac_f64_dpp %0, %6, v[40:41] row_newbcast:4 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %1, %6, v[42:43] row_newbcast:4 row_mask:0xf bank_mask:0xf\n"
+)
+                         : "+v"(a0), "+v"(a1)
+                         : "v"(v & 1023u), "v"(r0), "v"(rb), "v"(zero), "v"(x0)
+                         : "scc", "s24", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+        } else if (MODE == 15) { // unit position, new form: v_mad_u32_u16 (SGPR row) + ds_read_b128 + 2 v_add_f64
+            asm volatile("s_mov_b32 s24, 0x00030002\n" REP4("v_mad_u32_u16 %3, s24, %4, %2\n ds_read_b128 v[40:43], %3\n s_waitcnt lgkmcnt(3)\n v_add_f64 %0, %0, v[44:45]\n v_add_f64 %1, %1, v[46:47]\n"
+"v_mad_u32_u16 %3, s24, %4, %2 op_sel:[1,0,0,0]\n ds_read_b128 v[44:47], %3\n s_waitcnt lgkmcnt(3)\n v_add_f64 %0, %0, v[48:49]\n v_add_f64 %1, %1, v[50:51]\n"
+"v_mad_u32_u16 %3, s24, %4, %2\n ds_read_b128 v[48:51], %3\n s_waitcnt lgkmcnt(3)\n v_add_f64 %0, %0, v[52:53]\n v_add_f64 %1, %1, v[54:55]\n"
+"v_mad_u32_u16 %3, s24, %4, %2 op_sel:[1,0,0,0]\n ds_read_b128 v[52:55], %3\n s_waitcnt lgkmcnt(3)\n v_add_f64 %0, %0, v[40:41]\n v_add_f64 %1, %1, v[42:43]\n"
+)
+                         : "+v"(a0), "+v"(a1)
+                         : "v"(v & 1023u), "v"(r0), "v"(rb), "v"(zero)
+                         : "scc", "s24", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+        } else if (MODE == 16) { // general position, shipped form of round 3/4: .5 rdl (row pair) + 2 rdl (weight) + mad + read + 2 fma
+            asm volatile(REP4("v_readlane_b32 s24, %2, 3\n v_readlane_b32 s20, %2, 4\n v_readlane_b32 s21, %2, 5\n v_mad_u32_u16 %3, s24, %4, %2\n ds_read_b128 v[40:43], %3\n s_waitcnt lgkmcnt(3)\n v_fmac_f64 %0, s[20:21], v[44:45]\n v_fmac_f64 %1, s[20:21], v[46:47]\n"
+"v_readlane_b32 s22, %2, 7\n v_readlane_b32 s23, %2, 8\n v_mad_u32_u16 %3, s24, %4, %2 op_sel:[1,0,0,0]\n ds_read_b128 v[44:47], %3\n s_waitcnt lgkmcnt(3)\n v_fmac_f64 %0, s[22:23], v[48:49]\n v_fmac_f64 %1, s[22:23], v[50:51]\n"
+"v_readlane_b32 s24, %2, 9\n v_readlane_b32 s20, %2, 10\n v_readlane_b32 s21, %2, 11\n v_mad_u32_u16 %3, s24, %4, %2\n ds_read_b128 v[48:51], %3\n s_waitcnt lgkmcnt(3)\n v_fmac_f64 %0, s[20:21], v[52:53]\n v_fmac_f64 %1, s[20:21], v[54:55]\n"
+"v_readlane_b32 s22, %2, 13\n v_readlane_b32 s23, %2, 14\n v_mad_u32_u16 %3, s24, %4, %2 op_sel:[1,0,0,0]\n ds_read_b128 v[52:55], %3\n s_waitcnt lgkmcnt(3)\n v_fmac_f64 %0, s[22:23], v[40:41]\n v_fmac_f64 %1, s[22:23], v[42:43]\n"
+)
+                         : "+v"(a0), "+v"(a1)
+                         : "v"(v & 1023u), "v"(r0), "v"(rb), "v"(zero)
+                         : "scc", "s20", "s21", "s22", "s23", "s24", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -166,5 +198,9 @@ int main(int argc, char **argv) {
     if (want(10)) run<10>("unit packed: .25 rdl+bfe+mad", 16);
     if (want(11)) run<11>("v1 mix, wait every 2nd", 16);
     if (want(12)) run<12>("weights via ds_read_b64", 16);
+    if (want(13)) run<13>("v_fmac_f64_dpp row_newbcast", 64);
+    if (want(16)) run<16>("general, r4: 2.5 rdl+mad+2 fma", 16);
+    if (want(14)) run<14>("general, new: mad+2 fmac_dpp", 16);
+    if (want(15)) run<15>("unit, new: mad + 2 add", 16);
     return 0;
 }

@@ -43,6 +43,13 @@ constexpr uint32_t TL_NW = TL_NW_DEF;  // waves per workgroup (8: 2 per SIMD; 12
 constexpr uint32_t TL_LMAX = 104;      // widest panel: 192 ring rows x 104 x 8 B = 159744 B of LDS
 constexpr uint32_t TL_LDS = 160u << 10;
 constexpr int TL_W = 6;                // LDS row reads in flight per wave
+#ifndef TL_SROWS
+#define TL_SROWS 1
+#endif
+#ifndef TL_DPPW
+#define TL_DPPW 1
+#endif
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 constexpr uint32_t TL_TABC = 8;        // unit mode: counts 1 .. 8 take their weight from the per-position quotient table (one 64-byte line per position)
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -1038,6 +1045,20 @@ struct TileArgs {
 // KU > 0 (unit mode): position j < KU of every (slot, visit) pair holds a count-1 nonzero or nothing: its row is ADDED (no
 // weight, no v_readlane of one: the panel staged here was scaled by the per-inner factor, the sums are scaled by the
 // per-outer factor at the end); an unused unit position reads a row of zeros kept behind the ring.
+// acc += w[lane n of this lane's row of 16] * x: the broadcast of the weight happens inside the instruction (DPP), where the
+// round-3 form spent two v_readlane per general position. Nothing in front of it may have written `w` (2 wait states) or
+// EXEC (5) with a vector instruction: the weights come from a load, stage_chunk ends with the wait states.
+__device__ __forceinline__ double fmac_bcast(double acc, double w, double x, int n) {
+#define SCANRS_FB(N) \
+    case N: asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #N " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(x)); break;
+    switch (n) {
+        SCANRS_FB(0) SCANRS_FB(1) SCANRS_FB(2) SCANRS_FB(3) SCANRS_FB(4) SCANRS_FB(5) SCANRS_FB(6) SCANRS_FB(7)
+        SCANRS_FB(8) SCANRS_FB(9) SCANRS_FB(10) SCANRS_FB(11) SCANRS_FB(12) SCANRS_FB(13) SCANRS_FB(14) SCANRS_FB(15)
+    }
+#undef SCANRS_FB
+    return acc;
+}
+
 template <int K, int S, int KU>
 __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double *__restrict__ X, uint32_t ldx, uint32_t l,
                                                double *__restrict__ parts, uint32_t ldo, uint64_t part_stride, uint32_t n_items) {
@@ -1046,6 +1067,11 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
     // weights per record row: unit mode (K = 2, one unit position per slot) stores those of the general half only — lanes 0-31 load the
     // same words as lanes 32-63 and never use them
     constexpr uint32_t WPR = KU > 0 ? 32u : 64u;
+    constexpr bool SROWS = TL_SROWS && NSET == 1 && K == 2;
+    // DPPW: lane L holds the weights L % 16, 16 + L % 16, ... of the record row (one register pair per 16 weights), every row of 16
+    // lanes the same ones: a general position's FMA takes its weight from lane n of the lane's own row (fmac_bcast)
+    constexpr bool DPPW = TL_DPPW != 0 && (KU > 0 || S > 28); // (the 168-register kernels without unit positions have no room for 4 weight pairs)
+    constexpr int NWV = DPPW ? (int)(WPR / 16u) : 1;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t rowbytes = ldx * 8u;
@@ -1080,7 +1106,8 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
                      "s_mov_b32 m0, %3\n\t"
                      "s_nop 0\n\t"
                      "global_load_lds_dwordx4 %2, %4\n\t"
-                     "s_mov_b64 exec, %0"
+                     "s_mov_b64 exec, %0\n\t"
+                     "s_nop 1" // v_cmpx wrote EXEC: 5 wait states before a DPP instruction (fmac_bcast) may follow
                      : "=&s"(saved)
                      : "s"(limit), "v"(voff), "s"(m0v), "s"(sbase)
                      : "memory", "vcc");
@@ -1133,25 +1160,50 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
 
         const size_t vbase = (size_t)group * nt;
         uint32_t crow[NSET], nrow[NSET];
-        double cw[NSET], nw[NSET];
+        double cw[NSET][NWV], nw[NSET][NWV];
 #pragma unroll
         for (int b = 0; b < NSET; b++) {
-            crow[b] = prow32[((vbase + t0) * NSET + b) * 32u + (lane >> 1)];
-            cw[b] = ta.pw[((vbase + t0) * NSET + b) * WPR + (lane & (WPR - 1u))];
+            crow[b] = prow32[((vbase + t0) * NSET + b) * 32u + (lane >> 1)]; // (SROWS: brings the first visits' rows into L2)
+#pragma unroll
+            for (int v = 0; v < NWV; v++)
+                cw[b][v] = ta.pw[((vbase + t0) * NSET + b) * WPR + (DPPW ? v * 16u + (lane & 15u) : (lane & (WPR - 1u)))];
         }
 
         for (uint32_t t = t0; t < t1; t++) {
+            // SROWS: the visit's 64 row numbers are the same for every lane — two scalar loads put them into 32 SGPRs, where the
+            // address instruction of a position reads its half-word directly (no v_readlane per pair of positions: 32 of the ~300
+            // issue slots of a visit). Hand-issued: the compiler knows nothing of them (it would wait for ALL LDS reads wherever
+            // a scalar load is outstanding); they are in flight across the DMA wait and the barrier only, where no LDS read is,
+            // and the wait behind the barrier hands the registers to the compiler. The lines were brought into L2 by the vector
+            // load of a lane pair two visits earlier (nrow below).
+            u32x16 ra, rb;
+            if constexpr (SROWS) {
+                const uint32_t *rp = prow32 + (vbase + t) * 32u;
+                asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(ra), "=&s"(rb) : "s"(rp) : "memory");
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's LDS-DMA chunks of tile t (the compiler does not see them)
+            if constexpr (SROWS) {
+#pragma unroll
+                for (int b = 0; b < NSET; b++) asm volatile("" : "+v"(crow[b])); // keeps the L2 prefetch of the rows alive
+            }
 #ifndef TL_EXPERIMENT_NO_BARRIER // timing experiment only (wrong results): what the barrier per visit costs
-            __syncthreads(); // tile t is in the ring; everyone is done with visit t - 1, so the buffer of tile t + 1 - B is free
+            if constexpr (SROWS) {
+                // no fence: the LDS reads of visit t - 1 were consumed by its FMAs, the DMA writes were waited for above
+                __builtin_amdgcn_s_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ra), "+s"(rb)::"memory");
+            } else
+                __syncthreads(); // tile t is in the ring; everyone is done with visit t - 1, so the buffer of tile t + 1 - B is free
 #endif
             bufn = bufn + 1u == nbuf ? 0u : bufn + 1u;
             const uint32_t tr = t + 1 < t1 ? t + 1 : t; // the last visit of an item re-loads its own records: no branch in the loop
+            const uint32_t tp = t + 2 < t1 ? t + 2 : t1 - 1;
             // the next visit's records: nothing in this visit waits for them
 #pragma unroll
             for (int b = 0; b < NSET; b++) {
-                nrow[b] = prow32[((vbase + tr) * NSET + b) * 32u + (lane >> 1)];
-                nw[b] = ta.pw[((vbase + tr) * NSET + b) * WPR + (lane & (WPR - 1u))];
+                nrow[b] = prow32[((vbase + (SROWS ? tp : tr)) * NSET + b) * 32u + (lane >> 1)];
+#pragma unroll
+                for (int v = 0; v < NWV; v++)
+                    nw[b][v] = ta.pw[((vbase + tr) * NSET + b) * WPR + (DPPW ? v * 16u + (lane & 15u) : (lane & (WPR - 1u)))];
             }
             // The visit's S K positions as one software pipeline over position g (set g / (SPS K), lane g % (SPS K)): per step
             //   R(g)          v_readlane: the weight's halves (and, every 4th position, the quad's row bytes) into SGPRs; row
@@ -1165,8 +1217,8 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
             uint32_t wlo[NSET], whi[NSET];
 #pragma unroll
             for (int b = 0; b < NSET; b++) {
-                wlo[b] = (uint32_t)__double2loint(cw[b]);
-                whi[b] = (uint32_t)__double2hiint(cw[b]);
+                wlo[b] = (uint32_t)__double2loint(cw[b][0]);
+                whi[b] = (uint32_t)__double2hiint(cw[b][0]);
             }
             constexpr int PPS = SPS * K;      // positions per full set
             constexpr int NPT = S * K;        // positions per visit
@@ -1196,34 +1248,48 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
                     if (unit_of(g)) { // unit position: the row as it is
                         acc[sl].x += x[g % TL_W].x;
                         acc[sl].y += x[g % TL_W].y;
+                    } else if constexpr (DPPW) {
+                        const int wi = lane_of(g) & (int)(WPR - 1u);
+                        acc[sl].x = fmac_bcast(acc[sl].x, cw[set_of(g)][wi / 16], x[g % TL_W].x, wi % 16);
+                        acc[sl].y = fmac_bcast(acc[sl].y, cw[set_of(g)][wi / 16], x[g % TL_W].y, wi % 16);
                     } else {
                         acc[sl].x = fma(wq[g % WR], x[g % TL_W].x, acc[sl].x);
                         acc[sl].y = fma(wq[g % WR], x[g % TL_W].y, acc[sl].y);
                     }
-                    // pin the FMAs here (pure arithmetic: without a use the compiler sinks them to the end of the kernel)
-                    asm volatile("" : "+v"(acc[sl].x), "+v"(acc[sl].y));
-                }
-                if (i >= 2 && i - 2 < NPT) { // L(i - 2)
-                    const int g = i - 2;
-                    x[g % TL_W] = *(const __attribute__((address_space(3))) d2 *)addr[g % 2];
+                    // pin the FMAs here (pure arithmetic: without a use the compiler sinks them to the end of the kernel); the DPP form
+                    // is an asm statement already (and an asm that reads its result makes the compiler put an s_nop between them)
+                    if (unit_of(g) || !DPPW) asm volatile("" : "+v"(acc[sl].x), "+v"(acc[sl].y));
                 }
                 if (i >= 1 && i - 1 < NPT) { // A(i - 1)
                     const int g = i - 1;
                     // ring + row * rowbytes in one vector instruction (the address now, not in front of the read); the row is the low
                     // or the high half of the pair's scalar register, picked by op_sel: no scalar extract
+                    uint32_t sr;
+                    if constexpr (SROWS) {
+                        const int d = lane_of(g) >> 1;
+                        sr = d < 16 ? ra[d & 15] : rb[d & 15];
+                    } else
+                        sr = offs[g % 2];
                     if (lane_of(g) % 2 == 0)
-                        asm volatile("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(addr[g % 2]) : "s"(offs[g % 2]), "v"(rowbytes_v), "v"(ring));
+                        asm volatile("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(addr[g % 2]) : "s"(sr), "v"(rowbytes_v), "v"(ring));
                     else
-                        asm volatile("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(addr[g % 2]) : "s"(offs[g % 2]), "v"(rowbytes_v), "v"(ring));
+                        asm volatile("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(addr[g % 2]) : "s"(sr), "v"(rowbytes_v), "v"(ring));
+                }
+                if (i >= 2 && i - 2 < NPT) { // L(i - 2)
+                    const int g = i - 2;
+                    x[g % TL_W] = *(const __attribute__((address_space(3))) d2 *)addr[g % 2];
                 }
                 if (i < NPT) { // R(i)
                     const int b = set_of(i), p = lane_of(i);
-                    if (p % 2 == 0 || (i % PPS) % ns_of(i) == 0) {
-                        asm volatile("" : "+v"(crow[b])); // read the pair's rows here, not 64 steps early (they would fill the SGPR file)
-                        rows4 = rdlane(crow[b], p & ~1);
+                    if constexpr (!SROWS) {
+                        if (p % 2 == 0 || (i % PPS) % ns_of(i) == 0) {
+                            asm volatile("" : "+v"(crow[b])); // read the pair's rows here, not 64 steps early (they would fill the SGPR file)
+                            rows4 = rdlane(crow[b], p & ~1);
+                        }
+                        offs[i % 2] = rows4;
                     }
-                    offs[i % 2] = rows4;
-                    if (!unit_of(i)) wq[i % WR] = __hiloint2double((int)rdlane(whi[b], p), (int)rdlane(wlo[b], p));
+                    if constexpr (!DPPW)
+                        if (!unit_of(i)) wq[i % WR] = __hiloint2double((int)rdlane(whi[b], p), (int)rdlane(wlo[b], p));
                 }
                 if (i % DM == (TL_DMA_EARLY ? 0 : DM / 2) && i / DM < CH) stage_chunk(t + 1, bufn, i / DM);
                 asm volatile("" ::: "memory");
@@ -1232,7 +1298,8 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
 #pragma unroll
             for (int b = 0; b < NSET; b++) {
                 crow[b] = nrow[b];
-                cw[b] = nw[b];
+#pragma unroll
+                for (int v = 0; v < NWV; v++) cw[b][v] = nw[b][v];
             }
         }
         if (live && lane * 2u < l) {
