@@ -107,19 +107,21 @@ struct DevBuf {
         return *this;
     }
     ~DevBuf() { release(); }
+    static constexpr size_t SLACK = 4096;
     void alloc(size_t count) {
         release();
         n = count;
         if (!count) return;
-        // 64 bytes of slack behind every buffer: kernels that read a vector in aligned 16-byte chunks (tile_assign_wave_kernel) look up
-        // to two chunks past the end of the last vector
-        p = static_cast<T *>(device_alloc(count * sizeof(T) + 64));
+        // Slack behind every buffer: kernels that read a vector in aligned 16-byte chunks (tile_assign_wave_kernel) look up to two
+        // chunks past the end of the last vector; the tile kernel loads the records and weights of the next two visits without
+        // asking whether they exist (spmm_tile_body: 2 visits x 2 sets x 64 weights x 8 B behind the last group's last visit)
+        p = static_cast<T *>(device_alloc(count * sizeof(T) + SLACK));
     }
     void ensure(size_t count) {
         if (count > n) alloc(count);
     }
     void release() {
-        if (p) device_free_later(p, n * sizeof(T) + 64);
+        if (p) device_free_later(p, n * sizeof(T) + SLACK);
         p = nullptr;
         n = 0;
     }

@@ -1047,7 +1047,7 @@ struct TileArgs {
 // per-outer factor at the end); an unused unit position reads a row of zeros kept behind the ring.
 // acc += w[lane n of this lane's row of 16] * x: the broadcast of the weight happens inside the instruction (DPP), where the
 // round-3 form spent two v_readlane per general position. Nothing in front of it may have written `w` (2 wait states) or
-// EXEC (5) with a vector instruction: the weights come from a load, stage_chunk ends with the wait states.
+// EXEC (5) with a vector instruction: the weights come from a load, nothing in the loop writes EXEC.
 __device__ __forceinline__ double fmac_bcast(double acc, double w, double x, int n) {
 #define SCANRS_FB(N) \
     case N: asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #N " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(x)); break;
@@ -1079,7 +1079,6 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
     const uint32_t tpp = ta.sh.tpp, nt = ta.sh.nt, nbuf = ta.sh.B;
     const uint32_t n_wgg = (uint32_t)((ta.n_groups + TL_NW - 1) / TL_NW);
     const char *Xb = reinterpret_cast<const char *>(X);
-    const uint64_t x_bytes = ta.n_inner * (uint64_t)rowbytes;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)lds;
     if (ta.sh.KU) { // the row of zeros behind the ring (unused unit positions); visible to everybody after the first barrier
         const uint32_t zoff = nbuf * tile_bytes;
@@ -1089,28 +1088,33 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
     // LDS-DMA staging of tile t into ring buffer `buf`: 1 KB per wave-instruction, chunk i of this wave. No branches (a join
     // makes the compiler wait for ALL outstanding LDS reads at the next use) and hand-issued for the same reason (with the
     // builtin anywhere in the block of the position pipeline the compiler stops counting LDS reads): M0 = LDS destination of
-    // lane 0, 16 bytes per lane; lanes past the end of the tile — the next ring buffer is live — or of the panel are
-    // switched off through EXEC (all of them for a chunk or a tile that does not exist).
+    // lane 0, 16 bytes per lane. No lane is ever switched off (round 3/4 masked the lanes past the end of the tile or of the
+    // panel through EXEC: v_cmpx + two s_mov + wait states, 7 instructions per chunk and 12 per visit for the limit, a tenth
+    // of the instructions of a visit): a chunk that would reach past the end of the tile — the next ring buffer is live — is
+    // moved back to END at the tile's end (it writes some bytes a neighbour writes too, the same values), one that does not
+    // exist becomes that last chunk once more, and the panel the kernel reads is always the library's own compact copy, which
+    // has two tiles of slack behind it (launch_spmm_tiles): what is staged from there lands in ring rows no record refers to
+    // (rows past the panel's end; the tile after the last one goes into a free buffer).
     constexpr int CH = (int)((24u * K * TL_LMAX * 8u / 1024u + TL_NW - 1) / TL_NW); // chunks per wave and tile (tiles of <= 24 K rows)
+    uint32_t coff[CH], voff[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+        coff[i] = min((wave + (uint32_t)i * TL_NW) * 1024u, tile_bytes - 1024u);
+        voff[i] = coff[i] + lane * 16u;
+        asm volatile("" : "+s"(coff[i]), "+v"(voff[i])); // computed once, kept in registers
+    }
+    auto stage_set = [&](uint32_t buf, uint32_t i) { // (M0 is nobody else's on gfx9: LDS instructions do not use it)
+        const uint32_t base = lds0 + buf * tile_bytes;
+        asm volatile("s_add_u32 m0, %0, %1" ::"s"(base), "s"(coff[i]) : "memory", "scc");
+    };
+    auto stage_go = [&](uint32_t t, uint32_t i) { // at least one instruction after stage_set (M0 write -> LDS-DMA: 1 wait state)
+        const char *sbase = Xb + (uint64_t)t * tile_bytes;
+        asm volatile("global_load_lds_dwordx4 %0, %1" ::"v"(voff[i]), "s"(sbase) : "memory");
+    };
     auto stage_chunk = [&](uint32_t t, uint32_t buf, uint32_t i) {
-        const uint32_t off = (wave + i * TL_NW) * 1024u;
-        const uint64_t src0 = (uint64_t)t * tile_bytes;
-        const uint64_t left = x_bytes > src0 ? x_bytes - src0 : 0ull; // bytes of the panel from this tile on
-        const uint32_t limit = left < tile_bytes ? (uint32_t)left : tile_bytes;
-        const uint32_t m0v = lds0 + buf * tile_bytes + off;
-        uint32_t voff = off + lane * 16u;
-        const char *sbase = Xb + src0;
-        uint64_t saved;
-        asm volatile("s_mov_b64 %0, exec\n\t"
-                     "v_cmpx_gt_u32_e32 vcc, %1, %2\n\t"
-                     "s_mov_b32 m0, %3\n\t"
-                     "s_nop 0\n\t"
-                     "global_load_lds_dwordx4 %2, %4\n\t"
-                     "s_mov_b64 exec, %0\n\t"
-                     "s_nop 1" // v_cmpx wrote EXEC: 5 wait states before a DPP instruction (fmac_bcast) may follow
-                     : "=&s"(saved)
-                     : "s"(limit), "v"(voff), "s"(m0v), "s"(sbase)
-                     : "memory", "vcc");
+        stage_set(buf, i);
+        asm volatile("s_nop 0" ::: "memory");
+        stage_go(t, i);
     };
     // Lanes that own no column pair still take part in every ds_read_b128, which the LDS serves in four groups of 16 lanes
     // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, {32-35,44-47,52-59}, {36-43,48-51,60-63}: MI355X_MICROARCH.md, LDS): an idle
@@ -1195,8 +1199,9 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
                 __syncthreads(); // tile t is in the ring; everyone is done with visit t - 1, so the buffer of tile t + 1 - B is free
 #endif
             bufn = bufn + 1u == nbuf ? 0u : bufn + 1u;
-            const uint32_t tr = t + 1 < t1 ? t + 1 : t; // the last visit of an item re-loads its own records: no branch in the loop
-            const uint32_t tp = t + 2 < t1 ? t + 2 : t1 - 1;
+            // the records of the next visit(s), whether they are this item's or not (or nobody's: behind the last group's last visit
+            // lies DevBuf's slack): no selection, no branch
+            const uint32_t tr = t + 1, tp = t + 2;
             // the next visit's records: nothing in this visit waits for them
 #pragma unroll
             for (int b = 0; b < NSET; b++) {
@@ -1225,10 +1230,7 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
             constexpr int WR = TL_W + 3;      // weights live from R(g) to F(g)
             // the next tile's LDS-DMA chunks go out in the first third of the visit, a few steps apart (all at once they queue on
             // the texture path; spread over the whole visit the last ones are still in flight at the barrier: -1.5 ms per pass)
-#ifndef TL_DMA_EARLY
-#define TL_DMA_EARLY 1
-#endif
-            constexpr int DM = TL_DMA_EARLY ? (NPT / (3 * CH) > 1 ? NPT / (3 * CH) : 1) : NPT / CH;
+            constexpr int DM = NPT / (3 * CH) > 1 ? NPT / (3 * CH) : 1;
             uint32_t rows4 = 0;
             uint32_t offs[2];
             lds_cptr_t addr[2];
@@ -1291,7 +1293,11 @@ __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double 
                     if constexpr (!DPPW)
                         if (!unit_of(i)) wq[i % WR] = __hiloint2double((int)rdlane(whi[b], p), (int)rdlane(wlo[b], p));
                 }
-                if (i % DM == (TL_DMA_EARLY ? 0 : DM / 2) && i / DM < CH) stage_chunk(t + 1, bufn, i / DM);
+                if constexpr (DM >= 2) { // M0 in one step, the load in the next: no wait state to pay for
+                    if (i % DM == 0 && i / DM < CH) stage_set(bufn, i / DM);
+                    if (i % DM == 1 && i / DM < CH) stage_go(t + 1, i / DM);
+                } else if (i / DM < CH)
+                    stage_chunk(t + 1, bufn, i / DM);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -1394,7 +1400,7 @@ void launch_tile_kernel(Storage &st, const TileArgs &ta, const double *X, uint32
 
 bool spmm_tiles_ok(const Storage &st, const SparseCopy &cp, uint32_t ldx, uint32_t l) {
     return l >= 16 && l <= TL_LMAX && (ldx & 1u) == 0 && cp.n_outer > 0 && cp.n_inner > 0 && cp.nnz > 0 &&
-           ((size_t)st.tile_b * st.tile_t + 1u) * even_up(l) * 8 <= TL_LDS;
+           ((size_t)st.tile_b * st.tile_t + 1u) * even_up(l) * 8 <= TL_LDS && (size_t)st.tile_t * even_up(l) * 8 >= 1024u; // (a tile is at least one staging chunk)
 }
 
 // Auto path (spmm_path 0): the hybrid product serves a large matrix once its layout under this map exists — built when a
@@ -1472,19 +1478,18 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     const uint32_t ldc = even_up(l);
     const double *Xov = X; // the overflow part works on the panel as it came
     const uint32_t ldxov = ldx;
+    // The tile kernel always reads the library's own compact copy: its staging never switches a lane off, so it reads up to two
+    // tiles past the panel's end (spmm_tile_body) — the copy has that much slack behind it.
+    double *xc = st.scratch.get<double>("tile_xc", ((size_t)cp.n_inner + 2u * sh.T) * ldc);
     if (tl.unit_mode) { // unit mode: the tile kernel's panel carries the per-inner factor of the unit weight
-        double *xc = st.scratch.get<double>("tile_xc", (size_t)cp.n_inner * ldc);
         const uint64_t n = cp.n_inner * (uint64_t)ldc;
         hipLaunchKernelGGL(tile_scale_panel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, X, ldx, cp.n_inner, l, ldc, tl.vi.p, xc);
-        X = xc;
-        ldx = ldc;
-    } else if (ldx != ldc) {
-        double *xc = st.scratch.get<double>("tile_xc", (size_t)cp.n_inner * ldc);
+    } else {
         launch_copy_cols(st, X, ldx, xc, ldc, cp.n_inner, l);
-        X = xc;
-        ldx = ldc;
-        Xov = xc;
+        if (ldx != ldc) Xov = xc;
     }
+    X = xc;
+    ldx = ldc;
     int dev = 0, n_cu = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
