@@ -18,7 +18,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libscanrs_amd.so")
+# SCANRS_AMD_LIB: another build of the same library (A/B timing of two builds on one GPU box; tools/pass_bench.py)
+LIB_PATH = os.environ.get("SCANRS_AMD_LIB") or os.path.join(_HERE, "lib", "libscanrs_amd.so")
 
 CSR, CSC = 0, 1
 FN_LN_1P, FN_LOG2_1P, FN_LOG10_1P, FN_SQUARE = 2, 3, 4, 5

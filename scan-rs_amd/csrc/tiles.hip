@@ -1045,20 +1045,6 @@ struct TileArgs {
 // KU > 0 (unit mode): position j < KU of every (slot, visit) pair holds a count-1 nonzero or nothing: its row is ADDED (no
 // weight, no v_readlane of one: the panel staged here was scaled by the per-inner factor, the sums are scaled by the
 // per-outer factor at the end); an unused unit position reads a row of zeros kept behind the ring.
-// acc += w[lane n of this lane's row of 16] * x: the broadcast of the weight happens inside the instruction (DPP), where the
-// round-3 form spent two v_readlane per general position. Nothing in front of it may have written `w` (2 wait states) or
-// EXEC (5) with a vector instruction: the weights come from a load, nothing in the loop writes EXEC.
-__device__ __forceinline__ double fmac_bcast(double acc, double w, double x, int n) {
-#define SCANRS_FB(N) \
-    case N: asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #N " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(x)); break;
-    switch (n) {
-        SCANRS_FB(0) SCANRS_FB(1) SCANRS_FB(2) SCANRS_FB(3) SCANRS_FB(4) SCANRS_FB(5) SCANRS_FB(6) SCANRS_FB(7)
-        SCANRS_FB(8) SCANRS_FB(9) SCANRS_FB(10) SCANRS_FB(11) SCANRS_FB(12) SCANRS_FB(13) SCANRS_FB(14) SCANRS_FB(15)
-    }
-#undef SCANRS_FB
-    return acc;
-}
-
 template <int K, int S, int KU>
 __device__ __forceinline__ void spmm_tile_body(const TileArgs &ta, const double *__restrict__ X, uint32_t ldx, uint32_t l,
                                                double *__restrict__ parts, uint32_t ldo, uint64_t part_stride, uint32_t n_items) {
