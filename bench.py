@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 LDS_PEAK_TBS = 150.0   # MI355X_MICROARCH.md, LDS: ds_read_b128 = 256 B/clk/CU, "aggregate with every CU streaming (~2.4 GHz): ~150 TB/s"
 LDS_SURVEY_TBS = 78.6  # SURVEY.md §8d's estimate (128 B/clk/CU x 256 CUs x 2.4 GHz), kept beside it
-PMC_PROFILE = "r04b_pmc_traffic.json"  # committed PMC passes (separate --pmc runs) the `traffic` field is read from
+PMC_PROFILE = "r04c_pmc_traffic.json"  # committed PMC passes (separate --pmc runs) the `traffic` field is read from
 KERNEL_SOURCES = ("scan-rs_amd/csrc/tiles.hip", "scan-rs_amd/csrc/kernels.hip", "scan-rs_amd/csrc/device_map.hpp")
 
 
@@ -600,6 +600,28 @@ def main():
         alg_per_launch = st["algorithmic_bytes"] / max(1, st["launches"])
         lds_per_launch = st["onchip_gather_bytes"] / max(1, st["launches"])
         avg_s = st["total_ms"] / max(1, st["launches"]) * 1e-3
+        # LDS-array and vector-pipe occupancy of the same kernel from the committed counter passes (same source-hash rule as `traffic`):
+        # SQ_LDS_IDX_ACTIVE = LDS-array cycles (4 per ds_read_b128, idle lanes included), SQ_INSTS_VALU x 4 clk per SIMD, against the
+        # cycles the launch had at the shader clock the run held (SQ_BUSY_CYCLES / 32 shader engines / duration: the kernel is
+        # power-limited well below the 2.4 GHz the peaks are quoted at) - measured in the profile run, with ITS launch duration
+        occupancy = None
+        try:
+            if traffic is not None:
+                with open(os.path.join(ROOT, "profiles", PMC_PROFILE.replace("traffic", "counters"))) as f:
+                    cj = json.load(f)
+                ck = cj["kernels"].get(name) or cj["kernels"].get(name.split("/")[0])
+                if cj.get("kernel_source_sha256_16") == kernel_source_hash() and ck and cj.get("avg_launch_ms", {}).get(name.split("/")[0]):
+                    t_prof = cj["avg_launch_ms"][name.split("/")[0]] * 1e-3
+                    clk = ck["SQ_BUSY_CYCLES"]["avg_per_launch"] / 32.0 / t_prof
+                    occupancy = {
+                        "source": f"profiles/{PMC_PROFILE.replace('traffic', 'counters')} (separate --pmc passes, same kernel sources), launch {round(t_prof * 1e3, 2)} ms there",
+                        "shader_clock_ghz_held": round(clk / 1e9, 2),
+                        "lds_array_busy": round(ck["SQ_LDS_IDX_ACTIVE"]["avg_per_launch"] / (256 * clk * t_prof), 3),
+                        "valu_busy": round(ck["SQ_INSTS_VALU"]["avg_per_launch"] * 4.0 / (1024 * clk * t_prof), 3),
+                        "valu_instructions_per_lds_read": round(ck["SQ_INSTS_VALU"]["avg_per_launch"] / ck["SQ_INSTS_LDS"]["avg_per_launch"], 2),
+                    }
+        except (OSError, ValueError, KeyError, ZeroDivisionError):
+            occupancy = None
         roof = {
             "bound": "hbm",
             "kernel": name,
@@ -623,6 +645,7 @@ def main():
                 "peak": LDS_PEAK_TBS,
                 "frac": round(lds_per_launch / avg_s / 1e12 / LDS_PEAK_TBS, 4) if avg_s > 0 and lds_per_launch else None,
                 "frac_of_survey_estimate_78.6": round(lds_per_launch / avg_s / 1e12 / LDS_SURVEY_TBS, 4) if avg_s > 0 and lds_per_launch else None,
+                "occupancy_from_counters": occupancy,
             },
             "kernel_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
             "launches_per_step_all": {k: round(v["launches"] / args.steps, 1) for k, v in sorted(prof.items())},

@@ -108,12 +108,7 @@ def main():
         if g("SQ_INSTS_VALU") and g("SQ_INSTS_VMEM_RD"):
             d["valu_insts_per_vmem_read"] = g("SQ_INSTS_VALU") / g("SQ_INSTS_VMEM_RD")
         v["derived"] = d
-    json.dump({
-        "_how": "separate rocprofv3 --pmc passes (tools/profile_round.sh): {TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum}, {SQ_WAVE_CYCLES SQ_BUSY_CYCLES "
-                "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY}, {TCP_TOTAL_CACHE_ACCESSES_sum "
-                "TCP_TCC_READ_REQ_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum}; same command as the traffic passes; averages per launch of a kernel class. "
-                "SQ_* are in quad-cycles summed over waves (MI355X_MICROARCH.md, rocprofv3 PMC slots).",
-        "commit": commit, "kernel_source_sha256_16": src_hash, "kernels": cc}, open(f"profiles/{tag}_pmc_counters.json", "w"), indent=1)
+    class_ms = {}
     # ---- kernel stats -----------------------------------------------------------------------------------------------------
     sfile, tfile = one(f"{raw}/stats/**/*_kernel_stats.csv"), one(f"{raw}/stats/**/*_kernel_trace.csv")
     if sfile and tfile:
@@ -137,11 +132,21 @@ def main():
                     fo.write(f"#   {key} grid=({gx},{gy}) calls={len(d)} avg_ms={d.mean():.4f} total_ms={d.sum():.2f}\n")
             for key, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 fo.write(f"# class {key}: calls={n} avg_ms={t / n:.4f} total_ms={t:.2f}\n")
+                class_ms[key.split("/")[0]] = round(t / n, 4) if key.split("/")[0] not in class_ms else class_ms[key.split("/")[0]]
             w = csv.writer(fo)
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
             for r in rows:
                 if "scanrs" in r["Name"] or "rocprim" in r["Name"]:
                     w.writerow([r["Name"][:140], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+    json.dump({
+        "_how": "separate rocprofv3 --pmc passes (tools/profile_round.sh): {TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum}, {SQ_WAVE_CYCLES SQ_BUSY_CYCLES "
+                "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY}, {TCP_TOTAL_CACHE_ACCESSES_sum "
+                "TCP_TCC_READ_REQ_sum TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum}; same command as the traffic passes; averages per launch of a kernel class. "
+                "SQ_* are in quad-cycles summed over waves (MI355X_MICROARCH.md, rocprofv3 PMC slots).",
+        "commit": commit, "kernel_source_sha256_16": src_hash,
+        # average launch duration per kernel class in the --stats run (no counters): bench.py derives the shader clock the launch held
+        # from SQ_BUSY_CYCLES with it
+        "avg_launch_ms": class_ms, "kernels": cc}, open(f"profiles/{tag}_pmc_counters.json", "w"), indent=1)
     print(json.dumps({k: round(v.get("hbm_bytes_per_launch_corrected", 0) / 1e6, 1) for k, v in tr.items()}))
     print(json.dumps({k: v.get("derived") for k, v in cc.items()}, indent=1))
 
