@@ -356,6 +356,8 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *                       goes to the overflow part. Makes the layout fit real count matrices (a few thousand genes detected in most
  *                       cells, most genes in almost none). 0: one slot per vector
  *   "tile_split_x" (1.8), "tile_split_min" (0.5)   the two densities of that rule, in nonzeros per tile
+ *   "tile_build_one_pass" (1)  the wave-level layout builder writes the records and collects the nonzeros without a position in ONE
+ *                       walk over the matrix (temporaries of 8 bytes per nonzero, then a compaction); 0: a counting walk first
  *   "tile_weights_wide" (1)  the weight refresh of a unit-mode layout works four positions per thread with wide loads and stores
  *                       (0: one position per thread; same values)
  *   "dense_side_no_lds" (0)  experiment: dense kernels queued on the side streams use the register-only MFMA forms, which can run

@@ -1782,6 +1782,8 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
         } else if (k == "tile_split_min") {
             if (!(value >= 0.0) || value > 16.0) fail(SCANRS_ERR_ARGUMENT, "tile_split_min must be in [0, 16]");
             st.tile_split_min = value;
+        } else if (k == "tile_build_one_pass") {
+            st.tile_build_one_pass = value != 0.0;
         } else if (k == "tile_weights_wide") {
             st.tile_weights_wide = value != 0.0;
         } else if (k == "tile_builder") {

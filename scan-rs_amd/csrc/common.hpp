@@ -299,6 +299,7 @@ struct Storage {
     int tile_split = 1;                   // tile layout: slots per outer vector from its density (several for dense vectors, none — all overflow — for very sparse ones); 0: one slot per vector
     double tile_split_x = 1.8;            // ... nonzeros per panel tile a slot is sized for
     double tile_split_min = 0.5;          // ... vectors below this many nonzeros per tile get no slot
+    int tile_build_one_pass = 1;          // wave-level layout builder: records and overflow in ONE walk over the matrix + a compaction (0: counting pass, then fill pass)
     int tile_weights_wide = 1;            // weight refresh of a unit-mode layout: four positions per thread with wide loads / stores (0: one position per thread)
     int tile_builder = 1;                 // layout builder: 1 = wave-level (a lane per vector, visits in lock-step, rows written whole; default shape only), 0 = per-thread walk
     uint32_t tile_build_waves = 0;        // ... its waves per CU through a dummy LDS allocation (0: no cap — measured the same at 8, 16, 32 and without; and a builder that asks for LDS cannot run beside the persistent tile kernel of a first pass)

@@ -338,14 +338,24 @@ __global__ __launch_bounds__(64) void tile_assign_wave_kernel(const uint64_t *__
         }
         p = lo;
     }
+    const uint64_t part_lo = p; // the part's first nonzero in the source arrays
     if (V > 1u) p += (r + V - (uint32_t)((p - s) % V)) % V; // this slot's first position of the part: p = s + r (mod V)
     const uint64_t e = o * sh.n_parts + part;
     AssignState a{t0, KU, t0, KG, 0, 0, 0, 0, 0, 0};
     unsigned long long n_ov = 0;
-    unsigned long long op = (FILL && valid && V == 1u) ? ov_off[e] : 0ull;
+    // FILL with ov_off == nullptr: ONE pass (no counting pass in front): the overflow nonzeros of a (vector, part) segment go into arrays
+    // indexed like the SOURCE, from the segment's first nonzero on (they are at most as many as the segment has), the count of the
+    // segment into ov_cursor (zeroed before; the lanes of a split vector add theirs up as they go); tile_ov_compact_kernel then
+    // moves them to their final places.
+    const bool one_pass = FILL && ov_off == nullptr;
+    unsigned long long op = (FILL && !one_pass && valid && V == 1u) ? ov_off[e] : 0ull;
     auto overflow = [&](uint32_t idx, uint32_t cnt) {
         if (FILL) {
-            const unsigned long long at = V == 1u ? op++ : atomicAdd(&ov_cursor[e], 1ull);
+            unsigned long long at;
+            if (one_pass)
+                at = part_lo + (V == 1u ? n_ov++ : atomicAdd(&ov_cursor[e], 1ull));
+            else
+                at = V == 1u ? op++ : atomicAdd(&ov_cursor[e], 1ull);
             ov_indices[at] = idx;
             ov_values[at] = cnt;
         } else {
@@ -456,6 +466,58 @@ __global__ __launch_bounds__(64) void tile_assign_wave_kernel(const uint64_t *__
             ovc[e] = n_ov;
         else if (n_ov)
             atomicAdd(&ovc[e], n_ov);
+    }
+    if (one_pass && valid && V == 1u) ov_cursor[e] = n_ov;
+}
+
+// One-pass build: the overflow nonzeros of segment e = (vector, part) stand in `tmp_*` from the segment's first source position on
+// (a vector without slots: ALL its nonzeros of the part are overflow and are taken from the source arrays themselves); their final
+// place starts at ov_off[e]. A wave takes 64 segments: every lane looks up one of them, then the wave copies them one after the other.
+__global__ __launch_bounds__(256) void tile_ov_compact_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
+                                                              const uint32_t *__restrict__ values, const uint32_t *__restrict__ slot_first,
+                                                              uint64_t n_outer, TileShape sh, const unsigned long long *__restrict__ ov_off,
+                                                              const uint32_t *__restrict__ tmp_indices, const uint32_t *__restrict__ tmp_values,
+                                                              uint32_t *__restrict__ ov_indices, uint32_t *__restrict__ ov_values) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t n_seg = n_outer * sh.n_parts;
+    const uint64_t e0 = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u;
+    if (e0 >= n_seg) return;
+    const uint64_t e = e0 + lane;
+    uint64_t src = 0, dst = 0;
+    uint32_t cnt = 0, from_source = 0;
+    if (e < n_seg) {
+        dst = ov_off[e];
+        cnt = (uint32_t)(ov_off[e + 1] - dst);
+        if (cnt) {
+            const uint64_t o = e / sh.n_parts;
+            const uint32_t part = (uint32_t)(e - o * sh.n_parts);
+            uint64_t lo = indptr[o], hi = indptr[o + 1];
+            const uint64_t key = (uint64_t)part * sh.tpp * sh.T;
+            if (part > 0)
+                while (lo < hi) {
+                    const uint64_t mid = (lo + hi) >> 1;
+                    if ((uint64_t)indices[mid] < key)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+            src = lo;
+            from_source = slot_first[o + 1] == slot_first[o] ? 1u : 0u;
+        }
+    }
+    uint64_t busy = __builtin_amdgcn_ballot_w64(cnt != 0u);
+    while (busy) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(busy);
+        busy &= busy - 1;
+        const uint32_t n = rdlane(cnt, j);
+        const uint64_t sj = ((uint64_t)rdlane((uint32_t)(src >> 32), j) << 32) | rdlane((uint32_t)src, j);
+        const uint64_t dj = ((uint64_t)rdlane((uint32_t)(dst >> 32), j) << 32) | rdlane((uint32_t)dst, j);
+        const bool fs = rdlane(from_source, j) != 0u;
+        const uint32_t *si = fs ? indices : tmp_indices, *sv = fs ? values : tmp_values;
+        for (uint32_t k = lane; k < n; k += 64u) {
+            ov_indices[dj + k] = si[sj + k];
+            ov_values[dj + k] = sv[sj + k];
+        }
     }
 }
 
@@ -718,6 +780,27 @@ __global__ void tile_gather_slots_kernel(const double *__restrict__ per_vec, con
     if (i < n_slots) per_slot[i] = per_vec[slot_vec[i]];
 }
 
+// segment bounds of the overflow sort: a vector with one slot (or none) wrote its overflow in index order already -> length 0
+struct SplitSegment {
+    const uint64_t *indptr;
+    const uint32_t *slot_first;
+    int end;
+    __host__ __device__ unsigned long long operator()(unsigned o) const {
+        const bool split = slot_first[o + 1] - slot_first[o] > 1u;
+        return indptr[o + ((end && split) ? 1u : 0u)];
+    }
+};
+__global__ void tile_split_copyback_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ slot_first, uint64_t n_outer,
+                                           const uint32_t *__restrict__ si, const uint32_t *__restrict__ sv, uint32_t *__restrict__ di,
+                                           uint32_t *__restrict__ dv) {
+    const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_outer || slot_first[o + 1] - slot_first[o] <= 1u) return;
+    for (uint64_t p = indptr[o]; p < indptr[o + 1]; p++) {
+        di[p] = si[p];
+        dv[p] = sv[p];
+    }
+}
+
 __global__ void tile_ovptr_kernel(const unsigned long long *__restrict__ ov_off, uint64_t n_outer, uint32_t n_parts,
                                   uint64_t *__restrict__ indptr) {
     const uint64_t o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -845,6 +928,11 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     const uint64_t n_seg = cp.n_outer * sh.n_parts;
     lap("slots");
     // ---- count the overflow per (vector, part) ----
+    // one_pass (the wave builder's default): no counting pass - the fill pass writes the records AND the overflow nonzeros (into
+    // temporaries indexed like the source, counted per segment as they come), a compaction moves them to their places; the
+    // max_overflow verdict then comes after the records were written (a rejected layout is rare and costs one fill pass)
+    const bool one_pass = wave_builder && st.tile_build_one_pass != 0;
+    DevBuf<uint32_t> tmp_oi, tmp_ovv;
     DevBuf<unsigned long long> ovc(n_seg + 1), ovo(n_seg + 1);
     SCANRS_HIP(hipMemsetAsync(ovc.p, 0, (n_seg + 1) * 8, s)); // the slots of a split vector add up theirs
     const dim3 grid((unsigned)((n_seg + 255) / 256));
@@ -856,7 +944,25 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
 #define SCANRS_ASSIGN(FILLV, KUV, OVC, OFF, CUR, PROW, PCNT, OVI, OVV)                                                                          \
     hipLaunchKernelGGL((tile_assign_wave_kernel<FILLV, 48, KUV>), dim3((unsigned)n_witems), dim3(64), wb_lds, s, cp.indptr.p, cp.indices.p, cp.values.p, \
                        tl->slot_vec.p, tl->slot_first.p, tl->n_slots, tl->n_groups, sh, OVC, OFF, CUR, PROW, PCNT, OVI, OVV)
-    if (wave_builder) {
+    if (one_pass) {
+        if (n_rec) {
+            tl->prow.alloc(n_rec);
+            tl->pcnt.alloc(n_rec);
+        }
+        tmp_oi.alloc(std::max<uint64_t>(cp.nnz, 1));
+        tmp_ovv.alloc(std::max<uint64_t>(cp.nnz, 1));
+        lap("hipMalloc of records");
+        if (n_witems) {
+            if (sh.KU)
+                SCANRS_ASSIGN(true, 1, (unsigned long long *)nullptr, (const unsigned long long *)nullptr, ovc.p, tl->prow.p, tl->pcnt.p, tmp_oi.p, tmp_ovv.p);
+            else
+                SCANRS_ASSIGN(true, 0, (unsigned long long *)nullptr, (const unsigned long long *)nullptr, ovc.p, tl->prow.p, tl->pcnt.p, tmp_oi.p, tmp_ovv.p);
+        }
+        if (split && n_seg)
+            hipLaunchKernelGGL((tile_slotless_kernel<false>), grid, dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p, tl->slot_first.p, cp.n_outer, sh,
+                               ovc.p, (const unsigned long long *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        lap("fill (one pass)");
+    } else if (wave_builder) {
         if (n_witems) {
             if (sh.KU)
                 SCANRS_ASSIGN(false, 1, ovc.p, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint16_t *)nullptr, (uint8_t *)nullptr,
@@ -886,11 +992,11 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
                     (unsigned long long)cp.n_outer, (unsigned long long)cp.n_inner, 100.0 * (double)n_ov / (double)cp.nnz, 100.0 * max_overflow);
         return nullptr;
     }
-    if (n_rec) { // (the weights are allocated with the first map: 32 or 64 per record row, tile_layout_weights)
+    if (n_rec && !one_pass) { // (the weights are allocated with the first map: 32 or 64 per record row, tile_layout_weights)
         tl->prow.alloc(n_rec);
         tl->pcnt.alloc(n_rec);
     }
-    lap("hipMalloc of records");
+    if (!one_pass) lap("hipMalloc of records");
     // (the weights need no initialisation: tile_weights_kernel writes every position that is ever read, used or not)
     if (!wave_builder && n_rec) { // the per-thread walk patches records into an initialised layout; the wave builder writes every record itself
         hipLaunchKernelGGL(tile_init_rows_kernel, dim3((unsigned)std::min<uint64_t>((n_rec / 4 + 255) / 256, 1u << 23)), dim3(256), 0, s, tl->prow.p, n_rec, sh);
@@ -906,7 +1012,11 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     ov.indices.alloc(std::max<uint64_t>(n_ov, 1));
     ov.values.alloc(std::max<uint64_t>(n_ov, 1));
     ov.fvals.alloc(std::max<uint64_t>(n_ov, 1));
-    if (wave_builder) {
+    if (one_pass) {
+        if (n_ov)
+            hipLaunchKernelGGL(tile_ov_compact_kernel, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, s, cp.indptr.p, cp.indices.p, cp.values.p,
+                               tl->slot_first.p, cp.n_outer, sh, ovo.p, tmp_oi.p, tmp_ovv.p, ov.indices.p, ov.values.p);
+    } else if (wave_builder) {
         // the slots of a split vector take their places in the vector's overflow segment from a cursor (ovc, now a copy of the offsets)
         if (tl->max_mult > 1u) SCANRS_HIP(hipMemcpyAsync(ovc.p, ovo.p, (n_seg + 1) * 8, hipMemcpyDeviceToDevice, s));
         if (n_witems) {
@@ -924,22 +1034,26 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     }
 #undef SCANRS_ASSIGN
     SCANRS_HIP(hipGetLastError());
-    lap("fill");
+    lap(one_pass ? "overflow compaction" : "fill");
     if (n_ov && tl->max_mult > 1u) {
         // the overflow nonzeros of a split vector arrived in the order of its lanes: back into ascending index order (what the gather
-        // kernel's bounds table and the reference's accumulation order want) by a segmented sort over the vectors
+        // kernel's bounds table and the reference's accumulation order want) by a segmented sort — over the split vectors only (the
+        // others are segments of length 0 to the sort: a tenth of the cells of the headline matrix are split, 4.5 -> 1.5 ms)
         if (n_ov > 0xFFFFFFFFull) fail(SCANRS_ERR_SHAPE, "overflow part of a split layout beyond 2^32-1 nonzeros is not supported");
         DevBuf<uint32_t> ki(n_ov), vi2(n_ov);
         unsigned end_bit = 1;
         while (end_bit < 32u && (cp.n_inner >> end_bit) != 0) end_bit++;
+        const SplitSegment seg_begin{ov.indptr.p, tl->slot_first.p, 0}, seg_end{ov.indptr.p, tl->slot_first.p, 1};
+        auto it_b = rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned>(0u), seg_begin);
+        auto it_e = rocprim::make_transform_iterator(rocprim::make_counting_iterator<unsigned>(0u), seg_end);
         size_t tb = 0;
-        SCANRS_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tb, ov.indices.p, ki.p, ov.values.p, vi2.p, (unsigned)n_ov, (unsigned)cp.n_outer, ov.indptr.p,
-                                                       ov.indptr.p + 1, 0u, end_bit, s));
+        SCANRS_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tb, ov.indices.p, ki.p, ov.values.p, vi2.p, (unsigned)n_ov, (unsigned)cp.n_outer, it_b, it_e, 0u,
+                                                       end_bit, s));
         DevBuf<char> tsort(std::max<size_t>(tb, 16));
-        SCANRS_HIP(rocprim::segmented_radix_sort_pairs(tsort.p, tb, ov.indices.p, ki.p, ov.values.p, vi2.p, (unsigned)n_ov, (unsigned)cp.n_outer, ov.indptr.p,
-                                                       ov.indptr.p + 1, 0u, end_bit, s));
-        SCANRS_HIP(hipMemcpyAsync(ov.indices.p, ki.p, n_ov * 4, hipMemcpyDeviceToDevice, s));
-        SCANRS_HIP(hipMemcpyAsync(ov.values.p, vi2.p, n_ov * 4, hipMemcpyDeviceToDevice, s));
+        SCANRS_HIP(rocprim::segmented_radix_sort_pairs(tsort.p, tb, ov.indices.p, ki.p, ov.values.p, vi2.p, (unsigned)n_ov, (unsigned)cp.n_outer, it_b, it_e, 0u,
+                                                       end_bit, s));
+        hipLaunchKernelGGL(tile_split_copyback_kernel, grid_1d(cp.n_outer), dim3(256), 0, s, ov.indptr.p, tl->slot_first.p, cp.n_outer, ki.p, vi2.p,
+                           ov.indices.p, ov.values.p);
         SCANRS_SYNC(s);
         lap("overflow sort");
     }
@@ -1409,7 +1523,8 @@ bool tile_layout_build_auto(Storage &st, SparseCopy &cp, hipStream_t s) {
     // room: records (11 B per position: row 2, count 1, weight 8) + overflow + the build's temporaries + the partial-sum buffers, and 8 GB for the solver
     const double nt = (double)((cp.n_inner + st.tile_t - 1) / st.tile_t);
     const double need = 11.0 * 64.0 * (double)((cp.n_outer + st.tile_s - 1) / st.tile_s) * nt * ((st.tile_s + 64 / st.tile_k - 1) / (64 / st.tile_k)) +
-                        0.2 * 12.0 * (double)cp.nnz + 32.0 * (double)cp.n_outer * 64.0 + 2.0 * (double)cp.n_outer * 104.0 * 8.0 * 2.0;
+                        0.2 * 12.0 * (double)cp.nnz + 32.0 * (double)cp.n_outer * 64.0 + 2.0 * (double)cp.n_outer * 104.0 * 8.0 * 2.0 +
+                        (st.tile_build_one_pass ? 8.0 * (double)cp.nnz : 0.0); // (the one-pass build's temporaries)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
     const double have = (double)free_b + (cp.tiles ? cp.tiles->bytes() : 0.0); // a stale layout is released first

@@ -647,6 +647,30 @@ def test_wave_level_layout_builder_equals_the_per_thread_walk(sa, tile_ku):
             assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (rows, cols, fill, storage)
 
 
+def test_one_pass_layout_build_equals_count_then_fill(sa):
+    """The wave-level builder writes records and overflow in ONE walk (overflow into temporaries indexed like the source, then a
+    compaction) instead of a counting walk followed by a fill walk: the layouts must be the same - products bit for bit - with
+    split vectors (several slots), vectors without a slot (everything overflow), several parts, empty vectors, counts above 255."""
+    rng = np.random.default_rng(93)
+    for rows, cols, fill, vmax in ((1, 1, 1.0, 3), (33, 97, 0.9, 2), (65, 4800, 0.6, 4), (257, 2000, 0.05, 400), (700, 1000, 0.03, 3),
+                                   (97, 20000, 0.02, 3), (2000, 193, 0.2, 300), (130, 9000, 0.3, 3)):
+        dense = random_counts(rng, rows, cols, fill, vmax)
+        dense[rng.random(rows) < 0.2, :] = 0
+        sparse_rows = rng.random(rows) < 0.3  # far below one nonzero per tile: no slot in the row-major layout
+        dense[sparse_rows, :] *= (rng.random((int(sparse_rows.sum()), cols)) < 0.02)
+        dense[0, 0] = 1
+        for storage in (so.CSR, so.CSC):
+            outs = []
+            for one_pass in (0, 1):
+                g, _ = pair(sa, dense, storage)
+                g.set_spmm_path(3).set_option("tile_build_one_pass", one_pass).set_option("tile_split_min", 0.3)
+                g.compose_scale_axis(1, np.linspace(0.5, 1.5, cols)).apply(sa.FN_LOG2_1P)
+                q = np.cos(np.arange(cols * 40, dtype=np.float64)).reshape(cols, 40)
+                ql = np.sin(np.arange(rows * 24, dtype=np.float64)).reshape(24, rows)
+                outs.append((g.dot(q), g.rdot(ql)))
+            assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (rows, cols, fill, storage)
+
+
 def test_wide_weight_refresh_equals_the_one_position_form(sa):
     """The weights of a unit-mode layout are refreshed four positions per thread with wide loads and stores (round 4); the values must
     be the ones the one-position-per-thread kernel writes: products bit for bit, both table orientations (linear and visit-major
