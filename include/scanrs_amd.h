@@ -394,7 +394,8 @@ int scanrs_mat_get_counter(scanrs_mat *m, const char *key, uint64_t *value);
  *                                  that was just freed is scrubbed in the background; an allocation that lands on it waits:
  *                                  seconds for the tens of GB of a handle). 0: no cache. See scanrs_release_cached_memory. */
 int scanrs_set_global_option(const char *key, double value);
-/* Optional: loads the library's device code, starts the one-off host-side table computation of the seeded start panels and
+/* Optional: loads the library's device code, starts the one-off host-side table computation of the seeded start panels, pins the
+ * 72 MB host staging buffer a PCA's result delivery and start panel go through (kept in a process-wide pool across handles) and
  * touches the runtime paths the first call would otherwise initialise (~30-60 ms on MI355X): call it at program start to
  * keep that out of the first scanrs_mat_create / normalize / PCA. Everything works without it. */
 int scanrs_init(void);

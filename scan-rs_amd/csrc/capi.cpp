@@ -464,6 +464,55 @@ Profile::~Profile() {
 }
 
 // ---- Storage -------------------------------------------------------------------------------------
+// ---- pinned host staging buffers, kept across handles ------------------------------------------------------------------------
+// A handle stages its seeded start panel (26 MB) and the delivery of V (ring of 8 x 8 MB) through pinned memory; pinning 64 MB costs
+// 5-8 ms, once per handle until round 4. Buffers go back to a small pool when their handle dies, and scanrs_init() pins the first
+// one ahead of the first call (portable: usable from every device of a single-process multi-GPU program).
+namespace {
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> idle;
+    size_t idle_bytes = 0;
+};
+PinnedPool &pinned_pool() {
+    static PinnedPool *p = new PinnedPool(); // never destroyed: handles may outlive static destruction order
+    return *p;
+}
+} // namespace
+void *pinned_take(size_t bytes, size_t *got) {
+    PinnedPool &g = pinned_pool();
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        int best = -1;
+        for (int i = 0; i < (int)g.idle.size(); i++)
+            if (g.idle[i].second >= bytes && (best < 0 || g.idle[i].second < g.idle[best].second)) best = i;
+        if (best >= 0) {
+            void *p = g.idle[best].first;
+            *got = g.idle[best].second;
+            g.idle_bytes -= *got;
+            g.idle.erase(g.idle.begin() + best);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    SCANRS_HIP(hipHostMalloc(&p, bytes, hipHostMallocPortable));
+    *got = bytes;
+    return p;
+}
+void pinned_give(void *p, size_t bytes) noexcept {
+    if (!p) return;
+    PinnedPool &g = pinned_pool();
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        if (g.idle.size() < 4 && g.idle_bytes + bytes <= ((size_t)1 << 30)) {
+            g.idle.emplace_back(p, bytes);
+            g.idle_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
 struct Storage::SideBuild {
     std::thread th;
     hipStream_t stream = nullptr;
@@ -520,7 +569,7 @@ Storage::~Storage() {
         } catch (const Failure &) {
         }
     }
-    if (host_stage) (void)hipHostFree(host_stage);
+    if (host_stage) pinned_give(host_stage, host_stage_bytes);
     if (aux_stream) {
         (void)wait_stream_quiet(aux_stream);
         (void)hipStreamDestroy(aux_stream);
@@ -1058,6 +1107,9 @@ int scanrs_init(void) {
         need_device();
         jump_tables_prefetch();
         library_warm_up();
+        size_t got = 0;
+        void *p = pinned_take((size_t)72 << 20, &got); // the staging ring of a 10^6 x 50 delivery (67 MB) and the start panel
+        pinned_give(p, got);
     });
 }
 int scanrs_release_cached_memory(void) {

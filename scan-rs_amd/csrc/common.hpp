@@ -239,6 +239,10 @@ struct ShardInfo {
 };
 
 // Storage shared by a handle and its views (AdaptiveMat::view / t share `&[AdaptiveVec]`).
+// Pinned host staging buffers, kept across handles (capi.cpp): take the smallest idle one of at least `bytes` or pin a new one.
+void *pinned_take(size_t bytes, size_t *got);
+void pinned_give(void *p, size_t bytes) noexcept;
+
 struct Storage {
     uint64_t rows = 0, cols = 0;
     int storage = SCANRS_CSR; // orientation of `primary`: CSR -> outer = rows
@@ -273,13 +277,13 @@ struct Storage {
     // grow-only pinned host staging buffer (seeded start panels): no page faults, DMA-speed uploads
     void *host_stage = nullptr;
     size_t host_stage_bytes = 0;
+    // (from / back to a small process-wide pool, capi.cpp: pinning 64 MB takes several ms, and scanrs_init can do it ahead of the first call)
     void *pinned(size_t bytes) {
         if (bytes > host_stage_bytes) {
-            if (host_stage) (void)hipHostFree(host_stage);
+            if (host_stage) pinned_give(host_stage, host_stage_bytes);
             host_stage = nullptr;
             host_stage_bytes = 0;
-            SCANRS_HIP(hipHostMalloc(&host_stage, bytes, hipHostMallocDefault));
-            host_stage_bytes = bytes;
+            host_stage = pinned_take(bytes, &host_stage_bytes);
         }
         return host_stage;
     }
