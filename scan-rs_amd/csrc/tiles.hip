@@ -931,7 +931,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     // one_pass (the wave builder's default): no counting pass - the fill pass writes the records AND the overflow nonzeros (into
     // temporaries indexed like the source, counted per segment as they come), a compaction moves them to their places; the
     // max_overflow verdict then comes after the records were written (a rejected layout is rare and costs one fill pass)
-    const bool one_pass = wave_builder && st.tile_build_one_pass != 0;
+    bool one_pass = wave_builder && st.tile_build_one_pass != 0;
     DevBuf<uint32_t> tmp_oi, tmp_ovv;
     DevBuf<unsigned long long> ovc(n_seg + 1), ovo(n_seg + 1);
     SCANRS_HIP(hipMemsetAsync(ovc.p, 0, (n_seg + 1) * 8, s)); // the slots of a split vector add up theirs
@@ -944,13 +944,21 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
 #define SCANRS_ASSIGN(FILLV, KUV, OVC, OFF, CUR, PROW, PCNT, OVI, OVV)                                                                          \
     hipLaunchKernelGGL((tile_assign_wave_kernel<FILLV, 48, KUV>), dim3((unsigned)n_witems), dim3(64), wb_lds, s, cp.indptr.p, cp.indices.p, cp.values.p, \
                        tl->slot_vec.p, tl->slot_first.p, tl->n_slots, tl->n_groups, sh, OVC, OFF, CUR, PROW, PCNT, OVI, OVV)
+    if (one_pass) { // its temporaries (8 bytes per nonzero) must fit beside the layout: if they cannot be had, the two-walk form
+        try {
+            tmp_oi.alloc(std::max<uint64_t>(cp.nnz, 1));
+            tmp_ovv.alloc(std::max<uint64_t>(cp.nnz, 1));
+        } catch (const Failure &) {
+            tmp_oi.release();
+            tmp_ovv.release();
+            one_pass = false;
+        }
+    }
     if (one_pass) {
         if (n_rec) {
             tl->prow.alloc(n_rec);
             tl->pcnt.alloc(n_rec);
         }
-        tmp_oi.alloc(std::max<uint64_t>(cp.nnz, 1));
-        tmp_ovv.alloc(std::max<uint64_t>(cp.nnz, 1));
         lap("hipMalloc of records");
         if (n_witems) {
             if (sh.KU)
@@ -1523,12 +1531,20 @@ bool tile_layout_build_auto(Storage &st, SparseCopy &cp, hipStream_t s) {
     // room: records (11 B per position: row 2, count 1, weight 8) + overflow + the build's temporaries + the partial-sum buffers, and 8 GB for the solver
     const double nt = (double)((cp.n_inner + st.tile_t - 1) / st.tile_t);
     const double need = 11.0 * 64.0 * (double)((cp.n_outer + st.tile_s - 1) / st.tile_s) * nt * ((st.tile_s + 64 / st.tile_k - 1) / (64 / st.tile_k)) +
-                        0.2 * 12.0 * (double)cp.nnz + 32.0 * (double)cp.n_outer * 64.0 + 2.0 * (double)cp.n_outer * 104.0 * 8.0 * 2.0 +
-                        (st.tile_build_one_pass ? 8.0 * (double)cp.nnz : 0.0); // (the one-pass build's temporaries)
+                        0.2 * 12.0 * (double)cp.nnz + 32.0 * (double)cp.n_outer * 64.0 + 2.0 * (double)cp.n_outer * 104.0 * 8.0 * 2.0;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
-    const double have = (double)free_b + (cp.tiles ? cp.tiles->bytes() : 0.0); // a stale layout is released first
-    if (!(have > need + 8.0 * (double)(1ull << 30))) return false;
+    // what the driver has free, what a stale layout gives back, and the released blocks the library keeps for reuse (device_alloc
+    // hands them back to the driver before it gives up): without the last term a shard whose first PCA ran with one orientation on
+    // the gather kernels for lack of room never got that layout later either (2.6 10^9 nonzeros, k = 100: 2.26 instead of 1.86 s per step).
+    // The unused part of a reserve made ahead of time is NOT counted: the solver's panels will want it.
+    const double have = (double)free_b + (double)device_cache_bytes() + (cp.tiles ? cp.tiles->bytes() : 0.0);
+    if (!(have > need + 8.0 * (double)(1ull << 30))) {
+        if (trace_on())
+            fprintf(stderr, "[scanrs trace] tile layout: %llu outer x %llu inner not built: needs %.1f GB + 8.6 of headroom, the driver reports %.1f GB free\n",
+                    (unsigned long long)cp.n_outer, (unsigned long long)cp.n_inner, need / 1e9, have / 1e9);
+        return false;
+    }
     // Build now: the layout is only worth having when not too many nonzeros miss it (the overflow gather runs at two waves
     // per SIMD beside the tile kernel). At 27-28 % overflow (100 k x 20 k at 5 % density, both orientations) the hybrid product
     // still wins, 50 against 61 ms per PCA; with the heavy-tailed gene profile of
