@@ -1107,9 +1107,13 @@ int scanrs_init(void) {
         need_device();
         jump_tables_prefetch();
         library_warm_up();
-        size_t got = 0;
-        void *p = pinned_take((size_t)72 << 20, &got); // the staging ring of a 10^6 x 50 delivery (67 MB) and the start panel
-        pinned_give(p, got);
+        try { // best effort: a host that cannot pin 72 MB now will find out (and say so) when a call needs the buffer
+            size_t got = 0;
+            void *p = pinned_take((size_t)72 << 20, &got); // the staging ring of a 10^6 x 50 delivery (67 MB) and the start panel
+            pinned_give(p, got);
+        } catch (const Failure &) {
+            (void)hipGetLastError();
+        }
     });
 }
 int scanrs_release_cached_memory(void) {
