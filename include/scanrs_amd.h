@@ -362,6 +362,10 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *                       (0: one position per thread; same values)
  *   "dense_side_no_lds" (0)  experiment: dense kernels queued on the side streams use the register-only MFMA forms, which can run
  *                       beside the persistent tile kernel (measured slower: DESIGN.md section 9)
+ *   "tile_dense" (1)    tile layout of the default shape: 1 = DENSE record streams — the records of a (wave, visit) are a packed list,
+ *                       as long as the most loaded of the item's 8 waves needs for the tile that leaves the ring, and the accumulator of
+ *                       a record is selected at run time (VGPR index mode): about 1.05 record positions per nonzero and no overflow
+ *                       beyond the vectors too sparse to own a slot; 0 = the round-4 form, tile_k fixed positions per (slot, visit)
  *   "tile_builder" (1)  1: wave-level builder of the tile layout (default tile shape); 0: per-thread walk (reference form)
  *   "tile_build_waves" (0)   cap on the waves per CU of that builder (0: as many as fit)
  *   "sync_timeout_s" (120)  PROCESS-WIDE (same as scanrs_set_global_option): deadline of every host-side wait for the device

@@ -58,6 +58,7 @@ typedef __attribute__((address_space(3))) const char *lds_cptr_t;
 struct TileShape {
     uint32_t T, B, K, KU, S, sps, nset, nt, n_parts, tpp; // KU of the K positions of a (slot, visit) pair are "unit" positions
 };
+struct DenseItem; // tiles_dense.inc
 
 static inline dim3 grid_1d(uint64_t n) { // one work-item per element; a dispatch holds fewer than 2^32 of them
     const uint64_t blocks = (n + 255) / 256;
@@ -809,6 +810,10 @@ __global__ void tile_ovptr_kernel(const unsigned long long *__restrict__ ov_off,
 
 } // namespace
 
+// the dense record layout serves the default shape (tiles_dense.inc)
+static inline bool tile_dense_wanted(const Storage &st) {
+    return st.tile_dense != 0 && st.tile_builder != 0 && st.tile_k == 2u && st.tile_b == 4u && st.tile_s == 32u && st.tile_t == 48u;
+}
 // the tile layout of one orientation under one map
 struct TileLayout {
     TileShape sh{};
@@ -828,12 +833,25 @@ struct TileLayout {
     DevBuf<double> uo, vi;
     DevBuf<double> uo_slot;   // uo by slot (what the product kernel scales a slot's sums by)
     DevBuf<double> ratio_tab; // unit mode: quotient of the weight of counts 1 .. TL_TABC per position of the side that owns the nonlinear links
+    // dense layout (round 5, tiles_dense.inc): record streams [item][wave][chunk][16] instead of fixed positions per (slot, visit)
+    bool dense = false;
+    uint32_t dn_wgg = 0, dn_items = 0;
+    uint64_t dn_chunks = 0;        // chunks of 16 positions in drec / pw (cmeta: one entry each)
+    DevBuf<uint32_t> drec;         // 4 x slot-in-group | raw count << 8 | ring row << 16
+    DevBuf<uint64_t> cmeta;        // group << 32 | visit of a chunk (weight refresh)
+    DevBuf<char> ditems;           // DenseItem per workgroup item
+    DevBuf<uint32_t> rtab;         // rounds: chunks | first-of-visit << 8
+    bool separable = false;        // dense: the map's count-1 value is uo[outer] vi[inner] (tables in uo / vi / ratio_tab)
     // identity of the map the weights were evaluated under (MapOp ids are never reused); -1: none yet
     int sig_n = -1;
     uint32_t sig_id[MAX_OPS] = {};
     int sig_outer[MAX_OPS] = {};
-    double bytes() const { return (double)prow.n * 2.0 + (double)pcnt.n + (double)pw.n * 8.0 + (double)ov.nnz * 16.0 + (double)ratio_tab.n * 8.0; }
+    double bytes() const {
+        return (double)prow.n * 2.0 + (double)pcnt.n + (double)pw.n * 8.0 + (double)ov.nnz * 16.0 + (double)ratio_tab.n * 8.0 + (double)drec.n * 4.0 + (double)cmeta.n * 8.0 +
+               (double)rtab.n * 4.0;
+    }
     bool structure_matches(const Storage &st) const {
+        if (dense != tile_dense_wanted(st)) return false;
         const bool splittable = st.tile_builder != 0 && sh.K == 2u && sh.B == 4u && sh.S == 32u && sh.T == 48u; // the wave-level builder's shape
         const double want_x = splittable && st.tile_split ? st.tile_split_x : 0.0, want_min = splittable && st.tile_split ? st.tile_split_min : 0.0;
         return sh.K == st.tile_k && sh.S == st.tile_s && sh.T == st.tile_t && sh.B == st.tile_b && sh.KU == (st.tile_k == 2u && st.tile_ku ? 1u : 0u) &&
@@ -858,6 +876,8 @@ bool tile_shape_ok(uint32_t K, uint32_t S, uint32_t T, uint32_t B) {
     return ks && B >= 2 && T >= 8 && T <= 24u * K && B * T <= 192;
 }
 
+static TileLayout *dense_layout_build(Storage &st, const SparseCopy &cp, double max_overflow, hipStream_t s, std::unique_ptr<TileLayout> tl,
+                                      const std::function<void(const char *)> &lap); // tiles_dense.inc
 // max_overflow > 0: give up (nullptr) when more than that share of the nonzeros would land in the overflow part — known after the
 // counting pass, before anything large is allocated.
 TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_overflow, hipStream_t stream = nullptr) {
@@ -927,6 +947,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     if (tl->n_groups * sh.nt > 0xFFFFFFFFull || (sh.nset & (sh.nset - 1u))) fail(SCANRS_ERR_SHAPE, "matrix too large for the tile layout's 32-bit visit index");
     const uint64_t n_seg = cp.n_outer * sh.n_parts;
     lap("slots");
+    if (tile_dense_wanted(st)) return dense_layout_build(st, cp, max_overflow, s, std::move(tl), lap);
     // ---- count the overflow per (vector, part) ----
     // one_pass (the wave builder's default): no counting pass - the fill pass writes the records AND the overflow nonzeros (into
     // temporaries indexed like the source, counted per segment as they come), a compaction moves them to their places; the
@@ -1100,9 +1121,14 @@ static bool tile_map_separable(const DevMap &map, int &nl_outer) {
     return true;
 }
 
+static void dense_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &cp, const DevMap &map); // below
 // weights of every position and of the overflow part under `map`
 static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &cp, const DevMap &map) {
     Tick tick("tile layout weights");
+    if (tl.dense) {
+        dense_layout_weights(st, tl, cp, map);
+        return;
+    }
     const uint64_t n_rec = tl.prow.n;
     int nl_outer = 1;
     tl.unit_mode = tl.sh.KU > 0 && tile_map_separable(map, nl_outer);
@@ -1150,6 +1176,8 @@ static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &c
         tl.sig_outer[i] = map.ops[i].a_outer;
     }
 }
+
+#include "tiles_dense.inc"
 
 // ---- product -------------------------------------------------------------------------------------------------------
 namespace {
@@ -1636,10 +1664,12 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     const bool long_outer = cp.n_outer >= cp.n_inner;
     if (st.prof.on)
         st.prof.begin(st.stream, long_outer ? "spmm_tile_kernel/long-outer" : "spmm_tile_kernel/short-outer", bytes,
-                      (double)tl.n_groups * sh.nt * sh.S * sh.K * 8.0 * l);
+                      tl.dense ? (double)tl.dn_chunks * 16.0 * 8.0 * l : (double)tl.n_groups * sh.nt * sh.S * sh.K * 8.0 * l);
 #define SCANRS_TILE(KK, SS, UU) launch_tile_kernel<KK, SS, UU>(st, ta, X, ldx, l, pbuf, ldc, part_stride, n_items, grid)
     const bool um = tl.unit_mode; // a layout with unit positions under a map that does not separate runs the weighted kernel
     if (n_items == 0) { // every vector went to the overflow part: nothing for the tile kernel
+    } else if (tl.dense) {
+        launch_tile_dense_kernel(st, tl, X, ldx, l, pbuf, ldc, part_stride, next_item, grid);
     } else if (sh.K == 2 && sh.S == 32)
         um ? SCANRS_TILE(2, 32, 1) : SCANRS_TILE(2, 32, 0);
     else if (sh.K == 2 && sh.S == 28)
