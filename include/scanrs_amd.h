@@ -366,6 +366,8 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *                       as long as the most loaded of the item's 8 waves needs for the tile that leaves the ring, and the accumulator of
  *                       a record is selected at run time (VGPR index mode): about 1.05 record positions per nonzero and no overflow
  *                       beyond the vectors too sparse to own a slot; 0 = the round-4 form, tile_k fixed positions per (slot, visit)
+ *   "tile_sort_slots" (1)  dense tile layout: the slots take their places (workgroup item, wave, accumulator) in the order of their load,
+ *                       heaviest first, so that the 8 waves of an item carry about the same number of records per visit (0: vector order)
  *   "tile_builder" (1)  1: wave-level builder of the tile layout (default tile shape); 0: per-thread walk (reference form)
  *   "tile_build_waves" (0)   cap on the waves per CU of that builder (0: as many as fit)
  *   "sync_timeout_s" (120)  PROCESS-WIDE (same as scanrs_set_global_option): deadline of every host-side wait for the device

@@ -57,10 +57,20 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // address from a vector of row byte offsets (v43: lane L holds the offset of record L % 16)
 #define A_DPP(p, k) "v_add_u32_dpp " AD(k) ", v43, v46 row_newbcast:" #p " row_mask:0xf bank_mask:0xf\n"
 
+
+// packed records (mode 6): position p in half (p & 1) of s[36 + p / 2]: bits 7:0 of the half = 4 x slot, bits 15:8 = ring row.
+// A: s_bfe_u32 (row) + v_mad_u32_u24; F: low half -> s_set_gpr_idx_idx reads bits 7:0 directly, high half -> s_lshr_b32 first
+#define PK_A(p, k, sh) "s_bfe_u32 s84, s[36+" #p "/2], " sh "\n v_mad_u32_u24 " AD(k) ", s84, v47, v46\n"
+#define PK_A_LO(p, k) PK_A(p, k, "0x80008")
+#define PK_A_HI(p, k) PK_A(p, k, "0x80018")
+#define PK_F_LO_ON(p, k) "s_set_gpr_idx_on s[36+" #p "/2], 0x8\n" F_IDX_BODY(p, k)
+#define PK_F_LO(p, k) "s_set_gpr_idx_idx s[36+" #p "/2]\n" F_IDX_BODY(p, k)
+#define PK_F_HI(p, k) "s_lshr_b32 s85, s[36+" #p "/2], 16\n s_set_gpr_idx_idx s85\n" F_IDX_BODY(p, k)
+
 #define CLOBBERS                                                                                                                          \
     "scc", "m0", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54",  \
         "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", \
-        "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",     \
+        "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53",     \
         "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73",     \
         "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93",     \
         "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111",      \
@@ -160,6 +170,16 @@ __global__ __launch_bounds__(512, 2) void kb(const uint32_t *__restrict__ recs, 
                          : ACC_OPS
                          :
                          : CLOBBERS);
+        } else if (MODE == 6) {
+            asm volatile(PK_A_LO(0, 0) PK_A_HI(1, 1) PK_A_LO(2, 2) PK_A_HI(3, 3) PK_A_LO(4, 4) PK_A_HI(5, 5) PK_A_LO(6, 6) PK_A_HI(7, 7) //
+                         L_(0, 0) L_(1, 1) L_(2, 2) L_(3, 3) L_(4, 4) L_(5, 5) L_(6, 6) L_(7, 7)                                    //
+                         PK_A_LO(8, 8) PK_A_HI(9, 9) PK_A_LO(10, 10) PK_A_HI(11, 11) PK_A_LO(12, 12) PK_A_HI(13, 13) PK_A_LO(14, 14) PK_A_HI(15, 15) //
+                         L_(8, 8) L_(9, 9) L_(10, 10) L_(11, 11) L_(12, 12) L_(13, 13) L_(14, 14) L_(15, 15)                           //
+                         "s_waitcnt lgkmcnt(8)\n" PK_F_LO_ON(0, 0) PK_F_HI(1, 1) PK_F_LO(2, 2) PK_F_HI(3, 3) PK_F_LO(4, 4) PK_F_HI(5, 5) PK_F_LO(6, 6) PK_F_HI(7, 7) F_OFF //
+                         "s_waitcnt lgkmcnt(0)\n" PK_F_LO_ON(8, 8) PK_F_HI(9, 9) PK_F_LO(10, 10) PK_F_HI(11, 11) PK_F_LO(12, 12) PK_F_HI(13, 13) PK_F_LO(14, 14) PK_F_HI(15, 15) F_OFF
+                         : ACC_OPS
+                         :
+                         : CLOBBERS);
         }
     }
     t1 = __builtin_amdgcn_s_memtime();
@@ -188,6 +208,16 @@ void run(const char *name) {
             const uint32_t row = (uint32_t)(rand() % NROWS);
             recs[w * 16 + p] = (slot * 4u) | (1u << 8) | (row << 16);
             wts[w * 16 + p] = 0.5 + (rand() % 1000) / 1000.0;
+        }
+    std::vector<uint32_t> unpacked = recs;
+    if (MODE == 6)
+        for (size_t w = 0; w < n_waves; w++) {
+            uint32_t pk[8];
+            for (int p = 0; p < 16; p += 2) {
+                const uint32_t a = recs[w * 16 + p], b = recs[w * 16 + p + 1];
+                pk[p / 2] = ((a & 0xFFu) | ((a >> 16) << 8)) | (((b & 0xFFu) | ((b >> 16) << 8)) << 16);
+            }
+            for (int p = 0; p < 16; p++) recs[w * 16 + p] = p < 8 ? pk[p] : 0u;
         }
     uint32_t *d_recs;
     double *d_wts, *d_out;
@@ -229,7 +259,7 @@ void run(const char *name) {
                 for (int h = 0; h < 2; h++) {
                     double per = 0;
                     for (int p = 0; p < 16; p++) {
-                        const uint32_t r = recs[w * 16 + p];
+                        const uint32_t r = unpacked[w * 16 + p];
                         if ((r & 0xFFu) / 4u != (uint32_t)s) continue;
                         const uint32_t row = r >> 16, c = lane * 2u + h;
                         per += wts[w * 16 + p] * (1.0 + (double)row + (double)c / 128.0);
@@ -414,6 +444,7 @@ int main() {
     run<3>("indexed, batches of 8, DPP address");
     run<4>("indexed, B = 8, s_load + weights per chunk");
     run<5>("indexed VOP3 fma, SGPR weights, B = 8");
+    run<6>("indexed, B = 8, 16-bit packed records");
     run16<0, 16>("16 waves x 16 slots: static, B = 4");
     run16<1, 16>("16 waves x 16 slots: indexed, B = 4");
     run16<0, 12>("12 waves x 16 slots: static, B = 4");

@@ -1844,6 +1844,8 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.tile_weights_wide = value != 0.0;
         } else if (k == "tile_dense") {
             st.tile_dense = value != 0.0;
+        } else if (k == "tile_sort_slots") {
+            st.tile_sort_slots = value != 0.0;
         } else if (k == "tile_builder") {
             st.tile_builder = value != 0.0;
         } else if (k == "tile_build_waves") {

@@ -841,6 +841,8 @@ struct TileLayout {
     DevBuf<uint64_t> cmeta;        // group << 32 | visit of a chunk (weight refresh)
     DevBuf<char> ditems;           // DenseItem per workgroup item
     DevBuf<uint32_t> rtab;         // rounds: chunks | first-of-visit << 8
+    DevBuf<uint32_t> slot_order;   // dense: the slot at place p of the layout (group p / 32, accumulator p % 32), slots sorted by load; empty: place = slot
+    DevBuf<uint32_t> slot_pos;     // ... and the place of slot s
     bool separable = false;        // dense: the map's count-1 value is uo[outer] vi[inner] (tables in uo / vi / ratio_tab)
     // identity of the map the weights were evaluated under (MapOp ids are never reused); -1: none yet
     int sig_n = -1;
@@ -852,6 +854,7 @@ struct TileLayout {
     }
     bool structure_matches(const Storage &st) const {
         if (dense != tile_dense_wanted(st)) return false;
+        if (dense && (slot_order.n != 0) != (st.tile_sort_slots != 0 && n_slots > 1)) return false;
         const bool splittable = st.tile_builder != 0 && sh.K == 2u && sh.B == 4u && sh.S == 32u && sh.T == 48u; // the wave-level builder's shape
         const double want_x = splittable && st.tile_split ? st.tile_split_x : 0.0, want_min = splittable && st.tile_split ? st.tile_split_min : 0.0;
         return sh.K == st.tile_k && sh.S == st.tile_s && sh.T == st.tile_t && sh.B == st.tile_b && sh.KU == (st.tile_k == 2u && st.tile_ku ? 1u : 0u) &&
@@ -1480,7 +1483,8 @@ __global__ __launch_bounds__(64 * TL_NW) __attribute__((amdgpu_waves_per_eu(3, 3
 // out[o, :] = sum over the vector's slots (in order) of the sum over parts (in order) + overflow sum + LowRankOffset term
 // (sqz/src/low_rank_offset.rs:76-80)
 __global__ __launch_bounds__(256) void tile_finish_kernel(const double *__restrict__ parts, uint32_t n_parts, uint64_t part_stride,
-                                                          const uint32_t *__restrict__ slot_first, const double *__restrict__ ovout, uint64_t n_outer,
+                                                          const uint32_t *__restrict__ slot_first, const uint32_t *__restrict__ slot_pos,
+                                                          const double *__restrict__ ovout, uint64_t n_outer,
                                                           uint32_t l, uint32_t ldp, uint32_t ldo, double *__restrict__ out, const double *__restrict__ off_a,
                                                           uint32_t rank, const double *__restrict__ off_w, uint32_t ldw) {
     const uint32_t hp = (l + 1u) / 2u; // column pairs
@@ -1491,9 +1495,10 @@ __global__ __launch_bounds__(256) void tile_finish_kernel(const double *__restri
     d2 s = (d2){0.0, 0.0};
     const uint32_t s0 = slot_first[o], s1 = slot_first[o + 1];
     for (uint32_t sl = s0; sl < s1; sl++) {
-        d2 t = *reinterpret_cast<const d2 *>(parts + (size_t)sl * ldp + c);
+        const size_t at = slot_pos ? slot_pos[sl] : sl; // where the slot's sums lie (dense layout: slots sorted by load)
+        d2 t = *reinterpret_cast<const d2 *>(parts + at * ldp + c);
         for (uint32_t p = 1; p < n_parts; p++) {
-            const d2 u = *reinterpret_cast<const d2 *>(parts + (size_t)p * part_stride + (size_t)sl * ldp + c);
+            const d2 u = *reinterpret_cast<const d2 *>(parts + (size_t)p * part_stride + at * ldp + c);
             t.x += u.x;
             t.y += u.y;
         }
@@ -1558,8 +1563,11 @@ bool tile_layout_build_auto(Storage &st, SparseCopy &cp, hipStream_t s) {
     if (cp.tiles && cp.tiles->structure_matches(st)) return true;
     // room: records (11 B per position: row 2, count 1, weight 8) + overflow + the build's temporaries + the partial-sum buffers, and 8 GB for the solver
     const double nt = (double)((cp.n_inner + st.tile_t - 1) / st.tile_t);
-    const double need = 11.0 * 64.0 * (double)((cp.n_outer + st.tile_s - 1) / st.tile_s) * nt * ((st.tile_s + 64 / st.tile_k - 1) / (64 / st.tile_k)) +
-                        0.2 * 12.0 * (double)cp.nnz + 32.0 * (double)cp.n_outer * 64.0 + 2.0 * (double)cp.n_outer * 104.0 * 8.0 * 2.0;
+    // (dense layout: 12.5 B per position at about 1.1 positions per nonzero, 4 B per nonzero of build temporaries and the per-(group, visit) tables)
+    const double need = tile_dense_wanted(st)
+                            ? 18.0 * (double)cp.nnz + 40.0 * (double)((cp.n_outer + st.tile_s - 1) / st.tile_s + 8) * (nt + 1.0) + 2.0 * (double)cp.n_outer * 104.0 * 8.0 * 2.0
+                            : 11.0 * 64.0 * (double)((cp.n_outer + st.tile_s - 1) / st.tile_s) * nt * ((st.tile_s + 64 / st.tile_k - 1) / (64 / st.tile_k)) +
+                                  0.2 * 12.0 * (double)cp.nnz + 32.0 * (double)cp.n_outer * 64.0 + 2.0 * (double)cp.n_outer * 104.0 * 8.0 * 2.0;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
     // what the driver has free, what a stale layout gives back, and the released blocks the library keeps for reuse (device_alloc
@@ -1625,7 +1633,7 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     const uint32_t ldxov = ldx;
     // The tile kernel always reads the library's own compact copy: its staging never switches a lane off, so it reads up to two
     // tiles past the panel's end (spmm_tile_body) — the copy has that much slack behind it.
-    double *xc = st.scratch.get<double>("tile_xc", ((size_t)cp.n_inner + 2u * sh.T) * ldc);
+    double *xc = st.scratch.get<double>("tile_xc", ((size_t)cp.n_inner + 3u * sh.T) * ldc); // (the dense kernel stages one tile further: a part ends with a visit of its own)
     if (tl.unit_mode) { // unit mode: the tile kernel's panel carries the per-inner factor of the unit weight
         const uint64_t n = cp.n_inner * (uint64_t)ldc;
         hipLaunchKernelGGL(tile_scale_panel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, X, ldx, cp.n_inner, l, ldc, tl.vi.p, xc);
@@ -1686,7 +1694,7 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     if (st.prof.on) st.prof.end(st.stream);
     if (ovout && st.tile_overlap) SCANRS_HIP(hipStreamWaitEvent(st.stream, st.ev_ov, 0));
     const uint64_t n = cp.n_outer * (uint64_t)((l + 1u) / 2u);
-    hipLaunchKernelGGL(tile_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, pbuf, sh.n_parts, part_stride, tl.slot_first.p, ovout,
+    hipLaunchKernelGGL(tile_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, pbuf, sh.n_parts, part_stride, tl.slot_first.p, tl.slot_pos.p, ovout,
                        cp.n_outer, l, ldc, ldo, out, off_a, rank, off_w, ldw);
     SCANRS_HIP(hipGetLastError());
 }

@@ -579,7 +579,7 @@ def test_blocked_kernel_matches_gather_and_oracle(sa, storage):
 
 @pytest.mark.parametrize("storage", [so.CSR, so.CSC])
 @pytest.mark.parametrize("tile_k,tile_s,tile_t,tile_b,tile_ku", [(2, 28, 48, 4, 1), (2, 32, 48, 4, 1), (2, 32, 48, 4, 0), (2, 28, 48, 4, 0), (2, 32, 24, 8, 1), (3, 32, 64, 3, 0),
-                                                                 (4, 32, 96, 2, 0), (4, 28, 40, 3, 0)])
+                                                                 (4, 32, 96, 2, 0), (4, 28, 40, 3, 0), (2, 32, 48, 4, -1)])
 def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_s, tile_t, tile_b, tile_ku):
     """spmm path 3 (tiles.hip: the hybrid product — panel tiles staged through a ring of LDS buffers, K fixed record positions
     per (outer vector, visit) dealt first come first served with materialized weights, and the L2-blocked gather over the
@@ -597,7 +597,8 @@ def test_lds_staged_product_matches_gather_and_oracle(sa, storage, tile_k, tile_
         g3, _ = pair(sa, dense, storage)
         g1.set_spmm_path(1)
         g3.set_spmm_path(3).set_option("tile_k", tile_k).set_option("tile_s", tile_s).set_option("tile_t", tile_t).set_option("tile_b", tile_b)
-        g3.set_option("tile_ku", tile_ku)
+        # tile_ku -1: the dense record layout of round 5 (the default for this shape); the others: round 4's fixed positions per (slot, visit)
+        g3.set_option("tile_ku", max(tile_ku, 0)).set_option("tile_dense", 1 if tile_ku < 0 else 0)
         f = rng.random(cols) + 0.5
         fr = rng.random(rows) + 0.5
         for gm in (g1, g3):
@@ -640,6 +641,7 @@ def test_wave_level_layout_builder_equals_the_per_thread_walk(sa, tile_ku):
             for builder in (0, 1):
                 g, _ = pair(sa, dense, storage)
                 g.set_spmm_path(3).set_option("tile_builder", builder).set_option("tile_ku", tile_ku).set_option("tile_split", 0)  # one slot per vector: the walk's layout
+                g.set_option("tile_dense", 0)  # (the round-4 layout is the subject)
                 g.compose_scale_axis(1, np.linspace(0.5, 1.5, cols)).apply(sa.FN_LOG2_1P)
                 q = np.cos(np.arange(cols * 40, dtype=np.float64)).reshape(cols, 40)
                 ql = np.sin(np.arange(rows * 24, dtype=np.float64)).reshape(24, rows)
@@ -663,7 +665,7 @@ def test_one_pass_layout_build_equals_count_then_fill(sa):
             outs = []
             for one_pass in (0, 1):
                 g, _ = pair(sa, dense, storage)
-                g.set_spmm_path(3).set_option("tile_build_one_pass", one_pass).set_option("tile_split_min", 0.3)
+                g.set_spmm_path(3).set_option("tile_build_one_pass", one_pass).set_option("tile_split_min", 0.3).set_option("tile_dense", 0)
                 g.compose_scale_axis(1, np.linspace(0.5, 1.5, cols)).apply(sa.FN_LOG2_1P)
                 q = np.cos(np.arange(cols * 40, dtype=np.float64)).reshape(cols, 40)
                 ql = np.sin(np.arange(rows * 24, dtype=np.float64)).reshape(24, rows)
@@ -683,12 +685,42 @@ def test_wide_weight_refresh_equals_the_one_position_form(sa):
             outs = []
             for wide in (0, 1):
                 g, _ = pair(sa, dense, storage)
-                g.set_spmm_path(3).set_option("tile_weights_wide", wide)
+                g.set_spmm_path(3).set_option("tile_weights_wide", wide).set_option("tile_dense", 0)
                 g.compose_scale_axis(1, np.linspace(0.5, 1.5, cols)).apply(sa.FN_LOG2_1P).compose_scale_axis(0, np.linspace(0.7, 1.3, rows))
                 q = np.cos(np.arange(cols * 40, dtype=np.float64)).reshape(cols, 40)
                 ql = np.sin(np.arange(rows * 24, dtype=np.float64)).reshape(24, rows)
                 outs.append((g.dot(q), g.rdot(ql)))
             assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), (rows, cols, fill, storage)
+
+
+def test_dense_record_layout_equals_round4_layout_and_is_placement_independent(sa):
+    """Round 5: the records of a (wave, visit) are a packed list (tiles_dense.inc) and the accumulator of a record is picked at run time.
+    Against the round-4 layout (fixed positions per slot and visit) on the same matrices: the same products to rounding (the order
+    of the additions inside a slot is the same — a vector's nonzeros in index order — but the split between tile kernel and overflow
+    gather differs); with the slots placed in the order of their load and in vector order: BIT FOR BIT (placement moves a slot to
+    another wave, never its records). Shapes around the group / item / tile edges, several parts, empty vectors, vectors with several
+    slots, vectors without a slot, counts above 255 (overflow part), rounds of more than 4 chunks (dense spots)."""
+    rng = np.random.default_rng(95)
+    for rows, cols, fill, vmax in ((1, 1, 1.0, 3), (31, 95, 0.5, 3), (33, 97, 0.9, 2), (64, 48, 1.0, 2), (65, 4800, 0.6, 4), (257, 2000, 0.05, 400),
+                                   (700, 1000, 0.03, 3), (97, 20000, 0.02, 3), (2000, 193, 0.2, 300), (300, 400, 0.004, 2), (130, 9000, 0.3, 3), (520, 3000, 0.9, 5)):
+        dense = random_counts(rng, rows, cols, fill, vmax)
+        dense[rng.random(rows) < 0.2, :] = 0
+        sparse_rows = rng.random(rows) < 0.3  # far below one nonzero per tile: no slot in the row-major layout
+        dense[sparse_rows, :] *= (rng.random((int(sparse_rows.sum()), cols)) < 0.02)
+        dense[0, 0] = 1
+        for storage in (so.CSR, so.CSC):
+            outs = []
+            for dense_layout, sort_slots in ((0, 0), (1, 0), (1, 1)):
+                g, _ = pair(sa, dense, storage)
+                g.set_spmm_path(3).set_option("tile_dense", dense_layout).set_option("tile_sort_slots", sort_slots).set_option("tile_split_min", 0.3)
+                g.compose_scale_axis(1, np.linspace(0.5, 1.5, cols)).apply(sa.FN_LOG2_1P).compose_scale_axis(0, np.linspace(0.7, 1.3, rows))
+                q = np.cos(np.arange(cols * 40, dtype=np.float64)).reshape(cols, 40)
+                ql = np.sin(np.arange(rows * 24, dtype=np.float64)).reshape(24, rows)
+                outs.append((g.dot(q), g.rdot(ql)))
+                assert np.array_equal(outs[-1][0], g.dot(q))  # repeatable
+            assert_close(outs[1][0], outs[0][0], rtol=1e-12, atol=1e-11)
+            assert_close(outs[1][1], outs[0][1], rtol=1e-12, atol=1e-11)
+            assert np.array_equal(outs[1][0], outs[2][0]) and np.array_equal(outs[1][1], outs[2][1]), (rows, cols, fill, storage)
 
 
 def test_invalid_sparse_input_is_refused(sa):
@@ -750,14 +782,15 @@ def test_dense_outer_vectors_get_several_slots(sa):
     m.sort_indices()
     assert m.nnz > (1 << 24)
     mk = lambda: sa.AdaptiveMat.from_csmat(cells, genes, sa.CSR, m.indptr.astype(np.uint64), m.indices.astype(np.uint32), m.data.astype(np.uint32))
-    g, g_unsplit, ref = mk(), mk(), mk()
+    g, g_unsplit, g_dense_unsplit, ref = mk(), mk(), mk(), mk()
     g.set_option("tile_split_min", 0.3)  # the 2 950 sparse genes of this matrix sit at 0.48 nonzeros per tile, right at the default limit below which a vector gets no slot
-    g_unsplit.set_option("tile_split", 0)
+    g_unsplit.set_option("tile_split", 0).set_option("tile_dense", 0)  # round 4's layout: two positions per slot and visit
+    g_dense_unsplit.set_option("tile_split", 0)  # round 5's dense records have no capacity per slot: one slot per vector works too (43 records per visit into one accumulator)
     ref.set_spmm_path(2)
     x = rng.standard_normal((genes, 40))
     y = rng.standard_normal((40, cells))
     outs = {}
-    for name, h in (("auto", g), ("unsplit", g_unsplit), ("gather", ref)):
+    for name, h in (("auto", g), ("unsplit", g_unsplit), ("dense_unsplit", g_dense_unsplit), ("gather", ref)):
         h.profile_enable(True)
         for _ in range(2):  # the auto path builds a layout on the second sighting of a map
             outs[name] = (h.dot(x), h.rdot(y))
@@ -772,7 +805,9 @@ def test_dense_outer_vectors_get_several_slots(sa):
     assert any(k.startswith("spmm_tile_kernel/long-outer") for k in prof), prof
     assert not any(k.startswith("spmm_tile_kernel/short-outer") for k in prof), prof  # one slot per vector: refused as before
     assert any(k.startswith("spmm_gather2d_kernel<1>/short-outer") for k in prof), prof
-    for name in ("auto", "unsplit"):
+    prof = outs["dense_unsplit_prof"]
+    assert any(k.startswith("spmm_tile_kernel/long-outer") for k in prof) and any(k.startswith("spmm_tile_kernel/short-outer") for k in prof), prof
+    for name in ("auto", "unsplit", "dense_unsplit"):
         for a, b in zip(outs[name], outs["gather"]):
             assert np.max(np.abs(a - b)) <= 1e-11 * np.max(np.abs(b))
 

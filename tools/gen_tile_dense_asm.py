@@ -12,8 +12,8 @@ Register map (all clobbered by the asm statement; the compiler keeps v0-v25 and 
   v[64:127]   panel rows of 16 positions in flight (4 registers each)
   v[48:63]    their LDS addresses
   v[40:47]    weights of the round's 4 chunks: lane L holds weight L % 16 of the chunk (one register pair per chunk)
-  v[38:39]    this lane's address in the weight stream (END of the current round's weights + 8 (L % 16)); v[28:29] the same for the next round
-  v26 4 x lane, v27 sink of the touch load
+  v[38:39]    this lane's address in the weight stream: 8 L behind the END of the NEXT round's weights
+  v26 4 x lane, v27 sink of the touch load, v30 4 x (lane % 16); v[28:29] the NEXT round's 64 weights as loaded (lane L: weight L)
   v36 ring base of the lane (LDS address of its column pair in ring row 0), v37 row pitch in bytes
   v[31:35]    LDS-DMA source offsets of the wave's 5 staging chunks
   s[36:99]    the round's records: bits 7:0 = 4 x slot (the VGPR index), 15:8 = raw count (weight refresh only), 31:16 = ring row
@@ -93,20 +93,12 @@ def dma(i, out):
     out.append(f"global_load_lds_dwordx4 v{31 + i}, s[24:25]")
 
 
-def reload_w(c, out):
-    """weights of chunk slot c for the NEXT round (v[28:29] = this lane's address behind the next round's weights)"""
-    if "w" in SKIP:
-        out.append("s_nop 0")
-        return
-    out.append(f"global_load_dwordx2 v[{W0 + 2 * c}:{W0 + 2 * c + 1}], v[28:29], off offset:{-128 * (4 - c)}")
-
-
 def gen():
-    """Vector-memory operations of a round, in issue order: [touch][staging x 5][weight reloads of chunk slots 0, 1, 2, 3 for the NEXT round].
-    A slot's weights are reloaded as soon as the round has used them (behind F of its second batch; slots the round does not enter:
-    at its start), so before the first F of slot c in the next round exactly 3 - c + 1 + 5 + c = 9 younger operations exist whatever the
-    two rounds' lengths: s_waitcnt vmcnt(9). A round that is not the first of its visit issues its five staging loads too (the tile
-    staged last once more: same bytes, same place) so that the count holds."""
+    """Vector memory per round: one touch load (next round's records into L2), ONE weight load for the next round (lane L takes
+    weight L of the 64 positions that END at the round's last one: 512 contiguous bytes; four loads of 16 replicated weights each
+    cost four times the return bytes on the CU's fetch path, which the staging shares: -1.7 ms per pass without them), five staging
+    loads. All of it is issued at the round's start and waited for (vmcnt(0)) at the next round's start. The weights reach the
+    form the FMAs want - every row of 16 lanes holds the 16 weights of ONE chunk - by eight ds_bpermute_b32 (LDS crossbar)."""
     o = []
     a = o.append
     # ---- inputs into the fixed registers ----
@@ -126,6 +118,7 @@ def gen():
     a("v_mov_b32 v36, %[ring]")
     a("v_mov_b32 v37, %[rowb]")
     a("v_mov_b32 v26, %[lane4]")
+    a("v_and_b32 v30, 60, v26")  # 4 (lane % 16): ds_bpermute address of this lane's weight inside a chunk
     for i in range(5):
         a(f"v_mov_b32 v{31 + i}, %[voff{i}]")
     a("s_cmp_eq_u32 s26, 0")
@@ -133,19 +126,15 @@ def gen():
     a("s_load_dwordx2 s[28:29], s[22:23], 0x0")  # headers of rounds 0 and 1
     a("s_waitcnt lgkmcnt(0)")
     a("s_mov_b32 s34, s29")
-    # weights of round 0 (behind the five staging loads of the item's first tile: the pattern of a round)
+    # weights of round 0
     a("s_and_b32 s29, s28, 0xff")
     a("s_lshl_b32 s30, s29, 7")
-    a("v_add_co_u32 v28, vcc, s30, v38")
-    a("v_addc_co_u32 v29, vcc, 0, v39, vcc")
-    for c in range(4):
-        reload_w(c, o)
+    a("v_add_co_u32 v38, vcc, s30, v38")
+    a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
+    a("global_load_dwordx2 v[28:29], v[38:39], off offset:-512")
     a("LROUND%=:")
-    a("v_mov_b32 v38, v28")
-    a("v_mov_b32 v39, v29")
     a("s_and_b32 s29, s28, 0xff")   # chunks of this round
     a("s_and_b32 s100, s34, 0xff")  # ... of the next one
-
     a("s_lshl_b32 s30, s29, 6")
     a("s_add_u32 s20, s20, s30")
     a("s_addc_u32 s21, s21, 0")
@@ -160,12 +149,17 @@ def gen():
     a("s_add_u32 s22, s22, 4")
     a("s_addc_u32 s23, s23, 0")
     a("s_lshl_b32 s30, s100, 7")
-    a("v_add_co_u32 v28, vcc, s30, v38")
-    a("v_addc_co_u32 v29, vcc, 0, v39, vcc")
+    # This round's weights must be there, and the tile staged during the visit BEFORE the last one (first read now); the five
+    # staging loads of the last round - if it was the first of its visit (bit 9) they are the youngest operations - may still be in flight
+    a("s_bitcmp1_b32 s28, 9")
+    a("s_cbranch_scc0 LW0%=")
+    a("s_waitcnt vmcnt(5)")
+    a("s_branch LW1%=")
+    a("LW0%=:")
+    a("s_waitcnt vmcnt(0)")
+    a("LW1%=:")
     a("s_bitcmp1_b32 s28, 8")
     a("s_cbranch_scc0 LNOBAR%=")
-    # first round of a visit: the tile staged during the last visit has landed for every wave; the next one goes to the buffer behind it
-    a("s_waitcnt vmcnt(4)")
     if "b" not in SKIP:
         a("s_barrier")
     a("s_add_u32 s24, s24, s27")
@@ -174,8 +168,17 @@ def gen():
     a("s_cmp_eq_u32 s35, s19")
     a("s_cselect_b32 s35, s18, s35")
     a("LNOBAR%=:")
-    a("global_load_dword v27, v26, s[20:21]" if "t" not in SKIP else "s_nop 0")  # touch: the next round's records into L2 (its scalar loads then hit there)
-    a("s_waitcnt lgkmcnt(0)")
+    # the round's weights: row r of the loaded register pair holds chunk r's 16 weights -> four pairs in which EVERY row holds one chunk's
+    for c in range(4):
+        a(f"ds_bpermute_b32 v{W0 + 2 * c}, v30, v28 offset:{64 * c}")
+        a(f"ds_bpermute_b32 v{W0 + 2 * c + 1}, v30, v29 offset:{64 * c}")
+    a("global_load_dword v27, v26, s[20:21]" if "t" not in SKIP else "s_nop 0")  # touch: the next round's records into L2
+    a("v_add_co_u32 v38, vcc, s30, v38")  # -> behind the next round's weights
+    a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
+    a("s_waitcnt lgkmcnt(0)")  # records, headers, the permuted weights (v[28:29] is free again)
+    a("global_load_dwordx2 v[28:29], v[38:39], off offset:-512" if "w" not in SKIP else "s_nop 0")
+    a("s_bitcmp1_b32 s28, 8")
+    a("s_cbranch_scc0 LNODMA%=")
     a("s_cmp_eq_u32 s29, 4")
     a("s_cbranch_scc1 LPRO0%=")
     a("s_cmp_eq_u32 s29, 3")
@@ -187,44 +190,53 @@ def gen():
     # an empty round (a visit nobody has work in yet: the first two of a part)
     for i in range(5):
         dma(i, o)
-    for c in range(4):
-        reload_w(c, o)
     a("s_branch LEND%=")
-    # prologues: rows of the first two batches of the round, the staging loads between them, then into the steady stream
-    for c in (3, 2, 1, 0):
-        a(f"LPRO{c}%=:")
-        blocks = []
-        for b in (2 * c, 2 * c + 1):
-            blk = []
-            for j in range(BP):
-                p = b * BP + j
-                blk.append(f"v_mad_u32_u16 {ad(p)}, {rec(p)}, v37, v36 op_sel:[1,0,0,0]")
-            blocks.append(blk)
-            blk = []
-            for j in range(BP):
-                p = b * BP + j
-                blk.append(f"ds_read_b128 {xq(p)}, {ad(p)}")
-            blocks.append(blk)
-        for i, blk in enumerate(blocks):
-            o.extend(blk)
-            dma(i, o)
-        dma(4, o)
-        for cc in range(c):
-            reload_w(cc, o)
-        if c != 0:
-            a(f"s_branch LS{2 * c}%=")
+    # a later round of a long visit: nothing to stage
+    a("LNODMA%=:")
+    a("s_cmp_eq_u32 s29, 4")
+    a("s_cbranch_scc1 LQRO0%=")
+    a("s_cmp_eq_u32 s29, 3")
+    a("s_cbranch_scc1 LQRO1%=")
+    a("s_cmp_eq_u32 s29, 2")
+    a("s_cbranch_scc1 LQRO2%=")
+    a("s_cmp_eq_u32 s29, 1")
+    a("s_cbranch_scc1 LQRO3%=")
+    a("s_branch LEND%=")
+    # prologues: rows of the first two batches of the round (with the staging loads between them), then into the steady stream
+    for with_dma in (False, True):
+        for c in (3, 2, 1, 0):
+            a(f"L{'P' if with_dma else 'Q'}RO{c}%=:")
+            blocks = []
+            for b in (2 * c, 2 * c + 1):
+                blk = []
+                for j in range(BP):
+                    p = b * BP + j
+                    blk.append(f"v_mad_u32_u16 {ad(p)}, {rec(p)}, v37, v36 op_sel:[1,0,0,0]")
+                blocks.append(blk)
+                blk = []
+                for j in range(BP):
+                    p = b * BP + j
+                    blk.append(f"ds_read_b128 {xq(p)}, {ad(p)}")
+                blocks.append(blk)
+            for i, blk in enumerate(blocks):
+                o.extend(blk)
+                if with_dma:
+                    dma(i, o)
+            if with_dma:
+                dma(4, o)
+            if not (with_dma and c == 0):
+                a(f"s_branch LS{2 * c}%=")
     for b in range(NB):
         a(f"LS{b}%=:")
-        if b % 2 == 0:
-            a("s_waitcnt vmcnt(9)" if not (SKIP & {"w", "d", "t"}) else "s_nop 0")
         a("s_waitcnt lgkmcnt(8)" if b < NB - 1 else "s_waitcnt lgkmcnt(0)")
         batch_F(b, o)
-        if b % 2 == 1:
-            reload_w(b // 2, o)
         if b + 2 < NB:
             batch_AL(b + 2, o)
     a("LEND%=:")
+    a("s_and_b32 s30, s28, 0x100")
+    a("s_lshl_b32 s30, s30, 1")
     a("s_mov_b32 s28, s34")
+    a("s_or_b32 s28, s28, s30")  # bit 9: the round before was the first of its visit (it staged a tile)
     a("s_mov_b32 s34, s101")
     a("s_sub_u32 s26, s26, 1")
     a("s_cmp_lg_u32 s26, 0")

@@ -50,7 +50,7 @@ def arrivals(indptr, indices, n_inner, x_target, x_min, order="natural"):
     return a, int((~keep).sum()), n_slots
 
 
-def simulate(a, g, policy, alpha=1.0, tpp=None):
+def simulate(a, g, policy, alpha=1.0, tpp=None, delay=False):
     """a[groups, tiles] -> (positions incl. padding, nonzeros, visits, sum of N_v, dropped)"""
     ng, nt = a.shape
     ni = (ng + NW - 1) // NW
@@ -65,7 +65,7 @@ def simulate(a, g, policy, alpha=1.0, tpp=None):
     for v in range(nt):
         last = (v + 1) % tpp == 0 or v == nt - 1
         new = a[:, :, v].astype(np.int64)
-        avail = new + mid + old
+        avail = (mid + old) if (delay and not last) else new + mid + old  # delay: a tile staged during visit v is first read in visit v + 1
         forced = avail if last else old
         need = -(-forced.max(axis=1) // g)  # chunks forced by the deadlines
         if policy == "eager":
@@ -83,7 +83,11 @@ def simulate(a, g, policy, alpha=1.0, tpp=None):
         d = np.minimum(old, cap); cap = cap - d; old = old - d
         assert not old.any()
         d = np.minimum(mid, cap); cap = cap - d; mid = mid - d
-        d = np.minimum(new, cap); new = new - d
+        if delay and not last:
+            d = 0 * new
+        else:
+            d = np.minimum(new, cap)
+        new = new - d
         old, mid = mid, new
         if last:
             assert not old.any() and not mid.any()
@@ -111,7 +115,8 @@ def main():
             for g in (16, 8, 4):
                 for policy, alpha in (("eager", 1), ("lazy", 1), ("mean", 1.0), ("mean", 1.05), ("q75", 1)):
                     pos, n, visits, chunks = simulate(a, g, policy, alpha, tpp)
-                    print(f"   g {g:2d} {policy:5s} a {alpha:4.2f}: positions per tile-served nonzero {pos / n:.3f}; per all nonzeros {pos / nnz:.3f}; chunks per visit {chunks / visits:.2f}")
+                    pos2, _, _, _ = simulate(a, g, policy, alpha, tpp, delay=True)
+                    print(f"   g {g:2d} {policy:5s} a {alpha:4.2f}: positions per tile-served nonzero {pos / n:.3f}; per all nonzeros {pos / nnz:.3f}; chunks per visit {chunks / visits:.2f}; tiles read one visit late: {pos2 / n:.3f}")
 
 
 if __name__ == "__main__":
