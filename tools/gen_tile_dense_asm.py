@@ -8,9 +8,10 @@ compiler-scheduled instruction may sit between s_set_gpr_idx_on and _off), and L
 be counted by hand. A generator keeps the numbering honest; the output is committed next to it.
 
 Register map (all clobbered by the asm statement; the compiler keeps v0-v25 and s0-s16):
-  v[128:255]  accumulators: slot q = v[128 + 4 q : 128 + 4 q + 3] (two f64: columns 2 lane, 2 lane + 1)
-  v[64:127]   panel rows of 16 positions in flight (4 registers each)
-  v[48:63]    their LDS addresses
+  v[88:215]   accumulators: slot q = v[88 + 4 q : 88 + 4 q + 3] (two f64: columns 2 lane, 2 lane + 1)
+  v[56:87]    panel rows of 8 positions in flight (4 registers each)
+  v[48:55]    their LDS addresses
+  (216 registers in all: two tile waves per SIMD leave 80 for a wave of the overflow gather, which runs beside this kernel)
   v[40:47]    weights of the round's 4 chunks: lane L holds weight L % 16 of the chunk (one register pair per chunk)
   v[38:39]    this lane's address in the weight stream: 8 L behind the END of the NEXT round's weights
   v26 4 x lane, v27 sink of the touch load, v30 4 x (lane % 16); v[28:29] the NEXT round's 64 weights as loaded (lane L: weight L)
@@ -26,28 +27,29 @@ import sys
 
 SKIP = set((os.environ.get("GEN_SKIP") or "").split(","))  # timing experiments (wrong results): w = weights, r = records, b = barrier, d = staging
 
-NB = 8            # batches per round
-BP = 8            # positions per batch
-ACC0 = 128
-X0 = 64
+BP = int(os.environ.get("GEN_BP") or 4)   # positions per batch (two batches of row reads in flight); 8 is as fast but takes 40 registers more
+NB = 64 // BP     # batches per round
+BPC = 16 // BP    # batches per chunk
+ACC0 = 88
+X0 = 56
 A0 = 48
 W0 = 40
 R0 = 36
 
 
 def xr(p, half):
-    k = p % 16
+    k = p % (2 * BP)
     b = X0 + 4 * k + 2 * half
     return f"v[{b}:{b + 1}]"
 
 
 def xq(p):
-    k = p % 16
+    k = p % (2 * BP)
     return f"v[{X0 + 4 * k}:{X0 + 4 * k + 3}]"
 
 
 def ad(p):
-    return f"v{A0 + p % 16}"
+    return f"v{A0 + p % (2 * BP)}"
 
 
 def rec(p):
@@ -207,7 +209,7 @@ def gen():
         for c in (3, 2, 1, 0):
             a(f"L{'P' if with_dma else 'Q'}RO{c}%=:")
             blocks = []
-            for b in (2 * c, 2 * c + 1):
+            for b in (BPC * c, BPC * c + 1):
                 blk = []
                 for j in range(BP):
                     p = b * BP + j
@@ -225,10 +227,10 @@ def gen():
             if with_dma:
                 dma(4, o)
             if not (with_dma and c == 0):
-                a(f"s_branch LS{2 * c}%=")
+                a(f"s_branch LS{BPC * c}%=")
     for b in range(NB):
         a(f"LS{b}%=:")
-        a("s_waitcnt lgkmcnt(8)" if b < NB - 1 else "s_waitcnt lgkmcnt(0)")
+        a(f"s_waitcnt lgkmcnt({BP})" if b < NB - 1 else "s_waitcnt lgkmcnt(0)")
         batch_F(b, o)
         if b + 2 < NB:
             batch_AL(b + 2, o)
