@@ -843,6 +843,7 @@ struct TileLayout {
     DevBuf<uint32_t> rtab;         // rounds: chunks | first-of-visit << 8
     DevBuf<uint32_t> slot_order;   // dense: the slot at place p of the layout (group p / 32, accumulator p % 32), slots sorted by load; empty: place = slot
     DevBuf<uint32_t> slot_pos;     // ... and the place of slot s
+    DevBuf<double> w_place, w_inner; // dense, separable map: the weight's factor by place ([8] per place when the outer side owns the nonlinear links) / [8] per inner position otherwise
     bool separable = false;        // dense: the map's count-1 value is uo[outer] vi[inner] (tables in uo / vi / ratio_tab)
     // identity of the map the weights were evaluated under (MapOp ids are never reused); -1: none yet
     int sig_n = -1;

@@ -10,7 +10,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
 rows.sort()
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 11
-tiles = [i for i, r in enumerate(rows) if "spmm_tile_kernel" in r[2]]
+tiles = [i for i, r in enumerate(rows) if ("spmm_tile_kernel" in r[2] or "spmm_tile_dense_kernel" in r[2])]
 first = tiles[-per]
 # start at the normalize in front of the step: look back for the row_reduce (library sizes)
 i0 = first
@@ -39,7 +39,7 @@ for s, e, n, q, c, busy in merged:
         continue
     print(f"{(s - t0) / 1e6:9.3f} .. {(e - t0) / 1e6:9.3f}  q{q:>3}  x{c:<4d} busy {busy / 1e6:8.3f} ms  {n}")
 # union of tile-kernel intervals vs the rest
-tile_iv = [(s, e) for s, e, n, q in out if "spmm_tile_kernel" in n]
+tile_iv = [(s, e) for s, e, n, q in out if "spmm_tile_kernel" in n or "spmm_tile_dense_kernel" in n]
 tt = sum(e - s for s, e in tile_iv)
 print(f"tile kernels: {tt / 1e6:.2f} ms in {len(tile_iv)} launches; everything else on the critical path: {(rows[-1][1] - t0 - tt) / 1e6:.2f} ms")
 gaps = []
