@@ -36,6 +36,23 @@ PMC_PROFILE = "r04e_pmc_traffic.json"  # committed PMC passes (separate --pmc ru
 KERNEL_SOURCES = ("scan-rs_amd/csrc/tiles.hip", "scan-rs_amd/csrc/kernels.hip", "scan-rs_amd/csrc/device_map.hpp")
 
 
+SHARDED_KERNEL_PREFIXES = ("spmm_", "tile_weights", "row_reduce", "col_moments", "col_sums", "materialize_map_values")  # work over the rank's own cells only
+
+
+def split_replicated_sharded(ms_full, ms_part, frac):
+    """A step on a cell range of share f of the matrix takes t(f) = replicated + sharded * f: what does not shrink with the range
+    (gene-side chains, the q x q eigenproblem, U's delivery) and what does (sparse passes, cell-side dense work, V's delivery).
+    From the step on the whole matrix (f = 1) and on a part of it (f = frac): the two terms at f = 1, clamped to [0, ms_full]."""
+    sharded = (ms_full - ms_part) / (1.0 - frac)
+    sharded = min(max(sharded, 0.0), ms_full)
+    return {"replicated_ms_per_step": round(ms_full - sharded, 2), "sharded_ms_per_step": round(sharded, 2)}
+
+
+def sharded_share_of_rank(sharded_ms, nnz_rank, nnz_total):
+    """the sharded term of one rank of a cell-range partition: the ranges are cut by nonzeros (scanrs_plan_shards)"""
+    return sharded_ms * nnz_rank / max(1, nnz_total)
+
+
 def kernel_source_hash():
     """sha256 over the sources of the sparse kernels: the committed PMC file carries the hash of the sources it was measured on, and
     `traffic` is only quoted from it when the sources loaded now are the same (profiles/summarize.py writes it)."""
@@ -62,13 +79,17 @@ def parse():
     ap.add_argument("--cpu-cells-all", type=int, default=100000, help="cells of the all-core CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reserve", action="store_true", help="do not reserve device memory ahead of the handle (scanrs_reserve_device_memory)")
-    ap.add_argument("--reserve-bytes-per-nnz", type=float, default=72.0, help="size of that reserve per nonzero of the shard")
+    ap.add_argument("--reserve-bytes-per-nnz", type=float, default=66.0,
+                    help="size of that reserve per nonzero of the shard (+ 1 GB): what the handle keeps (57 B per nonzero) + part of the transposition's temporaries")
     ap.add_argument("--no-heavy-tailed", action="store_true", help="skip the second, clearly labelled measurement on the heavy-tailed gene profile")
     ap.add_argument("--no-host-delivery", action="store_true", help="leave U and V in HBM in every step (value is then the device-resident rate)")
     ap.add_argument("--f32-panels", action="store_true",
                     help="opt-in fast mode: gathered panels rounded to f32, f64 sums (NOT the headline configuration)")
     ap.add_argument("--spmm-path", type=int, default=0, help="0 auto, 1 plain gather, 2 L2-blocked gather")
-    ap.add_argument("--also-randsvd", action="store_true", help="also time one RandSvd{10, 2} PCA (SURVEY.md §8d: reported alongside)")
+    ap.add_argument("--also-randsvd", action="store_true", help="(default at 1 GPU since round 5) also time one RandSvd{10, 2} PCA (SURVEY.md §8d: reported alongside)")
+    ap.add_argument("--no-randsvd", action="store_true", help="skip the RandSvd measurement")
+    ap.add_argument("--no-irlba", action="store_true", help="skip the IRLBA measurement")
+    ap.add_argument("--no-split-probe", action="store_true", help="skip the replicated / sharded split of the step (a second matrix with half the cells)")
     ap.add_argument("--also-irlba", action="store_true",
                     help="also time one Irlba{tol 1e-4, 50} run on the log-normalised (un-centred) matrix, the only input irlba.rs takes")
     ap.add_argument("--also-knn", type=int, default=0, metavar="K", help="also time scanrs_knn_device (K neighbours) on the device-resident scores")
@@ -284,7 +305,7 @@ def main():
     # (profiles/microbench/alloc_probe2: 0.24 s per 8 GB) — environment, not the path measured here; config.reserve_s reports it.
     t_r = time.perf_counter()
     if not args.no_reserve:
-        sa.reserve_device_memory(int(args.reserve_bytes_per_nnz * nnz_local) + (2 << 30))
+        sa.reserve_device_memory(int(args.reserve_bytes_per_nnz * nnz_local) + (1 << 30))
     t_reserve = time.perf_counter() - t_r
     # genes x cells (Cell Ranger orientation), stored cell-major = CSC
     dbg(f"shard [{lo}, {hi}) nnz {nnz_local}: create handle")
@@ -487,6 +508,13 @@ def main():
         nnz_ranks = [nnz_local]
     nnz_global = sum(nnz_ranks)
     prof = mat.profile_get()
+    # per rank: the time of the kernels that work the rank's own cells (events pass), to be read against per_rank_nnz
+    my_sharded_kernel_ms = sum(v_["total_ms"] for k_, v_ in prof.items() if k_.startswith(SHARDED_KERNEL_PREFIXES) and "gather2d_ov" not in k_) / args.steps
+    rank_sharded_kernel_ms = [my_sharded_kernel_ms]
+    if dist is not None:
+        tl2 = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tl2, torch.tensor([my_sharded_kernel_ms], dtype=torch.float64))
+        rank_sharded_kernel_ms = [float(x.item()) for x in tl2]
     ms_per_step = elapsed / args.steps * 1e3
     value = args.cells * args.steps / elapsed
 
@@ -506,21 +534,29 @@ def main():
         knn_ms = (time.perf_counter() - t0) * 1e3
 
     randsvd_ms = None
-    if args.also_randsvd and world == 1:
+    randsvd_kernels = irlba_kernels = None
+    if not args.no_randsvd and world == 1:
         import ctypes
 
         s_out = np.zeros(args.k)
         mat.reset_map()
         sa.normalize(mat, sa.Normalization.CellRanger)
+        run_rand = lambda: sa._check(sa._lib.scanrs_pca_rand(mat._h, ctypes.c_uint32(args.k), ctypes.c_double(10.0), ctypes.c_uint32(2), ctypes.c_uint64(0),
+                                                             None, None, s_out.ctypes.data_as(ctypes.c_void_p), None))
         barrier()
         t0 = time.perf_counter()
-        sa._check(sa._lib.scanrs_pca_rand(mat._h, ctypes.c_uint32(args.k), ctypes.c_double(10.0), ctypes.c_uint32(2), ctypes.c_uint64(0),
-                                          None, None, s_out.ctypes.data_as(ctypes.c_void_p), None))
+        run_rand()
         barrier()
         randsvd_ms = (time.perf_counter() - t0) * 1e3
+        mat.profile_reset()  # which kernels it ran: a second call with the per-launch events on (not the timed one)
+        mat.profile_enable(True)
+        run_rand()
+        barrier()
+        randsvd_kernels = {k_: round(v_["total_ms"], 2) for k_, v_ in sorted(mat.profile_get().items()) if v_["total_ms"] >= 0.5}
+        mat.profile_enable(False)
 
     irlba_ms = irlba_mprod = None
-    if args.also_irlba and world == 1:
+    if not args.no_irlba and world == 1:
         import ctypes
 
         s_out = np.zeros(args.k)
@@ -528,13 +564,58 @@ def main():
         sa.log_normalize_with_size_factor(mat, None, sa.FN_LOG2_1P)
         mp = ctypes.c_uint32()
         u_out, v_out = np.zeros((args.genes, args.k)), np.zeros((n_local, args.k))  # irlba returns host arrays (irlba.rs:71-76)
+        run_irlba = lambda: sa._check(sa._lib.scanrs_pca_irlba(mat._h, ctypes.c_uint32(args.k), ctypes.c_double(1e-4), ctypes.c_uint32(50), None, None,
+                                                               u_out.ctypes.data_as(ctypes.c_void_p), s_out.ctypes.data_as(ctypes.c_void_p),
+                                                               v_out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(mp)))
         barrier()
         t0 = time.perf_counter()
-        sa._check(sa._lib.scanrs_pca_irlba(mat._h, ctypes.c_uint32(args.k), ctypes.c_double(1e-4), ctypes.c_uint32(50), None, None,
-                                           u_out.ctypes.data_as(ctypes.c_void_p), s_out.ctypes.data_as(ctypes.c_void_p),
-                                           v_out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(mp)))
+        run_irlba()
         barrier()
         irlba_ms, irlba_mprod = (time.perf_counter() - t0) * 1e3, int(mp.value)
+        mat.profile_reset()
+        mat.profile_enable(True)
+        run_irlba()
+        barrier()
+        irlba_kernels = {k_: round(v_["total_ms"], 2) for k_, v_ in sorted(mat.profile_get().items()) if v_["total_ms"] >= 0.5}
+        mat.profile_enable(False)
+
+    # ---- replicated / sharded split of the step, visible from one GPU ----------------------------------------------------------------
+    # The same step on a second matrix with HALF the cells (same model, same genes): t(1/2) against t(1) gives the term that shrinks
+    # with the cell range and the one that does not - the floor of the step on 8 GPUs is replicated + sharded / 8 + the exchanges.
+    split = None
+    if world == 1 and not args.no_split_probe and args.cells >= 4096:
+        dbg("split probe")
+        hc = args.cells // 2
+        pip_, pix_, pvv_ = synth_counts_torch(hc, args.genes, args.density, args.seed, dev)
+        pmat = sa.AdaptiveMat.from_device(args.genes, hc, sa.CSC, pip_.data_ptr(), pix_.data_ptr(), pvv_.data_ptr())
+        p_nnz = int(pip_[-1].item())
+        del pip_, pix_, pvv_
+        for kv in args.opt:
+            key, val = kv.split("=")
+            pmat.set_option(key, float(val))
+        out_vp = np.zeros((hc, args.k))
+        out_vp.fill(0.0)
+
+        def pstep():
+            pmat.reset_map()
+            sa.normalize(pmat, sa.Normalization.CellRanger)
+            return bk.run_pca(pmat, args.k, out=(out_u, out_vp)) if not args.no_host_delivery else bk.run_pca_device(pmat, args.k)
+
+        pstep()
+        pstep()
+        torch.cuda.synchronize()
+        pmat.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pstep()
+        torch.cuda.synchronize()
+        pmat.sync()
+        ms_half = (time.perf_counter() - t0) / args.steps * 1e3
+        split = split_replicated_sharded(elapsed / args.steps * 1e3, ms_half, p_nnz / max(1, nnz_local))
+        split["split_probe"] = {"cells": hc, "nnz": p_nnz, "ms_per_step": round(ms_half, 2),
+                                "method": "t(f) = replicated + sharded f from the step at f = 1 and at f = nnz share of a second matrix with half the cells"}
+        split["floor_8_gpus_ms_per_step"] = round(split["replicated_ms_per_step"] + split["sharded_ms_per_step"] / 8.0, 2)
+        del pmat
 
     # ---- the same step on a heavy-tailed gene profile (NOT the headline) ----------------------------------------------------------
     # SURVEY.md §8d's synthetic has a nearly flat gene popularity; a real 10x matrix has a few thousand genes detected in most cells and
@@ -646,6 +727,9 @@ def main():
                 "frac": round(lds_per_launch / avg_s / 1e12 / LDS_PEAK_TBS, 4) if avg_s > 0 and lds_per_launch else None,
                 "frac_of_survey_estimate_78.6": round(lds_per_launch / avg_s / 1e12 / LDS_SURVEY_TBS, 4) if avg_s > 0 and lds_per_launch else None,
                 "occupancy_from_counters": occupancy,
+                # bytes_per_launch counts the rows of SERVED nonzeros only (round 5; before: every record position, padding included)
+                "positions_per_served_nonzero": round(mat.counter("tile_positions") / max(1, mat.counter("tile_served_nonzeros")), 4),
+                "overflow_share_of_nonzeros": round(mat.counter("tile_overflow_nonzeros") / max(1, 2 * nnz_local), 5),
             },
             "kernel_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
             "launches_per_step_all": {k: round(v["launches"] / args.steps, 1) for k, v in sorted(prof.items())},
@@ -735,6 +819,9 @@ def main():
                 "first_call_cells_per_s": round(args.cells / t_setup, 1),
                 "first_call_includes": "handle creation from device-resident arrays (copy, validation, work items), normalize, PCA with host delivery; inside: the transposed (gene-major) copy and the tile layouts of the hybrid product (both orientations). Not included: scanrs_init (library_init_s)",
                 "first_call_breakdown_ms": first_breakdown,
+                # what a fresh process pays before its first PCA result: scanrs_init + the reserve (waits for the VRAM scrubber when another
+                # tenant has just exited: 0 or about 2 s, environment) + the first call
+                "first_call_from_process_start_s": round(t_init + t_reserve + t_setup, 3),
                 "heavy_tailed_ms_per_step": heavy["ms_per_step"] if heavy else None,
                 "heavy_tailed_profile": heavy,
                 "library_init_s": round(t_init, 3),
@@ -744,6 +831,7 @@ def main():
                 "sigma_top3": [round(float(x), 6) for x in (sig[:3] if sig is not None else [])],
                 "per_rank_ms_per_step": [round(x, 2) for x in rank_ms],
                 "per_rank_nnz": nnz_ranks,
+                "per_rank_sharded_kernel_ms_per_step": [round(x, 2) for x in rank_sharded_kernel_ms],
                 "allreduce_ms_per_step_rank0": round(ar_ms, 3),
             },
             "roofline": roof,
@@ -751,11 +839,15 @@ def main():
         }
         if knn_ms is not None:
             out["config"][f"knn{args.also_knn}_device_scores_ms"] = round(knn_ms, 1)
-        if randsvd_ms is not None:
-            out["config"]["randsvd_l10_it2_ms"] = round(randsvd_ms, 1)
-        if irlba_ms is not None:
-            out["config"]["irlba_tol1e-4_ms"] = round(irlba_ms, 1)
+        if randsvd_ms is not None:  # "with RandSvd reported alongside" (rand_svd.rs:54-129: l = 10 k = 500 columns, 2 power iterations)
+            out["config"]["randsvd_ms"] = out["config"]["randsvd_l10_it2_ms"] = round(randsvd_ms, 1)
+            out["config"]["randsvd_kernels_ms"] = randsvd_kernels
+        if irlba_ms is not None:  # irlba.rs:71-215 on the un-centred log-normalized matrix (tol 1e-4, at most 50 restarts)
+            out["config"]["irlba_ms"] = out["config"]["irlba_tol1e-4_ms"] = round(irlba_ms, 1)
             out["config"]["irlba_matrix_products"] = irlba_mprod
+            out["config"]["irlba_kernels_ms"] = irlba_kernels
+        if split is not None:
+            out["config"].update(split)
         print(json.dumps(out))
     wd.done = True
     del mat

@@ -378,7 +378,9 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value);
  * converge within the queued passes and that were run again with host factorizations. First-call accounting, host microseconds of
  * the calling thread since the handle was made: "t_layout_us" (tile layout builds), "t_side_wait_us" (waiting for the helper
  * thread of "side_build"), "t_start_panel_us", "t_delivery_us" (U, V to host arrays); process-wide: "t_alloc_us" / "alloc_calls"
- * (hipMalloc). */
+ * (hipMalloc). The tile layouts of the handle (both orientations, summed): "tile_positions" = record positions the tile kernel works
+ * per pair of passes, "tile_served_nonzeros" = nonzeros among them (the rest is padding), "tile_overflow_nonzeros" = nonzeros left
+ * to the overflow gather. */
 int scanrs_mat_get_counter(scanrs_mat *m, const char *key, uint64_t *value);
 /* Process-wide options of the entry points that take no handle:
  *   "h5_threads" (8)               threads that inflate the chunks of a large filtered HDF5 read

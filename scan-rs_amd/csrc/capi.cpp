@@ -630,6 +630,7 @@ SparseCopy &Storage::copy_with_outer_rows(bool outer_rows) {
         build_transposed_copy(*this, primary, other);
         has_other = true;
     }
+    other_settled = true;
     return other;
 }
 
@@ -989,7 +990,9 @@ static void axis_sums(scanrs_mat *m, int axis, int mode, double *d_sum, double *
     bool done = false;
     if (st.col_moments && mode != 0) {
         const bool other_outer_rows = (!outer_view_rows) != m->transposed;
-        const bool exists = other_outer_rows == (st.storage == SCANRS_CSR) || st.has_other;
+        // (other_settled, not has_other: whether the helper thread has finished the transposed copy by now depends on its speed, and the
+        // two passes round differently: the moments - and the PCA behind them - must not change from run to run)
+        const bool exists = other_outer_rows == (st.storage == SCANRS_CSR) || st.other_settled;
         if (exists) {
             SparseCopy &co = copy_outer_view_rows(m, !outer_view_rows);
             if (st.col_moments == 2 || co.nnz >= st.blocked_min_nnz) done = launch_col_moments(st, co, m->dev_map(!outer_view_rows), mode, d_sum, d_sumsq);
@@ -1909,6 +1912,14 @@ int scanrs_mat_get_counter(scanrs_mat *m, const char *key, uint64_t *value) {
             *value = device_alloc_us();
         else if (k == "alloc_calls")
             *value = device_alloc_calls();
+        else if (k == "tile_positions" || k == "tile_served_nonzeros" || k == "tile_overflow_nonzeros") { // both tile layouts of the handle
+            m->st->side_join_if(nullptr, true);
+            uint64_t a[3], b[3];
+            tile_layout_stats(m->st->primary.tiles.get(), a);
+            tile_layout_stats(m->st->has_other ? m->st->other.tiles.get() : nullptr, b);
+            const int i = k == "tile_positions" ? 0 : k == "tile_served_nonzeros" ? 1 : 2;
+            *value = a[i] + b[i];
+        }
         else
             fail(SCANRS_ERR_ARGUMENT, "unknown counter '%s'", key);
     });

@@ -1,5 +1,6 @@
 // Shared declarations of the scanrs_amd library (host side). gfx950 only.
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <cstdio>
@@ -198,6 +199,7 @@ struct MultiRow {
 // overflow matrix — what the hybrid LDS-tile + gather product walks
 struct TileLayout;
 void tile_layout_free(TileLayout *t);
+void tile_layout_stats(const TileLayout *t, uint64_t out[3]); // positions per pass, served nonzeros, overflow nonzeros
 
 // A compressed orientation: n_outer vectors over n_inner positions.
 struct SparseCopy {
@@ -248,7 +250,8 @@ struct Storage {
     int storage = SCANRS_CSR; // orientation of `primary`: CSR -> outer = rows
     SparseCopy primary;
     SparseCopy other; // the transposed orientation, built on first use
-    bool has_other = false;
+    std::atomic<bool> has_other{false}; // written by the helper thread too (SideBuild); readers that must not depend on its timing use other_settled
+    bool other_settled = false;         // calling thread only: `other` is known to exist at a point of the program that does not depend on the helper's speed (copy_with_outer_rows)
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr; // small dense work that overlaps a sparse pass (svd_bk's cross-block orthogonalisation)
     hipStream_t aux();

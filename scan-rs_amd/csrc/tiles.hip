@@ -837,6 +837,7 @@ struct TileLayout {
     bool dense = false;
     uint32_t dn_wgg = 0, dn_items = 0;
     uint64_t dn_chunks = 0;        // chunks of 16 positions in drec / pw (cmeta: one entry each)
+    uint64_t dn_served = 0;        // nonzeros that own a record
     DevBuf<uint32_t> drec;         // 4 x slot-in-group | raw count << 8 | ring row << 16
     DevBuf<uint64_t> cmeta;        // group << 32 | visit of a chunk (weight refresh)
     DevBuf<char> ditems;           // DenseItem per workgroup item
@@ -870,6 +871,18 @@ struct TileLayout {
 };
 
 void tile_layout_free(TileLayout *t) { delete t; }
+// record positions the tile kernel works per pass, nonzeros among them, nonzeros left to the overflow gather (scanrs_mat_get_counter)
+void tile_layout_stats(const TileLayout *t, uint64_t out[3]) {
+    out[0] = out[1] = out[2] = 0;
+    if (!t) return;
+    out[2] = t->ov.nnz;
+    if (t->dense) {
+        out[0] = t->dn_chunks * 16u;
+        out[1] = t->dn_served;
+    } else {
+        out[0] = t->prow.n;
+    }
+}
 
 uint32_t ensure_bounds_public(Storage &st, SparseCopy &cp, hipStream_t s); // kernels.hip
 void materialize_map_values(Storage &st, SparseCopy &cp, const DevMap &map, double *fout); // kernels.hip
@@ -1673,7 +1686,7 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     const bool long_outer = cp.n_outer >= cp.n_inner;
     if (st.prof.on)
         st.prof.begin(st.stream, long_outer ? "spmm_tile_kernel/long-outer" : "spmm_tile_kernel/short-outer", bytes,
-                      tl.dense ? (double)tl.dn_chunks * 16.0 * 8.0 * l : (double)tl.n_groups * sh.nt * sh.S * sh.K * 8.0 * l);
+                      tl.dense ? (double)tl.dn_served * 8.0 * l /* rows of SERVED nonzeros: padding positions move no useful byte */ : (double)tl.n_groups * sh.nt * sh.S * sh.K * 8.0 * l);
 #define SCANRS_TILE(KK, SS, UU) launch_tile_kernel<KK, SS, UU>(st, ta, X, ldx, l, pbuf, ldc, part_stride, n_items, grid)
     const bool um = tl.unit_mode; // a layout with unit positions under a map that does not separate runs the weighted kernel
     if (n_items == 0) { // every vector went to the overflow part: nothing for the tile kernel

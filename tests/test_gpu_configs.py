@@ -190,4 +190,19 @@ def test_config3_1M_matches_the_committed_oracle_result(sa):
     u2, s2, v2 = sa.BkSvd().run_pca(g, k, omega=omega)
     assert np.max(np.abs(s2 - s) / s) < 1e-8
     _check_against_fixture(fx, u2, s2, v2, k)
+    del g, u, v, u2, v2
+    torch.cuda.empty_cache()
+    # configs[3] at the headline size: the same matrix as two cell-range shards of one process (both on GPU 0 of the test box), the
+    # exchange steps through the library's one-shot all-reduce over peer-mapped memory (scanrs_multi_*): same fixture, same tolerances
+    # (round 4 ran this form at the 100 k fixture only)
+    ip2, ix2, vv2 = synth_counts_par(cells, genes, float(fx["density"]), int(fx["seed"]))
+    mm = sa.MultiMat(genes, cells, sa.CSC, ip2, ix2, vv2, 2, devices=[0, 0])
+    ranges = mm.shard_ranges()
+    nnz0 = int(ip2[ranges[0][2]])
+    assert abs(nnz0 - int(ip2[-1]) / 2) < 0.001 * int(ip2[-1])  # balanced by nonzeros
+    del ix2, vv2
+    mm.normalize(sa.Normalization.CellRanger)
+    um, sm, vm = mm.run_pca_bk(k, omega=omega)
+    _check_against_fixture(fx, um, sm, vm, k)
+    mm.close()
     torch.cuda.empty_cache()

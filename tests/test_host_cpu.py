@@ -413,3 +413,30 @@ def test_every_option_and_counter_is_documented_in_the_header():
     assert len(keys) > 30
     missing = sorted(k for k in keys if f'"{k}"' not in hdr)
     assert not missing, f"keys accepted by capi.cpp but not documented in include/scanrs_amd.h: {missing}"
+
+
+def test_replicated_sharded_split_of_a_step():
+    """bench.py reports what part of a step shrinks with the cell range (config.sharded_ms_per_step) and what does not
+    (config.replicated_ms_per_step) from the step on the whole matrix and on a second one with about half the nonzeros: the model
+    t(f) = replicated + sharded f must be recovered exactly, clamped where noise would make a term negative, and the sharded term of
+    rank r of a partition by nonzeros is its nonzero share of it (scanrs_plan_shards cuts by nonzeros)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for rep, sh, f in ((30.0, 190.0, 0.5), (12.5, 100.0, 0.4987), (0.0, 50.0, 0.25), (40.0, 0.0, 0.5)):
+        out = bench.split_replicated_sharded(rep + sh, rep + sh * f, f)
+        assert abs(out["replicated_ms_per_step"] - rep) < 0.011 and abs(out["sharded_ms_per_step"] - sh) < 0.011
+    out = bench.split_replicated_sharded(100.0, 101.0, 0.5)  # the part ran slower than the whole (noise): nothing is sharded
+    assert out == {"replicated_ms_per_step": 100.0, "sharded_ms_per_step": 0.0}
+    out = bench.split_replicated_sharded(100.0, 10.0, 0.5)  # more than everything cannot be sharded
+    assert out == {"replicated_ms_per_step": 0.0, "sharded_ms_per_step": 100.0}
+    # ranks of a partition by nonzeros: the shares add up to the sharded term and follow the nonzeros
+    import numpy as np
+
+    nnz = np.array([130, 127, 125, 129, 131, 126, 128, 128], dtype=np.int64) * 10**6
+    shares = [bench.sharded_share_of_rank(190.0, int(n), int(nnz.sum())) for n in nnz]
+    assert abs(sum(shares) - 190.0) < 1e-9 and max(shares) / min(shares) == pytest.approx(131 / 125)
+    assert all(name.startswith(bench.SHARDED_KERNEL_PREFIXES) for name in ("spmm_tile_kernel/long-outer", "tile_weights", "row_reduce_u32", "col_moments"))
+    assert not any(name.startswith(bench.SHARDED_KERNEL_PREFIXES) for name in ("chol_rinv", "gemm_nn_mfma_f64"))
