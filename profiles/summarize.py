@@ -23,7 +23,7 @@ def one(pattern):
 
 
 def classify(name, grid):
-    if "spmm_tile_kernel" in name:  # the persistent tile kernel of the hybrid product (both orientations: one grid of 256 workgroups)
+    if "spmm_tile_kernel" in name or "spmm_tile_dense_kernel" in name:  # the persistent tile kernel of the hybrid product (both orientations: one grid of 256 workgroups)
         return "spmm_tile_kernel"
     if "spmm_gather_ov_kernel" in name:  # the gather over the overflow part, beside the tile kernel (4 vectors per wave)
         return "spmm_gather2d_ov/long-outer" if grid > 2_500_000 else "spmm_gather2d_ov/short-outer"

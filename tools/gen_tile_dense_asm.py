@@ -7,14 +7,14 @@ physical one (the accumulators are picked through VGPR index mode, which shifts 
 compiler-scheduled instruction may sit between s_set_gpr_idx_on and _off), and LDS reads, scalar loads and LDS-DMA all have to
 be counted by hand. A generator keeps the numbering honest; the output is committed next to it.
 
-Register map (all clobbered by the asm statement; the compiler keeps v0-v25 and s0-s16):
+Register map (all clobbered by the asm statement; the compiler keeps v0-v25 and s0-s11):
   v[88:215]   accumulators: slot q = v[88 + 4 q : 88 + 4 q + 3] (two f64: columns 2 lane, 2 lane + 1)
   v[56:87]    panel rows of 8 positions in flight (4 registers each)
   v[48:55]    their LDS addresses
   (216 registers in all: two tile waves per SIMD leave 80 for a wave of the overflow gather, which runs beside this kernel)
   v[40:47]    weights of the round's 4 chunks: lane L holds weight L % 16 of the chunk (one register pair per chunk)
   v[38:39]    this lane's address in the weight stream: 8 L behind the END of the NEXT round's weights
-  v26 4 x lane, v27 sink of the touch load, v30 4 x (lane % 16); v[28:29] the NEXT round's 64 weights as loaded (lane L: weight L)
+  v[26:27] the NEXT round's 64 weights as loaded (lane L: weight L), v[28:29] this round's, v30 4 x (lane % 16)
   v36 ring base of the lane (LDS address of its column pair in ring row 0), v37 row pitch in bytes
   v[31:35]    LDS-DMA source offsets of the wave's 5 staging chunks
   s[36:99]    the round's records: bits 7:0 = 4 x slot (the VGPR index), 15:8 = raw count (weight refresh only), 31:16 = ring row
@@ -25,6 +25,8 @@ Register map (all clobbered by the asm statement; the compiler keeps v0-v25 and 
 import os
 import sys
 
+PRIO = int(os.environ.get("GEN_PRIO") or 0)  # experiments (no gain, profiles/HISTORY.md): 1 = waves 4-7 at priority 1, 2 = two copies of the round whose priorities alternate per batch, opposite in the two waves of a SIMD
+STAMP = bool(os.environ.get("GEN_STAMP"))  # diagnostic build: s_memtime stamps around the round's body, the staging wait and the barrier, summed per wave
 SKIP = set((os.environ.get("GEN_SKIP") or "").split(","))  # timing experiments (wrong results): w = weights, r = records, b = barrier, d = staging
 
 BP = int(os.environ.get("GEN_BP") or 4)   # positions per batch (two batches of row reads in flight); 8 is as fast but takes 40 registers more
@@ -70,13 +72,14 @@ def batch_AL(b, out):
         out.append(f"ds_read_b128 {xq(p)}, {ad(p)}")
 
 
-def batch_F(b, out):
+def batch_F(b, out, tail=False):
     for j in range(BP):
         p = b * BP + j
+        r = f"s{13 + j}" if tail else rec(p)
         if j == 0:
-            out.append(f"s_set_gpr_idx_on {rec(p)}, 0x8")
+            out.append(f"s_set_gpr_idx_on {r}, 0x8")
         else:
-            out.append(f"s_set_gpr_idx_idx {rec(p)}")
+            out.append(f"s_set_gpr_idx_idx {r}")
         q = p % 16
         out.append(f"v_fmac_f64_dpp v[{ACC0}:{ACC0 + 1}], {wreg(p)}, {xr(p, 0)} row_newbcast:{q} row_mask:0xf bank_mask:0xf")
         out.append(f"v_fmac_f64_dpp v[{ACC0 + 2}:{ACC0 + 3}], {wreg(p)}, {xr(p, 1)} row_newbcast:{q} row_mask:0xf bank_mask:0xf")
@@ -95,23 +98,40 @@ def dma(i, out):
     out.append(f"global_load_lds_dwordx4 v{31 + i}, s[24:25]")
 
 
+def reload_slot(c, out):
+    """records of chunk slot c for the NEXT round (s[32:33]: 256 bytes in front of its last record's end)"""
+    out.append(f"s_load_dwordx16 s[{R0 + 16 * c}:{R0 + 16 * c + 15}], s[32:33], {hex(64 * c)}")
+
+
 def gen():
-    """Vector memory per round: one touch load (next round's records into L2), ONE weight load for the next round (lane L takes
-    weight L of the 64 positions that END at the round's last one: 512 contiguous bytes; four loads of 16 replicated weights each
-    cost four times the return bytes on the CU's fetch path, which the staging shares: -1.7 ms per pass without them), five staging
-    loads. All of it is issued at the round's start and waited for (vmcnt(0)) at the next round's start. The weights reach the
-    form the FMAs want - every row of 16 lanes holds the 16 weights of ONE chunk - by eight ds_bpermute_b32 (LDS crossbar)."""
+    """One round = up to 4 chunks of 16 record positions, worked in batches of BP positions with two batches of row reads in flight.
+
+    What is loaded when (everything for round r + 1 travels while round r computes; the boundary between two rounds waits for nothing
+    that was not issued a good part of a round earlier):
+      * records (64 scalar registers, chunk slot c = s[36 + 16 c ..]): slot c of the next round is reloaded as soon as this round has
+        issued the last FMA that names it (behind F of batch 4 c + 3; slots the round does not enter: in its prologue; slot 3: in front
+        of the last batch, whose four accumulator indices are copied to s[13:16] first). Scalar loads return out of order, so only the
+        boundary's lgkmcnt(0) certifies them; the counted waits of the row reads in between stay correct (a count that includes scalar
+        loads can only wait for MORE row reads than needed, one per scalar load still in flight);
+      * weights: one 512-byte load per round into v[24:25] (lane L: weight L of the 64 positions that end at the next round's last
+        one), moved to v[28:29] and spread by eight ds_bpermute_b32 at the next round's start (every row of 16 lanes = one chunk);
+      * panel tiles: five LDS-DMA loads per wave and round, in the round's last four batches and behind it. A round that is not the
+        first of its visit stages the same tile once more (same bytes, same place; nobody reads it before the visit after the next):
+        with the same five loads in every round the boundary's vmcnt(5) means the same thing everywhere;
+      * headers: three rounds ahead (s28 / s34 / s101 / s12)."""
     o = []
     a = o.append
     # ---- inputs into the fixed registers ----
-    a("s_mov_b64 s[20:21], %[rec]")
-    a("s_mov_b64 s[22:23], %[rtab]")
-    a("s_mov_b64 s[24:25], %[src]")
-    a("s_mov_b32 s26, %[nrounds]")
-    a("s_mov_b32 s27, %[tb]")
-    a("s_mov_b32 s35, %[dst]")
-    a("s_mov_b32 s17, %[wave10]")
-    a("s_mov_b32 s18, %[lds0]")
+    # (every operand arrives in a vector register: the compiler has a dozen scalar registers left beside this statement's)
+    for name, lo in (("rec", 20), ("rtab", 22), ("src", 24)):
+        a(f"v_readfirstlane_b32 s{lo}, %[{name}lo]")
+        a(f"v_readfirstlane_b32 s{lo + 1}, %[{name}hi]")
+    a("v_readfirstlane_b32 s26, %[nrounds]")  # (uniform values handed over in vector registers: the compiler has few scalar ones left for operands)
+    a("v_readfirstlane_b32 s27, %[rowb]")
+    a("s_mul_i32 s27, s27, 48")  # bytes of a tile of 48 rows
+    a("v_readfirstlane_b32 s35, %[dst]")  # (uniform values handed over in vector registers: the compiler has few scalar ones left for operands)
+    a("v_readfirstlane_b32 s17, %[wave10]")  # (uniform values handed over in vector registers: the compiler has few scalar ones left for operands)
+    a("v_readfirstlane_b32 s18, %[lds0]")  # (uniform values handed over in vector registers: the compiler has few scalar ones left for operands)
     a("s_lshl_b32 s19, s27, 2")
     a("s_add_u32 s19, s19, s18")
     a("s_sub_u32 s31, s27, 0x400")
@@ -119,131 +139,194 @@ def gen():
     a("v_mov_b32 v39, %[pwhi]")
     a("v_mov_b32 v36, %[ring]")
     a("v_mov_b32 v37, %[rowb]")
-    a("v_mov_b32 v26, %[lane4]")
-    a("v_and_b32 v30, 60, v26")  # 4 (lane % 16): ds_bpermute address of this lane's weight inside a chunk
-    for i in range(5):
-        a(f"v_mov_b32 v{31 + i}, %[voff{i}]")
+    a("v_and_b32 v30, 60, %[lane4]")  # 4 (lane % 16): ds_bpermute address of this lane's weight inside a chunk
+    a("v_lshlrev_b32 v28, 2, %[lane4]")  # 16 x lane (v28: free until the first round)
+    for i in range(5):  # source offsets of the wave's five staging chunks: min((wave + 8 i) 1024, tile bytes - 1024) + 16 lane
+        a(f"s_add_u32 s30, s17, {i * 8192}")
+        a("s_min_u32 s30, s30, s31")
+        a(f"v_add_u32 v{31 + i}, s30, v28")
+    if PRIO == 1:
+        a("s_cmp_ge_u32 s17, 0x1000")
+        a("s_cbranch_scc0 LP0%=")
+        a("s_setprio 1")
+        a("LP0%=:")
+    if STAMP:
+        for r_ in (6, 7, 8, 9):
+            a(f"s_mov_b32 s{r_}, 0")
     a("s_cmp_eq_u32 s26, 0")
     a("s_cbranch_scc1 LDONE%=")
     a("s_load_dwordx2 s[28:29], s[22:23], 0x0")  # headers of rounds 0 and 1
+    a("s_load_dword s101, s[22:23], 0x8")        # ... 2
     a("s_waitcnt lgkmcnt(0)")
     a("s_mov_b32 s34, s29")
-    # weights of round 0
-    a("s_and_b32 s29, s28, 0xff")
-    a("s_lshl_b32 s30, s29, 7")
-    a("v_add_co_u32 v38, vcc, s30, v38")
-    a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
-    a("global_load_dwordx2 v[28:29], v[38:39], off offset:-512")
-    a("LROUND%=:")
-    a("s_and_b32 s29, s28, 0xff")   # chunks of this round
-    a("s_and_b32 s100, s34, 0xff")  # ... of the next one
+    a("s_and_b32 s29, s28, 0xff")                # chunks of round 0
     a("s_lshl_b32 s30, s29, 6")
     a("s_add_u32 s20, s20, s30")
     a("s_addc_u32 s21, s21, 0")
     a("s_sub_u32 s32, s20, 0x100")
     a("s_subb_u32 s33, s21, 0")
-    rb = "s[32:33]" if "r" not in SKIP else "%[rec]"  # experiment: always the item's first chunks (scalar-cache hits)
-    a(f"s_load_dwordx16 s[36:51], {rb}, 0x0")
-    a(f"s_load_dwordx16 s[52:67], {rb}, 0x40")
-    a(f"s_load_dwordx16 s[68:83], {rb}, 0x80")
-    a(f"s_load_dwordx16 s[84:99], {rb}, 0xc0")
-    a("s_load_dword s101, s[22:23], 0x8")  # header of the round after the next
-    a("s_add_u32 s22, s22, 4")
-    a("s_addc_u32 s23, s23, 0")
-    a("s_lshl_b32 s30, s100, 7")
-    # This round's weights must be there, and the tile staged during the visit BEFORE the last one (first read now); the five
-    # staging loads of the last round - if it was the first of its visit (bit 9) they are the youngest operations - may still be in flight
-    a("s_bitcmp1_b32 s28, 9")
-    a("s_cbranch_scc0 LW0%=")
-    a("s_waitcnt vmcnt(5)")
-    a("s_branch LW1%=")
-    a("LW0%=:")
-    a("s_waitcnt vmcnt(0)")
-    a("LW1%=:")
-    a("s_bitcmp1_b32 s28, 8")
-    a("s_cbranch_scc0 LNOBAR%=")
+    for c in range(4):
+        reload_slot(c, o)
+    a("s_lshl_b32 s30, s29, 7")
+    a("v_add_co_u32 v38, vcc, s30, v38")
+    a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
+    a("global_load_dwordx2 v[26:27], v[38:39], off offset:-512")  # weights of round 0
+    a("s_waitcnt vmcnt(0) lgkmcnt(0)")           # ... and the item's first tile (staged by the caller)
     if "b" not in SKIP:
-        a("s_barrier")
+        a("s_barrier")                            # round 0 is the first of its visit
     a("s_add_u32 s24, s24, s27")
     a("s_addc_u32 s25, s25, 0")
     a("s_add_u32 s35, s35, s27")
     a("s_cmp_eq_u32 s35, s19")
     a("s_cselect_b32 s35, s18, s35")
-    a("LNOBAR%=:")
-    # the round's weights: row r of the loaded register pair holds chunk r's 16 weights -> four pairs in which EVERY row holds one chunk's
-    for c in range(4):
-        a(f"ds_bpermute_b32 v{W0 + 2 * c}, v30, v28 offset:{64 * c}")
-        a(f"ds_bpermute_b32 v{W0 + 2 * c + 1}, v30, v29 offset:{64 * c}")
-    a("global_load_dword v27, v26, s[20:21]" if "t" not in SKIP else "s_nop 0")  # touch: the next round's records into L2
-    a("v_add_co_u32 v38, vcc, s30, v38")  # -> behind the next round's weights
-    a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
-    a("s_waitcnt lgkmcnt(0)")  # records, headers, the permuted weights (v[28:29] is free again)
-    a("global_load_dwordx2 v[28:29], v[38:39], off offset:-512" if "w" not in SKIP else "s_nop 0")
-    a("s_bitcmp1_b32 s28, 8")
-    a("s_cbranch_scc0 LNODMA%=")
-    a("s_cmp_eq_u32 s29, 4")
-    a("s_cbranch_scc1 LPRO0%=")
-    a("s_cmp_eq_u32 s29, 3")
-    a("s_cbranch_scc1 LPRO1%=")
-    a("s_cmp_eq_u32 s29, 2")
-    a("s_cbranch_scc1 LPRO2%=")
-    a("s_cmp_eq_u32 s29, 1")
-    a("s_cbranch_scc1 LPRO3%=")
-    # an empty round (a visit nobody has work in yet: the first two of a part)
-    for i in range(5):
-        dma(i, o)
-    a("s_branch LEND%=")
-    # a later round of a long visit: nothing to stage
-    a("LNODMA%=:")
-    a("s_cmp_eq_u32 s29, 4")
-    a("s_cbranch_scc1 LQRO0%=")
-    a("s_cmp_eq_u32 s29, 3")
-    a("s_cbranch_scc1 LQRO1%=")
-    a("s_cmp_eq_u32 s29, 2")
-    a("s_cbranch_scc1 LQRO2%=")
-    a("s_cmp_eq_u32 s29, 1")
-    a("s_cbranch_scc1 LQRO3%=")
-    a("s_branch LEND%=")
-    # prologues: rows of the first two batches of the round (with the staging loads between them), then into the steady stream
-    for with_dma in (False, True):
+
+    # ---- one round, in two copies: waves 0-3 run copy A, waves 4-7 (their partners on the four SIMDs) copy B. The copies differ in ONE
+    # thing: the priority a wave asks for alternates from batch to batch, opposite in the two copies. With equal priorities the older
+    # wave of a SIMD wins every issue conflict, finishes its round 570 clk early and waits at the barrier while its partner works on
+    # alone at the rate of a single wave (stamps: barrier wait 706 / 140 clk per round, the other way round with s_setprio 1 on waves 4-7).
+    if PRIO == 2:
+        a("s_bitcmp1_b32 s17, 12")  # wave >= 4
+        a("s_cbranch_scc1 LROUNDB%=")
+    for V in (("A", "B") if PRIO == 2 else ("A",)):
+        a("LROUND" + V + "%=:")
+        if STAMP:
+            a("s_memtime s[2:3]")
+        a("v_mov_b32 v28, v26")
+        a("v_mov_b32 v29, v27")
+        for c in range(4):
+            a(f"ds_bpermute_b32 v{W0 + 2 * c}, v30, v28 offset:{64 * c}")
+            a(f"ds_bpermute_b32 v{W0 + 2 * c + 1}, v30, v29 offset:{64 * c}")
+        a("s_and_b32 s100, s34, 0xff")               # chunks of the next round
+        a("s_lshl_b32 s30, s100, 7")
+        a("v_add_co_u32 v38, vcc, s30, v38")         # behind the next round's weights
+        a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
+        a("global_load_dwordx2 v[26:27], v[38:39], off offset:-512" if "w" not in SKIP else "s_nop 0")
+        a("s_lshl_b32 s30, s100, 6")                 # where the next round's four chunk slots come from
+        a("s_add_u32 s32, s20, s30")
+        a("s_addc_u32 s33, s21, 0")
+        a("s_sub_u32 s32, s32, 0x100")
+        a("s_subb_u32 s33, s33, 0")
+        if "t" not in SKIP:
+            # touch: the records of the round after the next one into L2 (their scalar loads, issued during the next round, then hit there:
+            # without it a boundary waits for slot 3's load to come from HBM, +350 clk per round). An LDS-DMA load into 256 scratch bytes of
+            # this wave behind the ring: it needs no register to land in, and it is this round's OLDEST vector-memory operation
+            a("s_min_u32 s30, s17, s31")
+            a("v_sub_u32 v48, v31, s30")             # 16 x lane (v48: an address register, free until the prologue)
+            a("v_lshrrev_b32 v48, 2, v48")           # 4 x lane: 256 bytes = four chunk slots
+            a("s_lshr_b32 s30, s17, 2")
+            a("s_add_u32 s30, s30, s19")
+            a("s_add_u32 m0, s30, 0x400")            # behind the ring and the row of zeros
+            a("s_nop 0")
+            a("global_load_lds_dword v48, s[32:33] offset:256")
+        a("s_load_dword s12, s[22:23], 0xc")         # header three rounds ahead
+        a("s_cmp_eq_u32 s29, 4")
+        a("s_cbranch_scc1 LPRO0" + V + "%=")
+        a("s_cmp_eq_u32 s29, 3")
+        a("s_cbranch_scc1 LPRO1" + V + "%=")
+        a("s_cmp_eq_u32 s29, 2")
+        a("s_cbranch_scc1 LPRO2" + V + "%=")
+        a("s_cmp_eq_u32 s29, 1")
+        a("s_cbranch_scc1 LPRO3" + V + "%=")
+        # an empty round (a visit nobody has work in yet: the first two of a part)
+        for c in range(4):
+            reload_slot(c, o)
+        for i in range(5):
+            dma(i, o)
+        a("s_branch LBND" + V + "%=")
+        # prologues: the slots this round does not enter, then the rows of its first two batches
         for c in (3, 2, 1, 0):
-            a(f"L{'P' if with_dma else 'Q'}RO{c}%=:")
-            blocks = []
-            for b in (BPC * c, BPC * c + 1):
-                blk = []
+            a(f"LPRO{c}" + V + "%=:")
+            for cc in range(c):
+                reload_slot(cc, o)
+            batch_AL(BPC * c, o)
+            batch_AL(BPC * c + 1, o)
+            if c != 0:
+                a(f"s_branch LS{BPC * c}" + V + "%=")
+        for b in range(NB):
+            a(f"LS{b}" + V + "%=:")
+            last = b == NB - 1
+            if PRIO == 2:
+                a(f"s_setprio {(b + (1 if V == 'B' else 0)) & 1}")
+            a(f"s_waitcnt lgkmcnt({BP})" if not last else "s_waitcnt lgkmcnt(0)")
+            if last:
+                # the last batch names its accumulators through copies, so that slot 3 can be reloaded before its FMAs instead of behind them
                 for j in range(BP):
-                    p = b * BP + j
-                    blk.append(f"v_mad_u32_u16 {ad(p)}, {rec(p)}, v37, v36 op_sel:[1,0,0,0]")
-                blocks.append(blk)
-                blk = []
-                for j in range(BP):
-                    p = b * BP + j
-                    blk.append(f"ds_read_b128 {xq(p)}, {ad(p)}")
-                blocks.append(blk)
-            for i, blk in enumerate(blocks):
-                o.extend(blk)
-                if with_dma:
-                    dma(i, o)
-            if with_dma:
-                dma(4, o)
-            if not (with_dma and c == 0):
-                a(f"s_branch LS{BPC * c}%=")
-    for b in range(NB):
-        a(f"LS{b}%=:")
-        a(f"s_waitcnt lgkmcnt({BP})" if b < NB - 1 else "s_waitcnt lgkmcnt(0)")
-        batch_F(b, o)
-        if b + 2 < NB:
-            batch_AL(b + 2, o)
-    a("LEND%=:")
-    a("s_and_b32 s30, s28, 0x100")
-    a("s_lshl_b32 s30, s30, 1")
-    a("s_mov_b32 s28, s34")
-    a("s_or_b32 s28, s28, s30")  # bit 9: the round before was the first of its visit (it staged a tile)
-    a("s_mov_b32 s34, s101")
-    a("s_sub_u32 s26, s26, 1")
-    a("s_cmp_lg_u32 s26, 0")
-    a("s_cbranch_scc1 LROUND%=")
+                    a(f"s_mov_b32 s{13 + j}, {rec(b * BP + j)}")
+                reload_slot(3, o)
+                batch_F(b, o, tail=True)
+            else:
+                batch_F(b, o)
+            if b % BPC == BPC - 1 and b // BPC < 3:
+                reload_slot(b // BPC, o)
+            if b >= NB - 4:
+                dma(b - (NB - 4), o)
+            if b + 2 < NB:
+                batch_AL(b + 2, o)
+        dma(4, o)
+        # ---- boundary ----
+        a("LBND" + V + "%=:")
+        if STAMP:
+            a("s_memtime s[4:5]")
+            a("s_waitcnt lgkmcnt(0)")
+            a("s_sub_u32 s10, s4, s2")
+            a("s_add_u32 s6, s6, s10")   # body
+            a("s_add_u32 s9, s9, 1")     # rounds
+        a("s_sub_u32 s26, s26, 1")
+        a("s_cmp_eq_u32 s26, 0")
+        a("s_cbranch_scc1 LDONE%=")
+        a("s_waitcnt vmcnt(5)")                      # the next round's weights; every staging load but this round's five
+        if STAMP:
+            a("s_memtime s[2:3]")
+            a("s_waitcnt lgkmcnt(0)")
+            a("s_sub_u32 s10, s2, s4")
+            a("s_add_u32 s7, s7, s10")   # wait for vector memory (+ the scalar loads the stamp forces)
+        a("s_bitcmp1_b32 s34, 8")
+        a("s_cbranch_scc0 LNB" + V + "%=")
+        if "b" not in SKIP:
+            a("s_barrier")
+        if STAMP:
+            a("s_memtime s[4:5]")
+            a("s_waitcnt lgkmcnt(0)")
+            a("s_sub_u32 s10, s4, s2")
+            a("s_add_u32 s8, s8, s10")   # barrier                            # next round = first of a visit: the tile it reads first has landed for everybody, nobody reads the oldest one any more
+        a("s_add_u32 s24, s24, s27")
+        a("s_addc_u32 s25, s25, 0")
+        a("s_add_u32 s35, s35, s27")
+        a("s_cmp_eq_u32 s35, s19")
+        a("s_cselect_b32 s35, s18, s35")
+        a("LNB" + V + "%=:")
+        a("s_waitcnt lgkmcnt(0)")                    # the next round's records and the header
+        a("s_mov_b32 s28, s34")
+        a("s_mov_b32 s34, s101")
+        a("s_mov_b32 s101, s12")
+        a("s_add_u32 s22, s22, 4")
+        a("s_addc_u32 s23, s23, 0")
+        a("s_mov_b32 s29, s100")
+        a("s_lshl_b32 s30, s29, 6")
+        a("s_add_u32 s20, s20, s30")
+        a("s_addc_u32 s21, s21, 0")
+        a("s_branch LROUND" + V + "%=")
     a("LDONE%=:")
+    if PRIO:
+        a("s_setprio 0")
+    a("s_waitcnt vmcnt(0) lgkmcnt(0)")           # nothing of this statement may land in a register later
+    if STAMP:
+        a("v_mov_b32 v30, 0")
+        a("v_mov_b32 v29, 0")
+        a("v_readfirstlane_b32 s2, %[stamplo]")
+        a("v_readfirstlane_b32 s3, %[stamphi]")
+        a("s_mov_b64 s[10:11], exec")
+        a("s_mov_b64 exec, 1")  # one lane adds the wave's sums
+        for i_, r_ in enumerate((6, 7, 8, 9)):
+            a(f"v_mov_b32 v28, s{r_}")
+            a(f"global_atomic_add_x2 v30, v[28:29], s[2:3] offset:{8 * i_}")
+        # the barrier wait by wave number (8 more sums behind the four)
+        a("s_lshr_b32 s12, s17, 7")  # 8 x wave
+        a("v_mov_b32 v30, s12")
+        a("v_mov_b32 v28, s8")
+        a("global_atomic_add_x2 v30, v[28:29], s[2:3] offset:32")
+        a("s_waitcnt vmcnt(0)")
+        a("s_mov_b64 exec, s[10:11]")
     return o
 
 

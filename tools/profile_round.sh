@@ -9,8 +9,8 @@ export SCANRS_COMMIT=${2:-"working tree"}   # the build container passes $(git r
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-host-delivery --no-heavy-tailed"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-delivery --no-heavy-tailed > $OUT/stats.json 2> $OUT/stats.err
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-host-delivery --no-heavy-tailed --no-randsvd --no-irlba --no-split-probe"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-delivery --no-heavy-tailed --no-randsvd --no-irlba --no-split-probe > $OUT/stats.json 2> $OUT/stats.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/write.json 2> $OUT/write.err
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --kernel-trace --output-format csv -d $OUT/tcc -- python3 bench.py $ARGS > $OUT/tcc.json 2> $OUT/tcc.err
