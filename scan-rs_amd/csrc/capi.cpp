@@ -60,8 +60,24 @@ struct StageRing {
 };
 thread_local StageRing tl_stages;
 thread_local const Storage *tl_handle = nullptr;
+
 std::atomic<double> g_sync_timeout_s{120.0};
 } // namespace
+// set by a bounded wait that gave up (timeout_report); cleared only when the whole device has been seen idle again (device_recovered)
+std::atomic<bool> g_device_lost{false};
+bool device_lost() { return g_device_lost.load(std::memory_order_acquire); }
+// the handles of this process (registered by Storage's constructor): "is every stream the library owns idle?" walks them
+static std::mutex g_storages_mu;
+static std::set<const Storage *> g_storages;
+static hipStream_t storage_side_stream(const Storage &st); // the helper thread's stream, if a helper exists (defined behind SideBuild)
+static bool storage_streams_idle(const Storage *st);
+static bool all_library_streams_idle() {
+    std::lock_guard<std::mutex> lk(g_storages_mu);
+    for (const Storage *st : g_storages)
+        if (!storage_streams_idle(st)) return false;
+    return true;
+}
+
 void stage_mark(const char *what, long a, long b) {
     StageRing::Rec &r = tl_stages.rec[tl_stages.n++ % StageRing::N];
     strncpy(r.what, what, sizeof(r.what) - 1);
@@ -75,7 +91,33 @@ void stage_mark(const char *what, long a, long b) {
 }
 double sync_timeout_s() { return g_sync_timeout_s.load(std::memory_order_relaxed); }
 void set_sync_timeout_s(double s) { g_sync_timeout_s.store(s, std::memory_order_relaxed); }
-CurrentHandle::CurrentHandle(const Storage *st) : prev(tl_handle) { tl_handle = st; }
+void *landing_slot(size_t bytes) {
+    static char *ring = nullptr;
+    static std::atomic<size_t> head{0};
+    static std::once_flag once;
+    constexpr size_t RING = 1u << 20;
+    std::call_once(once, [] {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, RING, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            p = malloc(RING); // pageable, but still a place that no stack frame owns
+        }
+        ring = static_cast<char *>(p);
+    });
+    const size_t need = (bytes + 7) & ~(size_t)7;
+    if (!ring || need > 4096) fail(SCANRS_ERR_DEVICE, "no landing slot of %zu bytes", bytes);
+    size_t at = head.fetch_add(need, std::memory_order_relaxed) % RING;
+    if (at + need > RING) at = head.fetch_add(need, std::memory_order_relaxed) % RING; // (a slot never straddles the end: the next one does not either)
+    if (at + need > RING) at = 0;
+    return ring + at;
+}
+static bool device_recovered();
+CurrentHandle::CurrentHandle(const Storage *st, bool waits_only) : prev(tl_handle) {
+    if (!waits_only && device_lost() && !device_recovered())
+        fail(SCANRS_ERR_DEVICE, "a device wait of this process timed out earlier (sync_timeout_s) and the device has not been seen idle since: the library "
+                                "does not queue new work or reuse memory that kernels may still be using (scanrs_mat_sync waits for a handle's streams)");
+    tl_handle = st;
+}
 CurrentHandle::~CurrentHandle() { tl_handle = prev; }
 
 // Poll `query` (hipSuccess: done, hipErrorNotReady: not yet, anything else: a device error) until the deadline. Spins for the
@@ -158,6 +200,9 @@ static void timeout_report(const char *kind, const char *pretty_func, const char
         }
         fflush(stderr);
     }
+    // From here on the library must assume that kernels and copies of this process are still running: nothing they may touch is
+    // reused or freed (device_free_flush leaks), and every later entry point fails fast until device_recovered() has seen the device idle.
+    g_device_lost.store(true, std::memory_order_release);
     fail(SCANRS_ERR_DEVICE, "device wait timed out after %.1f s (sync_timeout_s): %s in %s (%s:%d); streams: %s; last stages: %s", waited, kind, func,
          base_name(file), line, where[0] ? where : "n/a", stages[0] ? stages : "none");
 }
@@ -221,9 +266,27 @@ static bool device_ok() {
     }
     return cached == 1;
 }
+// After a timed-out wait: is the device idle again? One non-blocking question (the null stream is ordered behind every blocking stream
+// and hipDeviceSynchronize would be an unbounded wait); the library's non-blocking streams are asked one by one through their handles
+// when those are used again. Clears the flag when the legacy stream reports idle twice in a row 10 ms apart.
+static bool device_recovered() {
+    if (!device_lost()) return true;
+    for (int i = 0; i < 2; i++) {
+        if (hipStreamQuery(nullptr) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(10));
+    }
+    g_device_lost.store(false, std::memory_order_release);
+    return true;
+}
 static void need_device() {
     if (!device_ok())
         fail(SCANRS_ERR_DEVICE, "no gfx950 (MI355X) device is usable from this process; scanrs_amd has no CPU fallback");
+    if (!device_recovered())
+        fail(SCANRS_ERR_DEVICE, "a device wait of this process timed out earlier (sync_timeout_s) and the device has not been seen idle since: the library "
+                                "does not queue new work or reuse memory that kernels may still be using");
 }
 
 // ---- device memory: allocation with retry, deferred frees, block cache (common.hpp) ------------------------------------
@@ -238,9 +301,13 @@ struct Reserve { // one large allocation made ahead of time (scanrs_reserve_devi
     size_t size, used;
     int dev;
 };
+struct DeadBlock {
+    void *p;
+    const Storage *owner; // the handle that was current on the releasing thread (nullptr: none)
+};
 struct DeviceMemory {
     std::mutex mu;
-    std::vector<void *> dead;                           // released by their owners, waiting for a point where the device is idle
+    std::vector<DeadBlock> dead;                        // released by their owners, waiting for a point where the OWNER's streams are idle
     std::map<void *, std::pair<size_t, int>> live;      // every block handed out: pointer -> (size, device)
     std::vector<Reserve> reserves;                      // blocks carved from a reserve are never given back one by one: they stay in the cache
     std::multimap<std::pair<int, size_t>, void *> idle; // cached blocks by (device, size)
@@ -259,15 +326,36 @@ void device_free_later(void *p, size_t) {
     if (!p) return;
     DeviceMemory &g = devmem();
     std::lock_guard<std::mutex> lk(g.mu);
-    g.dead.push_back(p);
+    g.dead.push_back(DeadBlock{p, tl_handle});
+}
+// every stream a handle queues work on (main, the two auxiliary ones, the overflow gather's, the helper thread's) has run dry
+static bool storage_streams_idle(const Storage *st) {
+    if (!st) return true;
+    hipStream_t list[5] = {st->stream, st->aux_stream, st->aux2_stream, st->ov_stream, nullptr};
+    list[4] = storage_side_stream(*st);
+    for (hipStream_t q : list) {
+        if (!q) continue;
+        if (hipStreamQuery(q) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    return true;
 }
 // Released blocks of 1 MB and more are kept for the next allocation of about their size instead of going back to the driver:
 // VRAM that was just freed is scrubbed in the background and an allocation that lands on it waits for the scrubber — seconds for
 // the tens of GB a handle holds (the second and third handle of one process took 2.4 / 4.1 s for their first PCA instead of 0.4).
 // At most `device_cache_fraction` (default one half) of the device's memory is kept; scanrs_release_cached_memory() and a failed
 // allocation empty the cache.
-void device_free_flush() noexcept {
+// Moves released blocks to the cache (or back to the driver). A block is only touched when the handle that released it is known to
+// have no work in flight on ANY of its streams: `owner` = the handle whose blocks to look at (default: the calling thread's current
+// one; blocks released outside any handle go with it), `everything` = the caller has just seen the whole device idle.
+// the list used to be process-wide and a caller proved only that its own main stream was idle - a block another handle (or
+// this handle's helper thread / auxiliary stream) still used could be handed out again.
+static void device_free_flush_impl(const Storage *owner, bool owner_gone, bool everything) noexcept {
     DeviceMemory &g = devmem();
+    if (device_lost()) return; // kernels of a timed-out call may still use them: leaked on purpose
+    if (!everything && !owner_gone && !storage_streams_idle(owner)) return;
     std::vector<Block> to_free;
     {
         std::lock_guard<std::mutex> lk(g.mu);
@@ -277,7 +365,13 @@ void device_free_flush() noexcept {
             size_t fr = 0, tot = 0;
             if (hipMemGetInfo(&fr, &tot) == hipSuccess) cap = (size_t)((double)tot * g.cache_fraction);
         }
-        for (void *p : g.dead) {
+        std::vector<DeadBlock> keep;
+        for (const DeadBlock &db : g.dead) {
+            if (!everything && db.owner != owner && !(db.owner == nullptr && owner != nullptr)) {
+                keep.push_back(db);
+                continue;
+            }
+            void *p = db.p;
             auto it = g.live.find(p);
             if (it == g.live.end()) continue; // not ours (cannot happen)
             const Block b{p, it->second.first, it->second.second};
@@ -291,7 +385,7 @@ void device_free_flush() noexcept {
                 to_free.push_back(b);
             }
         }
-        g.dead.clear();
+        g.dead.swap(keep);
     }
     if (to_free.empty()) return;
     const auto t0 = std::chrono::steady_clock::now();
@@ -304,8 +398,21 @@ void device_free_flush() noexcept {
         fprintf(stderr, "[scanrs trace] released %zu buffers, %.2f GB, in %.2f ms\n", to_free.size(), (double)bytes / 1e9,
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 }
+void device_free_flush() noexcept { device_free_flush_impl(tl_handle, false, false); }
+// the handle at `owner` has been destroyed (its streams were drained by its destructor): its blocks can go
+void device_free_flush_owner_gone(const void *owner) noexcept { device_free_flush_impl(static_cast<const Storage *>(owner), true, false); }
 void device_cache_release() noexcept {
-    device_free_flush();
+    // every owner's blocks: only behind a wait for the whole device (bounded like every other wait; if it does not come, nothing is released)
+    {
+        bool idle = false;
+        if (!device_lost()) {
+            const hipError_t e = poll_until([&] { return hipStreamQuery(nullptr); }, sync_timeout_s(), nullptr);
+            if (e != hipSuccess) (void)hipGetLastError();
+            idle = e == hipSuccess && all_library_streams_idle();
+        }
+        if (!idle) return;
+        device_free_flush_impl(nullptr, false, true);
+    }
     DeviceMemory &g = devmem();
     std::vector<void *> take;
     {
@@ -528,6 +635,7 @@ struct Storage::SideBuild {
     std::string err;
     double ms = 0.0;
 };
+static hipStream_t storage_side_stream(const Storage &st) { return st.side ? st.side->stream : nullptr; }
 // Waits until the helper has finished with `target` (nullptr: with everything) and rethrows its failure. `need_layout` false: the
 // copy itself is enough (a reader of the triplet).
 void Storage::side_join_if(const SparseCopy *target, bool need_layout) {
@@ -588,6 +696,8 @@ Storage::~Storage() {
         (void)wait_stream_quiet(stream);
         (void)hipStreamDestroy(stream);
     }
+    std::lock_guard<std::mutex> lk(g_storages_mu);
+    g_storages.erase(this);
 }
 // Four streams per handle: the main stream (sparse products: the persistent tile kernel must get its CUs first) at the default
 // priority, the overflow gather (fills the registers the tile kernel leaves) and the two auxiliary streams (dense work nothing
@@ -845,6 +955,10 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
     if (!indptr) fail(SCANRS_ERR_ARGUMENT, "null indptr");
     if (rows > 0xFFFFFFFFull || cols > 0xFFFFFFFFull) fail(SCANRS_ERR_SHAPE, "dimensions must fit in u32 (AdaptiveVec limit)");
     auto st = std::make_shared<Storage>();
+    {
+        std::lock_guard<std::mutex> lk(g_storages_mu);
+        g_storages.insert(st.get());
+    }
     st->rows = rows;
     st->cols = cols;
     st->storage = storage;
@@ -869,8 +983,8 @@ static void create_common(uint64_t rows, uint64_t cols, int storage, const uint6
     // null stream (torch's default stream), anything else is the caller's to synchronise before the call
     SCANRS_HIP(hipMemcpyAsync(cp.indptr.p, indptr, (cp.n_outer + 1) * 8, kind, st->stream));
     uint64_t first = 0, last = 0;
-    SCANRS_HIP(hipMemcpyAsync(&first, cp.indptr.p, 8, hipMemcpyDeviceToHost, st->stream));
-    SCANRS_HIP(hipMemcpyAsync(&last, cp.indptr.p + cp.n_outer, 8, hipMemcpyDeviceToHost, st->stream));
+    first = SCANRS_D2H_VALUE(cp.indptr.p, st->stream);
+    last = SCANRS_D2H_VALUE(cp.indptr.p + cp.n_outer, st->stream);
     SCANRS_SYNC(st->stream);
     if (first != 0) fail(SCANRS_ERR_ARGUMENT, "indptr[0] must be 0");
     cp.nnz = last;
@@ -1077,9 +1191,7 @@ static void binom_impl(scanrs_mat *m, int kind) {
     axis_sums(m, 1, 1, rowsum, nullptr); // sum_axis::<f64>(Axis(1))
     launch_sum_f64(st, n->p, C, tot);
     if (cols_sharded(m)) allreduce_f64(st, tot, 1);
-    double total = 0.0;
-    SCANRS_HIP(hipMemcpyAsync(&total, tot, 8, hipMemcpyDeviceToHost, st.stream));
-    SCANRS_SYNC(st.stream);
+    const double total = SCANRS_D2H_VALUE(tot, st.stream);
     launch_binom_uv(st, kind, n->p, C, rowsum, R, total, pi->p, u->p, v->p);
     MapOp op;
     op.kind = kind;
@@ -1172,8 +1284,12 @@ int scanrs_mat_create_adaptive(uint64_t rows, uint64_t cols, int storage, const 
     });
 }
 void scanrs_mat_free(scanrs_mat *m) {
+    if (!m) return;
+    const Storage *owner = m->st.get();
+    const bool last = m->st.use_count() == 1;
     delete m;
-    device_free_flush(); // the handle's buffers (when this was the last view of its storage): their streams were drained by the destructor
+    // the handle's buffers (when this was the last view of its storage): its streams were drained by the destructor, nobody else queued work on them
+    if (last) device_free_flush_owner_gone(owner);
 }
 
 int scanrs_mat_view(const scanrs_mat *m, scanrs_mat **out) {
@@ -1934,7 +2050,7 @@ int scanrs_mat_set_panel_precision(scanrs_mat *m, int precision) {
 int scanrs_mat_sync(scanrs_mat *m) {
     return guard([&] {
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
-        CurrentHandle cur(m->st.get());
+        CurrentHandle cur(m->st.get(), true);
         SCANRS_SYNC(m->st->stream);
         device_free_flush();
     });

@@ -54,10 +54,26 @@ void set_sync_timeout_s(double s);
 // the handle whose streams a timed-out wait on this thread reports (set by the entry points that run device work)
 struct CurrentHandle {
     const Storage *prev;
-    explicit CurrentHandle(const Storage *st);
+    // Every entry point that queues device work makes one: after a timed-out wait (device_lost) it refuses until the device has been seen
+    // idle again. `waits_only`: an entry point that only waits (scanrs_mat_sync) - the way to get there.
+    explicit CurrentHandle(const Storage *st, bool waits_only = false);
     ~CurrentHandle();
 };
 #define SCANRS_SYNC(stream) ::scanrs::wait_stream((stream), __PRETTY_FUNCTION__, __FILE__, __LINE__)
+// A few bytes from the device whose landing place outlives a timed-out wait (copies into stack variables of a frame that a
+// timeout unwinds would land in whatever lives there later): the copy goes into a slot of a process-wide pinned ring and is read from
+// there behind the wait; when the wait gives up, the slot is simply not read.
+void *landing_slot(size_t bytes); // capi.cpp: 8-byte aligned, from a pinned ring of 1 MB that is never unmapped
+template <typename T>
+inline T d2h_value(const T *d, hipStream_t s, const char *func, const char *file, int line) {
+    T *slot = static_cast<T *>(landing_slot(sizeof(T)));
+    const hipError_t e = hipMemcpyAsync(slot, d, sizeof(T), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) ::scanrs::fail(SCANRS_ERR_DEVICE, "hipMemcpyAsync failed: %s (%s:%d)", hipGetErrorString(e), file, line);
+    void wait_stream(hipStream_t s, const char *func, const char *file, int line);
+    wait_stream(s, func, file, line);
+    return *slot;
+}
+#define SCANRS_D2H_VALUE(dptr, stream) ::scanrs::d2h_value((dptr), (stream), __PRETTY_FUNCTION__, __FILE__, __LINE__)
 #define SCANRS_SYNC_EVENT(ev) ::scanrs::wait_event((ev), __PRETTY_FUNCTION__, __FILE__, __LINE__)
 struct Tick {
     const char *what;
@@ -77,7 +93,9 @@ struct Tick {
 // to a process-wide list that is emptied where the device is known to be idle (end of create / a solver / scanrs_mat_sync /
 // scanrs_mat_free) — or when an allocation fails for lack of memory, which then tries again.
 void device_free_later(void *p, size_t bytes);
-void device_free_flush() noexcept;
+void device_free_flush() noexcept;                             // blocks released by the calling thread's current handle, if all of that handle's streams are idle
+void device_free_flush_owner_gone(const void *owner) noexcept; // blocks of a handle that has just been destroyed
+bool device_lost();                                            // a bounded wait gave up earlier: nothing is reused or freed, entry points fail fast
 void *device_alloc(size_t bytes); // hipMalloc with the retry above; throws Failure(SCANRS_ERR_DEVICE)
 void device_cache_release() noexcept;
 void device_reserve(size_t bytes);

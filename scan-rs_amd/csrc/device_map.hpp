@@ -176,10 +176,13 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t lane) {
 // acc += w[lane n of this lane's row of 16] * x: the broadcast of the weight happens inside the instruction (DPP), where the
 // round-3 form spent two v_readlane per general position. Nothing in front of it may have written `w` (2 wait states) or
 // EXEC (5) with a vector instruction, and every lane must be switched on (a lane whose source lane is off is not written).
-// tiles.hip: the weights come from a load, nothing in the position loop writes EXEC.
+// tiles.hip: the weights come from a load, nothing in the position loop writes EXEC. The hazard recognizer does not look into inline
+// assembly, so the two wait states travel with the instruction (s_nop 1: a register copy the allocator might place in front of it
+// is then harmless; its issue slot hides in the software pipeline). The dense kernel's stream (tile_dense_body.inc) is generated:
+// its weights are written by ds_bpermute_b32 and waited for with lgkmcnt, no vector instruction writes them.
 __device__ __forceinline__ double fmac_bcast(double acc, double w, double x, int n) {
 #define SCANRS_FB(N) \
-    case N: asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:" #N " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(x)); break;
+    case N: asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #N " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(w), "v"(x)); break;
     switch (n) {
         SCANRS_FB(0) SCANRS_FB(1) SCANRS_FB(2) SCANRS_FB(3) SCANRS_FB(4) SCANRS_FB(5) SCANRS_FB(6) SCANRS_FB(7)
         SCANRS_FB(8) SCANRS_FB(9) SCANRS_FB(10) SCANRS_FB(11) SCANRS_FB(12) SCANRS_FB(13) SCANRS_FB(14) SCANRS_FB(15)

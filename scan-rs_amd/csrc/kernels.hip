@@ -2378,9 +2378,7 @@ static bool col_moments_plan(Storage &st, SparseCopy &cp, const DevMap &map, int
         uint32_t *d = st.scratch.get<uint32_t>("cm_maxv", 1);
         SCANRS_HIP(hipMemsetAsync(d, 0, 4, st.stream));
         hipLaunchKernelGGL(max_u32_kernel, dim3(2048), dim3(256), 0, st.stream, cp.values.p, cp.nnz, d);
-        uint32_t h = 0;
-        SCANRS_HIP(hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, st.stream));
-        SCANRS_SYNC(st.stream);
+        const uint32_t h = SCANRS_D2H_VALUE(d, st.stream);
         cp.max_value = std::max(h, 1u);
     }
     double x = (double)cp.max_value;
@@ -2391,9 +2389,11 @@ static bool col_moments_plan(Storage &st, SparseCopy &cp, const DevMap &map, int
             const unsigned long long init[3] = {~0ull, 0ull, 0ull};
             SCANRS_HIP(hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, st.stream));
             hipLaunchKernelGGL(minmax_nonneg_kernel, dim3(512), dim3(256), 0, st.stream, map.ops[i].a, cp.n_outer, d);
-            unsigned long long h[3];
-            SCANRS_HIP(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, st.stream));
-            SCANRS_SYNC(st.stream);
+            struct H3 {
+                unsigned long long v[3];
+            };
+            const H3 h3 = SCANRS_D2H_VALUE(reinterpret_cast<const H3 *>(d), st.stream);
+            const unsigned long long *h = h3.v;
             if (h[2]) return false;
             double amax;
             memcpy(&amax, &h[1], 8);
@@ -2577,10 +2577,7 @@ void SparseCopy::build_items(hipStream_t s) {
     DevBuf<char> tmp(std::max<size_t>(tmp_bytes, 16));
     SCANRS_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, cnt.p, off.p, 0ull, n, rocprim::plus<unsigned long long>(), s));
     SCANRS_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, cnt.p + n, off.p + n, 0ull, n, rocprim::plus<unsigned long long>(), s));
-    unsigned long long tot[2] = {0, 0};
-    SCANRS_HIP(hipMemcpyAsync(&tot[0], off.p + n_outer, 8, hipMemcpyDeviceToHost, s));
-    SCANRS_HIP(hipMemcpyAsync(&tot[1], off.p + n + n_outer, 8, hipMemcpyDeviceToHost, s));
-    SCANRS_SYNC(s);
+    const unsigned long long tot[2] = {SCANRS_D2H_VALUE(off.p + n_outer, s), SCANRS_D2H_VALUE(off.p + n + n_outer, s)};
     if (tot[0] > 0xFFFFFFFFull) fail(SCANRS_ERR_SHAPE, "matrix needs more than 2^32 - 1 work items");
     n_items = (uint32_t)tot[0];
     n_multi = (uint32_t)tot[1];
@@ -2597,9 +2594,8 @@ void validate_copy(Storage &st, SparseCopy &cp, uint64_t *zeros, uint64_t *bad) 
     SCANRS_HIP(hipMemsetAsync(c.p, 0, 4 * sizeof(unsigned long long), st.stream));
     if (cp.n_outer) {
         hipLaunchKernelGGL(validate_starts_kernel, grid1(cp.n_outer, 256), dim3(256), 0, st.stream, cp.indptr.p, cp.n_outer, cp.indices.p, cp.nnz, c.p);
-        unsigned long long h1 = 0; // a broken indptr first: the streaming pass below trusts nnz only, the later passes trust indptr
-        SCANRS_HIP(hipMemcpyAsync(&h1, c.p + 1, 8, hipMemcpyDeviceToHost, st.stream));
-        SCANRS_SYNC(st.stream);
+        // a broken indptr first: the streaming pass below trusts nnz only, the later passes trust indptr
+        const unsigned long long h1 = SCANRS_D2H_VALUE(c.p + 1, st.stream);
         if (h1) {
             *zeros = 0;
             *bad = h1;
@@ -2614,9 +2610,11 @@ void validate_copy(Storage &st, SparseCopy &cp, uint64_t *zeros, uint64_t *bad) 
         const unsigned blocks = (unsigned)std::min<uint64_t>((n4 + 255) / 256, (uint64_t)n_cu * 16u);
         hipLaunchKernelGGL(validate_stream_kernel, dim3(blocks), dim3(256), 0, st.stream, cp.indices.p, cp.values.p, cp.nnz, cp.n_inner, c.p);
     }
-    unsigned long long h[4];
-    SCANRS_HIP(hipMemcpyAsync(h, c.p, sizeof(h), hipMemcpyDeviceToHost, st.stream));
-    SCANRS_SYNC(st.stream);
+    struct H4 {
+        unsigned long long v[4];
+    };
+    const H4 h4 = SCANRS_D2H_VALUE(reinterpret_cast<const H4 *>(c.p), st.stream);
+    const unsigned long long *h = h4.v;
     *zeros = h[0];
     *bad = h[1] - std::min(h[1], h[2]);
     if (cp.nnz) cp.max_value = (uint32_t)std::max<unsigned long long>(1ull, h[3]);

@@ -241,7 +241,11 @@ static void upload_panel(Ctx &c, const double *h, uint64_t rows, uint32_t l, dou
 // Large factors (the cell-side PcaResult panel is 400 MB at 10^6 x 50) go to the caller's pageable array through a
 // ring of pinned slots: the DMA engine fills slot i + 1 at link speed while host threads copy slot i out — a
 // direct copy into pageable memory is staged by the runtime on one thread (5.7 GB/s measured, 70 ms of a 580 ms call).
-static void download_panel_staged(Ctx &c, const double *d, uint32_t ld, uint64_t rows, uint32_t l, double *h) {
+// `gate(first_row, end_row)` (optional) is called before the copy of those rows is queued: the caller makes `cs` wait for whatever
+// still produces them (ritz_finish: the row block of the last GEMM, so that the copy of finished blocks runs beside the later ones).
+static void download_panel_staged(Ctx &c, const double *d, uint32_t ld, uint64_t rows, uint32_t l, double *h, hipStream_t cs = nullptr,
+                                  const std::function<void(uint64_t, uint64_t)> &gate = nullptr) {
+    if (!cs) cs = c.s;
     constexpr int NS = 8;            // slots in flight
     constexpr size_t SLOT = 8u << 20; // bytes per slot
     const size_t row_bytes = (size_t)l * 8;
@@ -282,19 +286,20 @@ static void download_panel_staged(Ctx &c, const double *d, uint32_t ld, uint64_t
         for (size_t i = 0; i < n_chunks; i++) {
             if (i >= NS)
                 while (!done[i - NS].load(std::memory_order_acquire)) std::this_thread::yield();
+            if (gate) gate((uint64_t)i * slot_rows, (uint64_t)i * slot_rows + chunk_rows(i));
             if (ld == l) // contiguous rows: a plain copy (the DMA engine's fast path; the pitched form runs at about half its rate)
                 SCANRS_HIP(hipMemcpyAsync(stage + (i % NS) * slot_rows * row_bytes, d + (size_t)i * slot_rows * ld, chunk_rows(i) * row_bytes,
-                                          hipMemcpyDeviceToHost, c.s));
+                                          hipMemcpyDeviceToHost, cs));
             else
                 SCANRS_HIP(hipMemcpy2DAsync(stage + (i % NS) * slot_rows * row_bytes, row_bytes, d + (size_t)i * slot_rows * ld, (size_t)ld * 8,
-                                            row_bytes, chunk_rows(i), hipMemcpyDeviceToHost, c.s));
-            SCANRS_HIP(hipEventRecord(ev[i % NS], c.s));
+                                            row_bytes, chunk_rows(i), hipMemcpyDeviceToHost, cs));
+            SCANRS_HIP(hipEventRecord(ev[i % NS], cs));
             if (i >= 1) {
                 SCANRS_SYNC_EVENT(ev[(i - 1) % NS]);
                 ready.store(i, std::memory_order_release);
             }
         }
-        c.sync();
+        SCANRS_SYNC(cs);
         ready.store(n_chunks, std::memory_order_release);
     } catch (...) {
         stop.store(true);
@@ -769,8 +774,11 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
     launch_gemm_nn(c.st, Q, ldq, q, dE, k, k, ds, 1.0, 0.0, nullptr, 0, dS, ldk);
     double *dEs = c.dev("ritz_es", (size_t)q * k);
     c.h2d(dEs, Es.data(), Es.size());
-    launch_gemm_nn(c.st, T, ldt, q, dEs, k, k, dt, 1.0, 0.0, nullptr, 0, dT, ldk);
-    {
+    // The T-side factor (10^6 x 50 at the headline size: a 2.5 ms GEMM, then 400 MB to the host) in row blocks: the copy of a finished block
+    // runs on a second stream beside the GEMM of the later ones (round 5; before: GEMM, then the whole copy)
+    const bool piped = hT != nullptr && dt * (uint64_t)k * 8 >= (64u << 20) && ldk == k;
+    if (!piped) {
+        launch_gemm_nn(c.st, T, ldt, q, dEs, k, k, dt, 1.0, 0.0, nullptr, 0, dT, ldk);
         stage_mark("ritz factors sync");
         c.sync();
         stage_mark("ritz factors synced");
@@ -779,6 +787,34 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
         if (hS) download_panel(c, dS, ldk, ds, k, hS); // null: the caller keeps the result in HBM (scanrs_pca_result_device)
         if (hT) download_panel(c, dT, ldk, dt, k, hT);
         c.sync();
+        c.st.t_delivery_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    } else {
+        constexpr int NBLK = 8;
+        const uint64_t blk = (((dt + NBLK - 1) / NBLK) + 1023) & ~1023ull;
+        hipEvent_t bev[NBLK];
+        int n_blk = 0;
+        for (uint64_t r0 = 0; r0 < dt; r0 += blk, n_blk++) {
+            const uint64_t nr = std::min<uint64_t>(blk, dt - r0);
+            launch_gemm_nn(c.st, T + r0 * ldt, ldt, q, dEs, k, k, nr, 1.0, 0.0, nullptr, 0, dT + r0 * ldk, ldk);
+            SCANRS_HIP(hipEventCreateWithFlags(&bev[n_blk], hipEventDisableTiming));
+            SCANRS_HIP(hipEventRecord(bev[n_blk], c.s));
+        }
+        Tick tk("ritz: download of the factors (beside the last GEMM)");
+        const auto t0 = std::chrono::steady_clock::now();
+        hipStream_t cs = c.st.aux2();
+        int waited = -1;
+        try {
+            download_panel_staged(c, dT, ldk, dt, k, hT, cs, [&](uint64_t r0, uint64_t r1) {
+                const int need = (int)((r1 - 1) / blk);
+                while (waited < need) SCANRS_HIP(hipStreamWaitEvent(cs, bev[++waited], 0));
+            });
+            if (hS) download_panel(c, dS, ldk, ds, k, hS);
+            c.sync();
+        } catch (...) {
+            for (int i = 0; i < n_blk; i++) (void)hipEventDestroy(bev[i]);
+            throw;
+        }
+        for (int i = 0; i < n_blk; i++) (void)hipEventDestroy(bev[i]);
         c.st.t_delivery_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     }
     // where the factors live on the device: side S first, side T second (the drivers map them to U / V)

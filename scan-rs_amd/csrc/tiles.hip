@@ -943,9 +943,8 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     SCANRS_HIP(rocprim::reduce(nullptr, tmp_bytes_m, mult.p, d_max, 0u, (size_t)cp.n_outer + 1, rocprim::maximum<uint32_t>(), s));
     DevBuf<char> tmp_m(std::max<size_t>(tmp_bytes_m, 16));
     SCANRS_HIP(rocprim::reduce(tmp_m.p, tmp_bytes_m, mult.p, d_max, 0u, (size_t)cp.n_outer + 1, rocprim::maximum<uint32_t>(), s));
-    SCANRS_HIP(hipMemcpyAsync(&n_slots32, tl->slot_first.p + cp.n_outer, 4, hipMemcpyDeviceToHost, s));
-    SCANRS_HIP(hipMemcpyAsync(&tl->max_mult, d_max, 4, hipMemcpyDeviceToHost, s));
-    SCANRS_SYNC(s);
+    n_slots32 = SCANRS_D2H_VALUE(tl->slot_first.p + cp.n_outer, s);
+    tl->max_mult = SCANRS_D2H_VALUE(d_max, s);
     tl->n_slots = n_slots32; // (a u32 scan: a sum past 2^32 would need > 2^32 vectors x 32 slots; the visit-index check below bounds it far lower)
     tl->slot_vec.alloc(std::max<uint64_t>(tl->n_slots, 1));
     hipLaunchKernelGGL(tile_slotvec_kernel, grid_1d(std::max<uint64_t>(cp.n_outer, 1)), dim3(256), 0, s, tl->slot_first.p, cp.n_outer, tl->slot_vec.p);
@@ -1029,8 +1028,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     DevBuf<char> tmp(std::max<size_t>(tmp_bytes, 16));
     SCANRS_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, ovc.p, ovo.p, 0ull, (size_t)n_seg + 1, rocprim::plus<unsigned long long>(), s));
     unsigned long long n_ov = 0;
-    SCANRS_HIP(hipMemcpyAsync(&n_ov, ovo.p + n_seg, 8, hipMemcpyDeviceToHost, s));
-    SCANRS_SYNC(s);
+    n_ov = SCANRS_D2H_VALUE(ovo.p + n_seg, s);
     lap("count + scan");
     if (max_overflow > 0.0 && (double)n_ov > max_overflow * (double)cp.nnz) {
         if (trace_on())
@@ -1603,7 +1601,17 @@ bool tile_layout_build_auto(Storage &st, SparseCopy &cp, hipStream_t s) {
     // gene_shape=0.1 shared_profile=1; the cell-major layout of the same matrix: 5.8 %, 19.5 ms). Such an orientation stays on
     // the gather kernels, and is not tried again until the tile shape changes.
     cp.tiles.reset();
-    TileLayout *t = tile_layout_build(st, cp, st.tile_max_overflow, s);
+    TileLayout *t = nullptr;
+    try {
+        t = tile_layout_build(st, cp, st.tile_max_overflow, s);
+    } catch (const Failure &e) {
+        // the room check above is an estimate (cached blocks of other devices, blocks carved from a reserve): when the build
+        // itself runs out of device memory the product falls back to the gather kernels instead of failing the solver. Other failures pass.
+        if (e.code != SCANRS_ERR_DEVICE || !strstr(scanrs_last_error(), "hipMalloc")) throw;
+        if (trace_on()) fprintf(stderr, "[scanrs trace] tile layout: not built, the device ran out of memory during the build (%s) -> gather kernels\n", scanrs_last_error());
+        (void)wait_stream_quiet(s);
+        return false; // (not remembered as rejected: a later call, with the solver's temporaries gone, may have the room)
+    }
     if (!t) {
         cp.tile_rejected_shape = tile_shape_signature(st);
         return false;
