@@ -79,8 +79,9 @@ def parse():
     ap.add_argument("--cpu-cells-all", type=int, default=100000, help="cells of the all-core CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reserve", action="store_true", help="do not reserve device memory ahead of the handle (scanrs_reserve_device_memory)")
-    ap.add_argument("--reserve-bytes-per-nnz", type=float, default=66.0,
-                    help="size of that reserve per nonzero of the shard (+ 1 GB): what the handle keeps (57 B per nonzero) + part of the transposition's temporaries")
+    ap.add_argument("--reserve-bytes-per-nnz", type=float, default=84.0,
+                    help="size of that reserve per nonzero of the shard (+ 1 GB): what the handle keeps after its first PCA - both copies of the matrix 16, "
+                         "both tile layouts 2 x 13.2, the solver's panels 23-26, small change - with the build's temporaries in the room the panels take later")
     ap.add_argument("--no-heavy-tailed", action="store_true", help="skip the second, clearly labelled measurement on the heavy-tailed gene profile")
     ap.add_argument("--no-host-delivery", action="store_true", help="leave U and V in HBM in every step (value is then the device-resident rate)")
     ap.add_argument("--f32-panels", action="store_true",

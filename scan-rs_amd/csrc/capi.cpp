@@ -60,6 +60,7 @@ struct StageRing {
 };
 thread_local StageRing tl_stages;
 thread_local const Storage *tl_handle = nullptr;
+thread_local const Storage *tl_dying = nullptr; // scanrs_mat_free: the storage whose members are being destroyed on this thread (its streams are drained)
 
 std::atomic<double> g_sync_timeout_s{120.0};
 } // namespace
@@ -298,18 +299,56 @@ struct Block {
 };
 struct Reserve { // one large allocation made ahead of time (scanrs_reserve_device_memory) that later requests are carved from
     char *base;
-    size_t size, used;
+    size_t size;
     int dev;
+    std::map<size_t, size_t> holes; // offset -> length of every unused stretch, neighbours merged: released blocks are reusable at any size
+    size_t unused() const {
+        size_t n = 0;
+        for (auto &h : holes) n += h.second;
+        return n;
+    }
+    bool owns(const void *p) const { return (const char *)p >= base && (const char *)p < base + size; }
+    // best fit (the smallest hole that holds it: the big holes stay whole for the big requests); nullptr when none does
+    void *take(size_t want) {
+        auto best = holes.end();
+        for (auto it = holes.begin(); it != holes.end(); ++it)
+            if (it->second >= want && (best == holes.end() || it->second < best->second)) best = it;
+        if (best == holes.end()) return nullptr;
+        const size_t off = best->first, len = best->second;
+        holes.erase(best);
+        if (len > want) holes.emplace(off + want, len - want);
+        return base + off;
+    }
+    void give(void *p, size_t len) {
+        size_t off = (size_t)((char *)p - base);
+        auto next = holes.lower_bound(off);
+        if (next != holes.begin()) {
+            auto prev = std::prev(next);
+            if (prev->first + prev->second == off) {
+                off = prev->first;
+                len += prev->second;
+                holes.erase(prev);
+            }
+        }
+        if (next != holes.end() && off + len == next->first) {
+            len += next->second;
+            holes.erase(next);
+        }
+        holes.emplace(off, len);
+    }
 };
 struct DeadBlock {
     void *p;
     const Storage *owner; // the handle that was current on the releasing thread (nullptr: none)
+    hipEvent_t ev[5];     // recorded at the release on every stream of the owner: work queued before the release is done when they are
+    int n_ev;
 };
 struct DeviceMemory {
     std::mutex mu;
-    std::vector<DeadBlock> dead;                        // released by their owners, waiting for a point where the OWNER's streams are idle
+    std::vector<DeadBlock> dead;                        // released by their owners, waiting for their release events
+    std::vector<hipEvent_t> release_events;             // spare events (created once, reused)
     std::map<void *, std::pair<size_t, int>> live;      // every block handed out: pointer -> (size, device)
-    std::vector<Reserve> reserves;                      // blocks carved from a reserve are never given back one by one: they stay in the cache
+    std::vector<Reserve> reserves;                      // blocks carved from a reserve go back into it (Reserve::give), never to the driver one by one
     std::multimap<std::pair<int, size_t>, void *> idle; // cached blocks by (device, size)
     size_t idle_bytes = 0;
     double cache_fraction = 0.5; // of the device's memory; 0: no cache (every released block goes back to the driver)
@@ -322,11 +361,39 @@ std::atomic<uint64_t> g_alloc_us{0}, g_alloc_calls{0};
 constexpr size_t CACHE_MIN = 1u << 20; // smaller blocks go straight back
 size_t round_block(size_t bytes) { return bytes >= CACHE_MIN ? (bytes + (2u << 20) - 1) & ~((size_t)(2u << 20) - 1) : bytes; }
 } // namespace
+// A released block may be handed out again once everything that was queued BEFORE the release, on any stream of the releasing handle
+// (main, the two auxiliary ones, the overflow gather's, the helper thread's), has run: one event per such stream, recorded here. Work
+// queued later cannot name the block. (hipFree used to give this guarantee by waiting for the whole device; ADVICE r4: a process-wide
+// list flushed by whoever saw its own main stream idle did not.)
 void device_free_later(void *p, size_t) {
     if (!p) return;
+    DeadBlock db{p, tl_handle, {nullptr, nullptr, nullptr, nullptr, nullptr}, 0};
     DeviceMemory &g = devmem();
+    if (!tl_handle && tl_dying) {
+        db.owner = tl_dying; // a member of a handle that is being destroyed: its destructor has drained every stream that could name the block
+    } else if (const Storage *st = tl_handle) {
+        hipStream_t list[5] = {st->stream, st->aux_stream, st->aux2_stream, st->ov_stream, storage_side_stream(*st)};
+        for (hipStream_t q : list) {
+            if (!q) continue;
+            hipEvent_t e = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(g.mu);
+                if (!g.release_events.empty()) {
+                    e = g.release_events.back();
+                    g.release_events.pop_back();
+                }
+            }
+            if ((!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) || hipEventRecord(e, q) != hipSuccess) {
+                (void)hipGetLastError();
+                if (e) (void)hipEventDestroy(e);
+                db.owner = nullptr; // no proof of completion for this one: it waits for a device-wide idle point
+                continue;
+            }
+            db.ev[db.n_ev++] = e;
+        }
+    }
     std::lock_guard<std::mutex> lk(g.mu);
-    g.dead.push_back(DeadBlock{p, tl_handle});
+    g.dead.push_back(db);
 }
 // every stream a handle queues work on (main, the two auxiliary ones, the overflow gather's, the helper thread's) has run dry
 static bool storage_streams_idle(const Storage *st) {
@@ -347,15 +414,11 @@ static bool storage_streams_idle(const Storage *st) {
 // the tens of GB a handle holds (the second and third handle of one process took 2.4 / 4.1 s for their first PCA instead of 0.4).
 // At most `device_cache_fraction` (default one half) of the device's memory is kept; scanrs_release_cached_memory() and a failed
 // allocation empty the cache.
-// Moves released blocks to the cache (or back to the driver). A block is only touched when the handle that released it is known to
-// have no work in flight on ANY of its streams: `owner` = the handle whose blocks to look at (default: the calling thread's current
-// one; blocks released outside any handle go with it), `everything` = the caller has just seen the whole device idle.
-// the list used to be process-wide and a caller proved only that its own main stream was idle - a block another handle (or
-// this handle's helper thread / auxiliary stream) still used could be handed out again.
-static void device_free_flush_impl(const Storage *owner, bool owner_gone, bool everything) noexcept {
+// Moves released blocks to the cache (or back to the driver): those whose release events have completed (device_free_later); with
+// `owner_gone` also every block of that (destroyed) handle; with `everything` (the caller has just seen the whole device idle) all.
+static void device_free_flush_impl(const Storage *owner, bool owner_gone, bool everything, bool cache_only = false) noexcept {
     DeviceMemory &g = devmem();
     if (device_lost()) return; // kernels of a timed-out call may still use them: leaked on purpose
-    if (!everything && !owner_gone && !storage_streams_idle(owner)) return;
     std::vector<Block> to_free;
     {
         std::lock_guard<std::mutex> lk(g.mu);
@@ -366,19 +429,44 @@ static void device_free_flush_impl(const Storage *owner, bool owner_gone, bool e
             if (hipMemGetInfo(&fr, &tot) == hipSuccess) cap = (size_t)((double)tot * g.cache_fraction);
         }
         std::vector<DeadBlock> keep;
-        for (const DeadBlock &db : g.dead) {
-            if (!everything && db.owner != owner && !(db.owner == nullptr && owner != nullptr)) {
+        for (DeadBlock &db : g.dead) {
+            // done with: its release events have all completed / its owner is gone (streams drained by the destructor) / the caller has
+            // just seen the whole device idle. A block released outside any handle waits for the last case.
+            bool done = everything || (owner_gone && db.owner == owner);
+            if (!done && db.owner != nullptr) {
+                done = true;
+                for (int i = 0; i < db.n_ev && done; i++) {
+                    const hipError_t e = hipEventQuery(db.ev[i]);
+                    if (e != hipSuccess) {
+                        (void)hipGetLastError();
+                        done = false;
+                    }
+                }
+            }
+            if (!done) {
                 keep.push_back(db);
                 continue;
             }
             void *p = db.p;
             auto it = g.live.find(p);
-            if (it == g.live.end()) continue; // not ours (cannot happen)
+            if (it == g.live.end()) { // not ours (cannot happen)
+                for (int i = 0; i < db.n_ev; i++) g.release_events.push_back(db.ev[i]);
+                continue;
+            }
             const Block b{p, it->second.first, it->second.second};
+            Reserve *home = nullptr;
+            for (Reserve &r : g.reserves)
+                if (r.owns(p)) home = &r;
+            const bool to_cache = home || (b.size >= CACHE_MIN && g.idle_bytes + b.size <= cap);
+            if (!to_cache && cache_only) { // in the middle of a call: hipFree would wait for the whole device, the block stays on the list
+                keep.push_back(db);
+                continue;
+            }
+            for (int i = 0; i < db.n_ev; i++) g.release_events.push_back(db.ev[i]);
             g.live.erase(it);
-            bool carved = false;
-            for (const Reserve &r : g.reserves) carved = carved || ((char *)p >= r.base && (char *)p < r.base + r.size);
-            if (carved || (b.size >= CACHE_MIN && g.idle_bytes + b.size <= cap)) {
+            if (home) {
+                home->give(p, b.size);
+            } else if (to_cache) {
                 g.idle.emplace(std::make_pair(b.dev, b.size), p);
                 g.idle_bytes += b.size;
             } else {
@@ -417,23 +505,18 @@ void device_cache_release() noexcept {
     std::vector<void *> take;
     {
         std::lock_guard<std::mutex> lk(g.mu);
-        bool any_live_in_reserve = false;
-        for (auto &kv : g.live)
-            for (const Reserve &r : g.reserves) any_live_in_reserve = any_live_in_reserve || ((char *)kv.first >= r.base && (char *)kv.first < r.base + r.size);
         for (auto it = g.idle.begin(); it != g.idle.end();) {
-            bool carved = false;
-            for (const Reserve &r : g.reserves) carved = carved || ((char *)it->second >= r.base && (char *)it->second < r.base + r.size);
-            if (carved && any_live_in_reserve) { // part of a reserve that is still in use: stays
-                ++it;
-                continue;
-            }
-            if (!carved) take.push_back(it->second);
+            take.push_back(it->second);
             g.idle_bytes -= it->first.second;
             it = g.idle.erase(it);
         }
-        if (!any_live_in_reserve) { // nothing handed out from the reserves any more: they go back whole
-            for (const Reserve &r : g.reserves) take.push_back(r.base);
-            g.reserves.clear();
+        for (auto it = g.reserves.begin(); it != g.reserves.end();) { // a reserve nothing is handed out from any more goes back whole
+            if (it->unused() == it->size) {
+                take.push_back(it->base);
+                it = g.reserves.erase(it);
+            } else {
+                ++it;
+            }
         }
     }
     for (void *p : take) (void)hipFree(p);
@@ -450,7 +533,9 @@ void device_reserve(size_t bytes) {
         fail(SCANRS_ERR_DEVICE, "reserving %.2f GB of device memory failed: %s", (double)bytes / 1e9, hipGetErrorString(e));
     }
     std::lock_guard<std::mutex> lk(g.mu);
-    g.reserves.push_back(Reserve{(char *)p, bytes, 0, dev});
+    Reserve r{(char *)p, bytes, dev, {}};
+    r.holes.emplace(0, bytes);
+    g.reserves.push_back(std::move(r));
 }
 void device_cache_set_fraction(double f) {
     DeviceMemory &g = devmem();
@@ -462,8 +547,46 @@ void device_cache_set_fraction(double f) {
 }
 size_t device_cache_bytes() {
     DeviceMemory &g = devmem();
+    device_free_flush_impl(nullptr, false, false, true); // released blocks whose events have completed count
     std::lock_guard<std::mutex> lk(g.mu);
     return g.idle_bytes;
+}
+// what scanrs_reserve_device_memory set aside on this device and nobody has been handed yet
+size_t device_reserve_unused_bytes() {
+    DeviceMemory &g = devmem();
+    device_free_flush_impl(nullptr, false, false, true);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g.mu);
+    size_t n = 0;
+    for (const Reserve &r : g.reserves)
+        if (r.dev == dev) n += r.unused();
+    return n;
+}
+// SCANRS_TRACE: what the library holds on the device, block by block (>= 256 MB), and what its reserves have left
+static void device_memory_report(const char *why) {
+    DeviceMemory &g = devmem();
+    std::lock_guard<std::mutex> lk(g.mu);
+    std::vector<size_t> big;
+    size_t live = 0, dead = 0;
+    for (auto &kv : g.live) {
+        live += kv.second.first;
+        if (kv.second.first >= (256u << 20)) big.push_back(kv.second.first);
+    }
+    for (auto &db : g.dead) {
+        auto it = g.live.find(db.p);
+        if (it != g.live.end()) dead += it->second.first;
+    }
+    std::sort(big.begin(), big.end(), std::greater<size_t>());
+    fprintf(stderr, "[scanrs trace] device memory (%s): %.2f GB in %zu blocks (%.2f GB of them released, waiting for their events), %.2f GB cached; blocks of 256 MB and more:", why,
+            (double)live / 1e9, g.live.size(), (double)dead / 1e9, (double)g.idle_bytes / 1e9);
+    for (size_t b : big) fprintf(stderr, " %.2f", (double)b / 1e9);
+    fprintf(stderr, "\n");
+    for (const Reserve &r : g.reserves) {
+        fprintf(stderr, "[scanrs trace]   reserve of %.2f GB on device %d, unused %.2f GB in %zu stretches:", (double)r.size / 1e9, r.dev, (double)r.unused() / 1e9, r.holes.size());
+        for (auto &h : r.holes) fprintf(stderr, " %.2f", (double)h.second / 1e9);
+        fprintf(stderr, "\n");
+    }
 }
 size_t device_live_bytes() {
     DeviceMemory &g = devmem();
@@ -478,6 +601,12 @@ void *device_alloc(size_t bytes) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (want >= CACHE_MIN) { // a cached block of this size, or up to 1/8 larger
+        bool any_dead;
+        {
+            std::lock_guard<std::mutex> lk(g.mu);
+            any_dead = !g.dead.empty();
+        }
+        if (any_dead) device_free_flush_impl(nullptr, false, false, true); // blocks whose release events have completed join the cache first
         std::lock_guard<std::mutex> lk(g.mu);
         auto it = g.idle.lower_bound(std::make_pair(dev, want));
         if (it != g.idle.end() && it->first.first == dev && it->first.second <= want + want / 8) {
@@ -490,14 +619,15 @@ void *device_alloc(size_t bytes) {
     }
     if (want >= CACHE_MIN) { // carve from a reserve made ahead of time
         std::lock_guard<std::mutex> lk(g.mu);
-        for (Reserve &r : g.reserves)
-            if (r.dev == dev && r.size - r.used >= want) {
-                void *p = r.base + r.used;
-                r.used += want;
+        for (Reserve &r : g.reserves) {
+            if (r.dev != dev) continue;
+            if (void *p = r.take(want)) {
                 g.live[p] = std::make_pair(want, dev);
                 return p;
             }
+        }
     }
+    if (want >= (1u << 30) && trace_on()) device_memory_report("no cached block and no reserve holds the request, asking the driver");
     void *p = nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, want);
@@ -1251,6 +1381,7 @@ int scanrs_device_memory_in_use(uint64_t *bytes) {
         if (!bytes) fail(SCANRS_ERR_ARGUMENT, "null argument");
         device_free_flush();
         *bytes = device_live_bytes();
+        if (trace_on()) device_memory_report("scanrs_device_memory_in_use");
     });
 }
 
@@ -1287,7 +1418,9 @@ void scanrs_mat_free(scanrs_mat *m) {
     if (!m) return;
     const Storage *owner = m->st.get();
     const bool last = m->st.use_count() == 1;
+    tl_dying = last ? owner : nullptr;
     delete m;
+    tl_dying = nullptr;
     // the handle's buffers (when this was the last view of its storage): its streams were drained by the destructor, nobody else queued work on them
     if (last) device_free_flush_owner_gone(owner);
 }

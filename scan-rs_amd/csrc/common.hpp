@@ -90,10 +90,11 @@ struct Tick {
 // hipFree waits for the whole device (a buffer dropped while a 20 ms sparse pass runs holds the host for those 20 ms), and VRAM
 // that was just freed is scrubbed in the background: an allocation right behind a large free waits for the scrubber (0.24 s
 // per 8 GB, profiles/microbench/alloc_probe2). So buffers are never freed in the middle of a call: release() hands the pointer
-// to a process-wide list that is emptied where the device is known to be idle (end of create / a solver / scanrs_mat_sync /
-// scanrs_mat_free) — or when an allocation fails for lack of memory, which then tries again.
+// to a list, together with one event per stream of the releasing handle; a block whose events have completed joins the cache at the
+// next allocation, and goes back to the driver only where a call ends (end of create / a solver / scanrs_mat_sync / scanrs_mat_free)
+// or when an allocation fails for lack of memory, which then tries again.
 void device_free_later(void *p, size_t bytes);
-void device_free_flush() noexcept;                             // blocks released by the calling thread's current handle, if all of that handle's streams are idle
+void device_free_flush() noexcept;                             // released blocks whose release events have completed
 void device_free_flush_owner_gone(const void *owner) noexcept; // blocks of a handle that has just been destroyed
 bool device_lost();                                            // a bounded wait gave up earlier: nothing is reused or freed, entry points fail fast
 void *device_alloc(size_t bytes); // hipMalloc with the retry above; throws Failure(SCANRS_ERR_DEVICE)
@@ -102,6 +103,7 @@ void device_reserve(size_t bytes);
 void device_cache_set_fraction(double f);
 size_t device_cache_bytes();
 size_t device_live_bytes();
+size_t device_reserve_unused_bytes();
 void library_warm_up(); // kernels.hip: loads every code object of the library (one empty launch per translation unit)
 uint64_t device_alloc_us();
 uint64_t device_alloc_calls();
@@ -156,7 +158,9 @@ struct Scratch {
         auto &b = bufs[key];
         size_t bytes = count * sizeof(T);
         if (bytes > b.n) {
-            b.alloc(bytes + bytes / 8 + 256);
+            // (an eighth more, so that a slightly larger request does not reallocate - up to 256 MB: the two 30 GB projection panels of a
+            // PCA of a 3.75 M-cell shard carried 7.5 GB of it)
+            b.alloc(bytes + std::min<size_t>(bytes / 8, (size_t)32 << 20) + 256);
             SCANRS_HIP(hipMemsetAsync(b.p, 0, b.n, stream)); // padding columns of panels start out as zeros
         }
         return reinterpret_cast<T *>(b.p);

@@ -1586,11 +1586,20 @@ bool tile_layout_build_auto(Storage &st, SparseCopy &cp, hipStream_t s) {
     // hands them back to the driver before it gives up): without the last term a shard whose first PCA ran with one orientation on
     // the gather kernels for lack of room never got that layout later either (2.6 10^9 nonzeros, k = 100: 2.26 instead of 1.86 s per step).
     // The unused part of a reserve made ahead of time is NOT counted: the solver's panels will want it.
-    const double have = (double)free_b + (double)device_cache_bytes() + (cp.tiles ? cp.tiles->bytes() : 0.0);
+    // Round 5: a reserve counts too, minus what a solver that has not started yet will want from it - 26 bytes per nonzero cover the
+    // panels of a top-100 PCA on the 30 M-cell shard (23 B per nonzero there). Without it the shard's second layout was refused during
+    // its first call (the reserve held the memory the driver no longer reported free) and built in the second call, outside the reserve.
+    // (the helper thread, which may run ahead of the solver, and a build outside a solver; the main thread inside a solver has its panels already)
+    const bool panels_taken = st.tile_hint > 0 && s == st.stream;
+    const double from_reserve = std::max(0.0, (double)device_reserve_unused_bytes() - (panels_taken ? 0.0 : 26.0 * (double)cp.nnz));
+    const double have = (double)free_b + (double)device_cache_bytes() + (cp.tiles ? cp.tiles->bytes() : 0.0) + from_reserve;
     if (!(have > need + 8.0 * (double)(1ull << 30))) {
         if (trace_on())
-            fprintf(stderr, "[scanrs trace] tile layout: %llu outer x %llu inner not built: needs %.1f GB + 8.6 of headroom, the driver reports %.1f GB free\n",
-                    (unsigned long long)cp.n_outer, (unsigned long long)cp.n_inner, need / 1e9, have / 1e9);
+            fprintf(stderr,
+                    "[scanrs trace] tile layout: %llu outer x %llu inner not built: needs %.1f GB + 8.6 of headroom, has %.1f GB (driver %.1f, cached blocks %.1f, "
+                    "reserve %.1f of %.1f unused%s)\n",
+                    (unsigned long long)cp.n_outer, (unsigned long long)cp.n_inner, need / 1e9, have / 1e9, (double)free_b / 1e9, (double)device_cache_bytes() / 1e9,
+                    from_reserve / 1e9, (double)device_reserve_unused_bytes() / 1e9, panels_taken ? ", the solver's panels exist" : ", less 26 B per nonzero for a solver's panels");
         return false;
     }
     // Build now: the layout is only worth having when not too many nonzeros miss it (the overflow gather runs at two waves
