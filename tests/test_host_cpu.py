@@ -440,3 +440,29 @@ def test_replicated_sharded_split_of_a_step():
     assert abs(sum(shares) - 190.0) < 1e-9 and max(shares) / min(shares) == pytest.approx(131 / 125)
     assert all(name.startswith(bench.SHARDED_KERNEL_PREFIXES) for name in ("spmm_tile_kernel/long-outer", "tile_weights", "row_reduce_u32", "col_moments"))
     assert not any(name.startswith(bench.SHARDED_KERNEL_PREFIXES) for name in ("chol_rinv", "gemm_nn_mfma_f64"))
+
+
+def test_dense_tile_kernel_leaves_registers_for_a_gather_wave(tmp_path):
+    """The dense tile kernel (scan-rs_amd/csrc/tiles_dense.inc + the generated tile_dense_body.inc) pins its registers by hand; the
+    compiler adds its own around the asm statement and ignores `amdgpu_num_vgpr`. Two tile waves per SIMD leave room for one wave of
+    the overflow gather (72 VGPRs) only while the kernel stays at 216 of the 512 registers: at 220 the gather no longer co-resides
+    and a pass regresses by a millisecond (profiles/HISTORY.md, round 5). Read from the code object's metadata."""
+    import re
+    import shutil
+    import subprocess
+
+    objdump, readelf = "/opt/rocm/lib/llvm/bin/llvm-objdump", "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    lib = os.path.join(ROOT, "scan-rs_amd", "lib", "libscanrs_amd.so")
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("no llvm binutils in this image")
+    copy = tmp_path / "lib.so"
+    shutil.copy(lib, copy)
+    subprocess.run([objdump, "--offloading", str(copy)], check=True, capture_output=True, cwd=tmp_path)
+    found = {}
+    for co in sorted(tmp_path.glob("lib.so.*gfx950*")):
+        notes = subprocess.run([readelf, "--notes", str(co)], capture_output=True, text=True).stdout
+        for m in re.finditer(r"\.name:\s+(\S*spmm_tile_dense_kernel\S*)(.*?)\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", notes, re.S):
+            found[m.group(1)] = (int(m.group(3)), int(m.group(4)))
+    assert found, "spmm_tile_dense_kernel not found in the library's gfx950 code objects"
+    for name, (vgprs, spills) in found.items():
+        assert vgprs <= 216 and spills == 0, (name, vgprs, spills)

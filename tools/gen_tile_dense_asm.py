@@ -29,6 +29,7 @@ PRIO = int(os.environ.get("GEN_PRIO") or 0)  # experiments (no gain, profiles/HI
 STAMP = bool(os.environ.get("GEN_STAMP"))  # diagnostic build: s_memtime stamps around the round's body, the staging wait and the barrier, summed per wave
 SKIP = set((os.environ.get("GEN_SKIP") or "").split(","))  # timing experiments (wrong results): w = weights, r = records, b = barrier, d = staging
 
+DMA_TOP = (os.environ.get("GEN_DMA") or "tail") == "top"  # staging loads at the round's start instead of in its last batches
 BP = int(os.environ.get("GEN_BP") or 4)   # positions per batch (two batches of row reads in flight); 8 is as fast but takes 40 registers more
 NB = 64 // BP     # batches per round
 BPC = 16 // BP    # batches per chunk
@@ -218,6 +219,9 @@ def gen():
             a("s_add_u32 m0, s30, 0x400")            # behind the ring and the row of zeros
             a("s_nop 0")
             a("global_load_lds_dword v48, s[32:33] offset:256")
+        if DMA_TOP:
+            for i in range(5):
+                dma(i, o)
         a("s_load_dword s12, s[22:23], 0xc")         # header three rounds ahead
         a("s_cmp_eq_u32 s29, 4")
         a("s_cbranch_scc1 LPRO0" + V + "%=")
@@ -230,8 +234,9 @@ def gen():
         # an empty round (a visit nobody has work in yet: the first two of a part)
         for c in range(4):
             reload_slot(c, o)
-        for i in range(5):
-            dma(i, o)
+        if not DMA_TOP:
+            for i in range(5):
+                dma(i, o)
         a("s_branch LBND" + V + "%=")
         # prologues: the slots this round does not enter, then the rows of its first two batches
         for c in (3, 2, 1, 0):
@@ -258,11 +263,12 @@ def gen():
                 batch_F(b, o)
             if b % BPC == BPC - 1 and b // BPC < 3:
                 reload_slot(b // BPC, o)
-            if b >= NB - 4:
+            if b >= NB - 4 and not DMA_TOP:
                 dma(b - (NB - 4), o)
             if b + 2 < NB:
                 batch_AL(b + 2, o)
-        dma(4, o)
+        if not DMA_TOP:
+            dma(4, o)
         # ---- boundary ----
         a("LBND" + V + "%=:")
         if STAMP:
