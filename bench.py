@@ -80,9 +80,10 @@ def parse():
     ap.add_argument("--cpu-cells-all", type=int, default=100000, help="cells of the all-core CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reserve", action="store_true", help="do not reserve device memory ahead of the handle (scanrs_reserve_device_memory)")
-    ap.add_argument("--reserve-bytes-per-nnz", type=float, default=84.0,
-                    help="size of that reserve per nonzero of the shard (+ 1 GB): what the handle keeps after its first PCA - both copies of the matrix 16, "
-                         "both tile layouts 2 x 13.2, the solver's panels 23-26, small change - with the build's temporaries in the room the panels take later")
+    ap.add_argument("--reserve-bytes-per-nnz", type=float, default=None,
+                    help="size of that reserve per nonzero of the shard (+ 1 GB). Default: computed from what the handle keeps after its first PCA - per nonzero "
+                         "both copies of the matrix 16 B, both tile layouts 2 x 13.2 B, 4 B of small change; per cell the solver's two projection panels "
+                         "(2 x 8 B x 2 k n_iter) and six b-wide panels - with the builds' temporaries in the room the panels take later")
     ap.add_argument("--no-heavy-tailed", action="store_true", help="skip the second, clearly labelled measurement on the heavy-tailed gene profile")
     ap.add_argument("--no-host-delivery", action="store_true", help="leave U and V in HBM in every step (value is then the device-resident rate)")
     ap.add_argument("--f32-panels", action="store_true",
@@ -306,8 +307,14 @@ def main():
     # On a box whose memory another process has just freed, the driver is still scrubbing it and an allocation waits for that
     # (profiles/microbench/alloc_probe2: 0.24 s per 8 GB) — environment, not the path measured here; config.reserve_s reports it.
     t_r = time.perf_counter()
+    reserve_bytes = 0
     if not args.no_reserve:
-        sa.reserve_device_memory(int(args.reserve_bytes_per_nnz * nnz_local) + (1 << 30))
+        if args.reserve_bytes_per_nnz is not None:
+            reserve_bytes = int(args.reserve_bytes_per_nnz * nnz_local)
+        else:
+            b_cols = 2 * args.k  # BkSvd: k_multiplier 2, n_iter 5
+            reserve_bytes = int(46.5 * nnz_local) + n_local * (2 * 8 * b_cols * 5 + 6 * 8 * b_cols)
+        sa.reserve_device_memory(reserve_bytes + (1 << 30))
     t_reserve = time.perf_counter() - t_r
     # genes x cells (Cell Ranger orientation), stored cell-major = CSC
     dbg(f"shard [{lo}, {hi}) nnz {nnz_local}: create handle")
@@ -828,6 +835,7 @@ def main():
                 "heavy_tailed_profile": heavy,
                 "library_init_s": round(t_init, 3),
                 "reserve_s": round(t_reserve, 3),
+                "reserve_bytes_per_nonzero": round((reserve_bytes + (1 << 30)) / max(1, nnz_local), 1) if reserve_bytes else 0.0,
                 "resident_bytes_per_nonzero": round(mem_after_first / max(1, nnz_local), 1) if mem_after_first else None,
                 "datagen_s": round(t_gen, 2),
                 "sigma_top3": [round(float(x), 6) for x in (sig[:3] if sig is not None else [])],
