@@ -7,20 +7,25 @@ physical one (the accumulators are picked through VGPR index mode, which shifts 
 compiler-scheduled instruction may sit between s_set_gpr_idx_on and _off), and LDS reads, scalar loads and LDS-DMA all have to
 be counted by hand. A generator keeps the numbering honest; the output is committed next to it.
 
-Register map (all clobbered by the asm statement; the compiler keeps v0-v25 and s0-s11):
+Register map (all clobbered by the asm statement; the compiler keeps v0-v25 and s0-s11; operands arrive in vector registers and are
+read with v_readfirstlane_b32):
   v[88:215]   accumulators: slot q = v[88 + 4 q : 88 + 4 q + 3] (two f64: columns 2 lane, 2 lane + 1)
   v[56:87]    panel rows of 8 positions in flight (4 registers each)
-  v[48:55]    their LDS addresses
-  (216 registers in all: two tile waves per SIMD leave 80 for a wave of the overflow gather, which runs beside this kernel)
+  v[48:55]    their LDS addresses (v48 also: the offset of the records' "touch" load at the round's start)
   v[40:47]    weights of the round's 4 chunks: lane L holds weight L % 16 of the chunk (one register pair per chunk)
   v[38:39]    this lane's address in the weight stream: 8 L behind the END of the NEXT round's weights
-  v[26:27] the NEXT round's 64 weights as loaded (lane L: weight L), v[28:29] this round's, v30 4 x (lane % 16)
   v36 ring base of the lane (LDS address of its column pair in ring row 0), v37 row pitch in bytes
   v[31:35]    LDS-DMA source offsets of the wave's 5 staging chunks
+  v30         4 x (lane % 16): the ds_bpermute address of this lane's weight inside a chunk
+  v[28:29]    this round's 64 weights as loaded (lane L: weight L), v[26:27] the NEXT round's
+  (216 registers in all: two tile waves per SIMD leave 80 for a wave of the overflow gather, which runs beside this kernel)
   s[36:99]    the round's records: bits 7:0 = 4 x slot (the VGPR index), 15:8 = raw count (weight refresh only), 31:16 = ring row
-  s[20:21] END of the current round's records, s[22:23] round table, s[24:25] next tile to stage, s26 rounds left, s27 tile bytes,
-  s28 header of the current round (7:0 chunks, bit 8 = first round of a visit), s29 its chunk count, s30 / s31 / s[32:33] scratch,
-  s34 next header (s101: the one after), s100 chunks of the next round, s35 LDS address of the buffer of the tile staged last, s17 wave << 10, s18 ring base, s19 ring end
+  s[13:16]    copies of the last batch's four records (their chunk slot is reloaded before its FMAs)
+  s17 wave << 10, s18 ring base, s19 ring end, s[20:21] END of the current round's records, s[22:23] round table,
+  s[24:25] next tile to stage, s26 rounds left, s27 tile bytes, s31 tile bytes - 1024, s35 LDS address of the buffer staged into,
+  s28 header of the current round (7:0 chunks, bit 8 = first round of a visit), s29 its chunk count, s34 / s101 / s12 the next
+  three headers, s100 chunks of the next round, s30 / s[32:33] scratch (s[32:33]: where the next round's chunk slots come from)
+  (stamp build: s[2:9] time stamps and sums, s[10:11] saved EXEC)
 """
 import os
 import sys
