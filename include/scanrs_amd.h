@@ -368,6 +368,11 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *                       beyond the vectors too sparse to own a slot; 0 = the round-4 form, tile_k fixed positions per (slot, visit)
  *   "tile_sort_slots" (1)  dense tile layout: the slots take their places (workgroup item, wave, accumulator) in the order of their load,
  *                       heaviest first, so that the 8 waves of an item carry about the same number of records per visit (0: vector order)
+ *   "tile_one_walk" (1)  dense tile layout: 1 = built in ONE walk over the matrix (the (group, part) blocks of the tile-sorted record
+ *                       list start at the prefix sums of their capacities, found by binary searches; counts above 255 leave through
+ *                       a bounded list); 0 = a counting walk and a filling walk. The same layout bit for bit.
+ *   "tile_emit_staged" (1)  dense tile layout, diagnostic: 0 makes the emission of the record streams search its per-visit tables in global
+ *                       memory instead of LDS - the form taken by itself when a part has more than 4 000 tiles. Same layout.
  *   "tile_builder" (1)  1: wave-level builder of the tile layout (default tile shape); 0: per-thread walk (reference form)
  *   "tile_build_waves" (0)   cap on the waves per CU of that builder (0: as many as fit)
  *   "sync_timeout_s" (120)  PROCESS-WIDE (same as scanrs_set_global_option): deadline of every host-side wait for the device

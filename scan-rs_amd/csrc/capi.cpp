@@ -2098,6 +2098,10 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.tile_dense = value != 0.0;
         } else if (k == "tile_sort_slots") {
             st.tile_sort_slots = value != 0.0;
+        } else if (k == "tile_one_walk") {
+            st.tile_one_walk = value != 0.0;
+        } else if (k == "tile_emit_staged") {
+            st.tile_emit_staged = value != 0.0;
         } else if (k == "tile_builder") {
             st.tile_builder = value != 0.0;
         } else if (k == "tile_build_waves") {

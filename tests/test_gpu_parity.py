@@ -699,7 +699,8 @@ def test_dense_record_layout_equals_round4_layout_and_is_placement_independent(s
     of the additions inside a slot is the same — a vector's nonzeros in index order — but the split between tile kernel and overflow
     gather differs); with the slots placed in the order of their load and in vector order: BIT FOR BIT (placement moves a slot to
     another wave, never its records). Shapes around the group / item / tile edges, several parts, empty vectors, vectors with several
-    slots, vectors without a slot, counts above 255 (overflow part), rounds of more than 4 chunks (dense spots)."""
+    slots, vectors without a slot, counts above 255 (overflow part), rounds of more than 4 chunks (dense spots). And the dense layout
+    built in ONE walk ("tile_one_walk", the default) against the two-walk build: bit for bit."""
     rng = np.random.default_rng(95)
     for rows, cols, fill, vmax in ((1, 1, 1.0, 3), (31, 95, 0.5, 3), (33, 97, 0.9, 2), (64, 48, 1.0, 2), (65, 4800, 0.6, 4), (257, 2000, 0.05, 400),
                                    (700, 1000, 0.03, 3), (97, 20000, 0.02, 3), (2000, 193, 0.2, 300), (300, 400, 0.004, 2), (130, 9000, 0.3, 3), (520, 3000, 0.9, 5)):
@@ -710,9 +711,10 @@ def test_dense_record_layout_equals_round4_layout_and_is_placement_independent(s
         dense[0, 0] = 1
         for storage in (so.CSR, so.CSC):
             outs = []
-            for dense_layout, sort_slots in ((0, 0), (1, 0), (1, 1)):
+            for dense_layout, sort_slots, one_walk in ((0, 0, 1), (1, 0, 1), (1, 1, 1), (1, 1, 0)):
                 g, _ = pair(sa, dense, storage)
                 g.set_spmm_path(3).set_option("tile_dense", dense_layout).set_option("tile_sort_slots", sort_slots).set_option("tile_split_min", 0.3)
+                g.set_option("tile_one_walk", one_walk).set_option("tile_emit_staged", one_walk)  # (the two-walk build also takes the unstaged emission)
                 g.compose_scale_axis(1, np.linspace(0.5, 1.5, cols)).apply(sa.FN_LOG2_1P).compose_scale_axis(0, np.linspace(0.7, 1.3, rows))
                 q = np.cos(np.arange(cols * 40, dtype=np.float64)).reshape(cols, 40)
                 ql = np.sin(np.arange(rows * 24, dtype=np.float64)).reshape(24, rows)
@@ -721,6 +723,8 @@ def test_dense_record_layout_equals_round4_layout_and_is_placement_independent(s
             assert_close(outs[1][0], outs[0][0], rtol=1e-12, atol=1e-11)
             assert_close(outs[1][1], outs[0][1], rtol=1e-12, atol=1e-11)
             assert np.array_equal(outs[1][0], outs[2][0]) and np.array_equal(outs[1][1], outs[2][1]), (rows, cols, fill, storage)
+            # built in one walk over the matrix or in a counting and a filling walk: the same layout, so the same bits
+            assert np.array_equal(outs[2][0], outs[3][0]) and np.array_equal(outs[2][1], outs[3][1]), (rows, cols, fill, storage)
 
 
 def test_invalid_sparse_input_is_refused(sa):
