@@ -34,6 +34,7 @@ PRIO = int(os.environ.get("GEN_PRIO") or 0)  # experiments (no gain, profiles/HI
 STAMP = bool(os.environ.get("GEN_STAMP"))  # diagnostic build: s_memtime stamps around the round's body, the staging wait and the barrier, summed per wave
 SKIP = set((os.environ.get("GEN_SKIP") or "").split(","))  # timing experiments (wrong results): w = weights, r = records, b = barrier, d = staging
 
+PRE = (os.environ.get("GEN_PRE") or "0") != "0"  # experiment (slower by 0.3 ms per pass, profiles/HISTORY.md): the row reads of a round's first two batches are issued at the boundary in front of it (0: in the round's prologue)
 DMA_TOP = (os.environ.get("GEN_DMA") or "tail") == "top"  # staging loads at the round's start instead of in its last batches
 BP = int(os.environ.get("GEN_BP") or 4)   # positions per batch (two batches of row reads in flight); 8 is as fast but takes 40 registers more
 NB = 64 // BP     # batches per round
@@ -178,30 +179,28 @@ def gen():
     a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
     a("global_load_dwordx2 v[26:27], v[38:39], off offset:-512")  # weights of round 0
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")           # ... and the item's first tile (staged by the caller)
-    if "b" not in SKIP:
-        a("s_barrier")                            # round 0 is the first of its visit
-    a("s_add_u32 s24, s24, s27")
-    a("s_addc_u32 s25, s25, 0")
-    a("s_add_u32 s35, s35, s27")
-    a("s_cmp_eq_u32 s35, s19")
-    a("s_cselect_b32 s35, s18, s35")
+    if not PRE:
+        if "b" not in SKIP:
+            a("s_barrier")                            # round 0 is the first of its visit
+        a("s_add_u32 s24, s24, s27")
+        a("s_addc_u32 s25, s25, 0")
+        a("s_add_u32 s35, s35, s27")
+        a("s_cmp_eq_u32 s35, s19")
+        a("s_cselect_b32 s35, s18, s35")
+    else:
+        a("s_branch LENTER%=")                        # round 0 is the first of its visit: barrier, then its first row reads
 
-    # ---- one round, in two copies: waves 0-3 run copy A, waves 4-7 (their partners on the four SIMDs) copy B. The copies differ in ONE
-    # thing: the priority a wave asks for alternates from batch to batch, opposite in the two copies. With equal priorities the older
-    # wave of a SIMD wins every issue conflict, finishes its round 570 clk early and waits at the barrier while its partner works on
-    # alone at the rate of a single wave (stamps: barrier wait 706 / 140 clk per round, the other way round with s_setprio 1 on waves 4-7).
-    if PRIO == 2:
-        a("s_bitcmp1_b32 s17, 12")  # wave >= 4
-        a("s_cbranch_scc1 LROUNDB%=")
-    for V in (("A", "B") if PRIO == 2 else ("A",)):
-        a("LROUND" + V + "%=:")
-        if STAMP:
-            a("s_memtime s[2:3]")
-        a("v_mov_b32 v28, v26")
-        a("v_mov_b32 v29, v27")
-        for c in range(4):
-            a(f"ds_bpermute_b32 v{W0 + 2 * c}, v30, v28 offset:{64 * c}")
-            a(f"ds_bpermute_b32 v{W0 + 2 * c + 1}, v30, v29 offset:{64 * c}")
+    def advance():
+        if "b" not in SKIP:
+            a("s_barrier")
+        a("s_add_u32 s24, s24, s27")
+        a("s_addc_u32 s25, s25, 0")
+        a("s_add_u32 s35, s35, s27")
+        a("s_cmp_eq_u32 s35, s19")
+        a("s_cselect_b32 s35, s18, s35")
+
+    def top():
+        """what a round starts for the rounds behind it: the next round's weights, the touch of the records two rounds ahead, the header three ahead"""
         a("s_and_b32 s100, s34, 0xff")               # chunks of the next round
         a("s_lshl_b32 s30, s100, 7")
         a("v_add_co_u32 v38, vcc, s30, v38")         # behind the next round's weights
@@ -216,8 +215,9 @@ def gen():
             # touch: the records of the round after the next one into L2 (their scalar loads, issued during the next round, then hit there:
             # without it a boundary waits for slot 3's load to come from HBM, +350 clk per round). An LDS-DMA load into 256 scratch bytes of
             # this wave behind the ring: it needs no register to land in, and it is this round's OLDEST vector-memory operation
+            # (v48: an address register; an instruction reads its address operand at issue, so the row reads that named it are past it)
             a("s_min_u32 s30, s17, s31")
-            a("v_sub_u32 v48, v31, s30")             # 16 x lane (v48: an address register, free until the prologue)
+            a("v_sub_u32 v48, v31, s30")             # 16 x lane
             a("v_lshrrev_b32 v48, 2, v48")           # 4 x lane: 256 bytes = four chunk slots
             a("s_lshr_b32 s30, s17, 2")
             a("s_add_u32 s30, s30, s19")
@@ -225,43 +225,26 @@ def gen():
             a("s_nop 0")
             a("global_load_lds_dword v48, s[32:33] offset:256")
         if DMA_TOP:
-            for i in range(5):
-                dma(i, o)
+            for i_ in range(5):
+                dma(i_, o)
         a("s_load_dword s12, s[22:23], 0xc")         # header three rounds ahead
-        a("s_cmp_eq_u32 s29, 4")
-        a("s_cbranch_scc1 LPRO0" + V + "%=")
-        a("s_cmp_eq_u32 s29, 3")
-        a("s_cbranch_scc1 LPRO1" + V + "%=")
-        a("s_cmp_eq_u32 s29, 2")
-        a("s_cbranch_scc1 LPRO2" + V + "%=")
-        a("s_cmp_eq_u32 s29, 1")
-        a("s_cbranch_scc1 LPRO3" + V + "%=")
-        # an empty round (a visit nobody has work in yet: the first two of a part)
+
+    def spread_weights():
+        a("v_mov_b32 v28, v26")
+        a("v_mov_b32 v29, v27")
         for c in range(4):
-            reload_slot(c, o)
-        if not DMA_TOP:
-            for i in range(5):
-                dma(i, o)
-        a("s_branch LBND" + V + "%=")
-        # prologues: the slots this round does not enter, then the rows of its first two batches
-        for c in (3, 2, 1, 0):
-            a(f"LPRO{c}" + V + "%=:")
-            for cc in range(c):
-                reload_slot(cc, o)
-            batch_AL(BPC * c, o)
-            batch_AL(BPC * c + 1, o)
-            if c != 0:
-                a(f"s_branch LS{BPC * c}" + V + "%=")
+            a(f"ds_bpermute_b32 v{W0 + 2 * c}, v30, v28 offset:{64 * c}")
+            a(f"ds_bpermute_b32 v{W0 + 2 * c + 1}, v30, v29 offset:{64 * c}")
+
+    def batches():
         for b in range(NB):
-            a(f"LS{b}" + V + "%=:")
+            a(f"LS{b}%=:")
             last = b == NB - 1
-            if PRIO == 2:
-                a(f"s_setprio {(b + (1 if V == 'B' else 0)) & 1}")
             a(f"s_waitcnt lgkmcnt({BP})" if not last else "s_waitcnt lgkmcnt(0)")
             if last:
                 # the last batch names its accumulators through copies, so that slot 3 can be reloaded before its FMAs instead of behind them
-                for j in range(BP):
-                    a(f"s_mov_b32 s{13 + j}, {rec(b * BP + j)}")
+                for j_ in range(BP):
+                    a(f"s_mov_b32 s{13 + j_}, {rec(b * BP + j_)}")
                 reload_slot(3, o)
                 batch_F(b, o, tail=True)
             else:
@@ -274,8 +257,64 @@ def gen():
                 batch_AL(b + 2, o)
         if not DMA_TOP:
             dma(4, o)
+
+    def rotate():
+        a("s_waitcnt lgkmcnt(0)")                    # the next round's records and the header
+        a("s_mov_b32 s28, s34")
+        a("s_mov_b32 s34, s101")
+        a("s_mov_b32 s101, s12")
+        a("s_add_u32 s22, s22, 4")
+        a("s_addc_u32 s23, s23, 0")
+        a("s_mov_b32 s29, s100")
+        a("s_lshl_b32 s30, s29, 6")
+        a("s_add_u32 s20, s20, s30")
+        a("s_addc_u32 s21, s21, 0")
+
+    def stamp_barrier_begin():
+        if STAMP:
+            a("s_memtime s[2:3]")
+
+    def stamp_barrier_end():
+        if STAMP:
+            a("s_memtime s[4:5]")
+            a("s_waitcnt lgkmcnt(0)")
+            a("s_sub_u32 s10, s4, s2")
+            a("s_add_u32 s8, s8, s10")   # barrier (with GEN_PRE the stamp's lgkmcnt(0) also waits for row reads in flight: an upper bound)
+
+    if not PRE:
+        # ---- one round (round-5 first form: everything a round needs is started at its top) ----
+        a("LROUND%=:")
+        if STAMP:
+            a("s_memtime s[2:3]")
+        spread_weights()
+        top()
+        a("s_cmp_eq_u32 s29, 4")
+        a("s_cbranch_scc1 LPRO0%=")
+        a("s_cmp_eq_u32 s29, 3")
+        a("s_cbranch_scc1 LPRO1%=")
+        a("s_cmp_eq_u32 s29, 2")
+        a("s_cbranch_scc1 LPRO2%=")
+        a("s_cmp_eq_u32 s29, 1")
+        a("s_cbranch_scc1 LPRO3%=")
+        # an empty round (a visit nobody has work in yet: the first two of a part)
+        for c in range(4):
+            reload_slot(c, o)
+        if not DMA_TOP:
+            for i_ in range(5):
+                dma(i_, o)
+        a("s_branch LBND%=")
+        # prologues: the slots this round does not enter, then the rows of its first two batches
+        for c in (3, 2, 1, 0):
+            a(f"LPRO{c}%=:")
+            for cc in range(c):
+                reload_slot(cc, o)
+            batch_AL(BPC * c, o)
+            batch_AL(BPC * c + 1, o)
+            if c != 0:
+                a(f"s_branch LS{BPC * c}%=")
+        batches()
         # ---- boundary ----
-        a("LBND" + V + "%=:")
+        a("LBND%=:")
         if STAMP:
             a("s_memtime s[4:5]")
             a("s_waitcnt lgkmcnt(0)")
@@ -292,31 +331,80 @@ def gen():
             a("s_sub_u32 s10, s2, s4")
             a("s_add_u32 s7, s7, s10")   # wait for vector memory (+ the scalar loads the stamp forces)
         a("s_bitcmp1_b32 s34, 8")
-        a("s_cbranch_scc0 LNB" + V + "%=")
-        if "b" not in SKIP:
-            a("s_barrier")
+        a("s_cbranch_scc0 LNB%=")
+        advance()                                     # next round = first of a visit: the tile it reads first has landed for everybody, nobody reads the oldest one any more
+        stamp_barrier_end()
+        a("LNB%=:")
+        rotate()
+        a("s_branch LROUND%=")
+    else:
+        # ---- one round, second form: what the round needs FIRST is started at the boundary in front of it. Entering a round (LENTER:
+        # its header in s28, its chunk count in s29, its records certified): weights into their rows; the loads for the rounds behind
+        # it; the record slots it will not enter, reloaded; the row reads of its first two batches — in FRONT of the barrier when the
+        # header says so (bit 9, set by the builder: none of those 8 positions names the tile that becomes readable behind this barrier
+        # in any of the item's 8 waves), else behind it. The latency of those reads and the scalar work then run beside the barrier wait.
+        a("LBATCH%=:")
+        batches()
+        a("LBND%=:")
         if STAMP:
             a("s_memtime s[4:5]")
             a("s_waitcnt lgkmcnt(0)")
             a("s_sub_u32 s10, s4, s2")
-            a("s_add_u32 s8, s8, s10")   # barrier                            # next round = first of a visit: the tile it reads first has landed for everybody, nobody reads the oldest one any more
-        a("s_add_u32 s24, s24, s27")
-        a("s_addc_u32 s25, s25, 0")
-        a("s_add_u32 s35, s35, s27")
-        a("s_cmp_eq_u32 s35, s19")
-        a("s_cselect_b32 s35, s18, s35")
-        a("LNB" + V + "%=:")
-        a("s_waitcnt lgkmcnt(0)")                    # the next round's records and the header
-        a("s_mov_b32 s28, s34")
-        a("s_mov_b32 s34, s101")
-        a("s_mov_b32 s101, s12")
-        a("s_add_u32 s22, s22, 4")
-        a("s_addc_u32 s23, s23, 0")
-        a("s_mov_b32 s29, s100")
-        a("s_lshl_b32 s30, s29, 6")
-        a("s_add_u32 s20, s20, s30")
-        a("s_addc_u32 s21, s21, 0")
-        a("s_branch LROUND" + V + "%=")
+            a("s_add_u32 s6, s6, s10")   # body (from the end of the barrier)
+            a("s_add_u32 s9, s9, 1")     # rounds
+        a("s_sub_u32 s26, s26, 1")
+        a("s_cmp_eq_u32 s26, 0")
+        a("s_cbranch_scc1 LDONE%=")
+        a("s_waitcnt vmcnt(5)")                      # the next round's weights; every staging load but this round's five
+        if STAMP:
+            a("s_memtime s[2:3]")
+            a("s_waitcnt lgkmcnt(0)")
+            a("s_sub_u32 s10, s2, s4")
+            a("s_add_u32 s7, s7, s10")   # wait for vector memory
+        rotate()
+        a("LENTER%=:")
+        spread_weights()
+        top()
+        a("s_cmp_eq_u32 s29, 0")
+        a("s_cbranch_scc1 LEMPTY%=")
+        a("s_bitcmp1_b32 s28, 8")                    # first round of a visit?
+        a("s_cbranch_scc0 LPF%=")                    # no: no barrier
+        a("s_bitcmp1_b32 s28, 9")                    # its first reads may go ahead of the barrier?
+        a("s_cbranch_scc1 LPF%=")
+        stamp_barrier_begin()
+        advance()
+        stamp_barrier_end()
+        a("s_andn2_b32 s28, s28, 0x100")             # (the barrier is behind us)
+        a("LPF%=:")
+        for n, lab in ((4, 0), (3, 1), (2, 2)):
+            a(f"s_cmp_eq_u32 s29, {n}")
+            a(f"s_cbranch_scc1 LPF{lab}%=")
+        for c in (3, 2, 1, 0):
+            a(f"LPF{c}%=:")
+            for cc in range(c):
+                reload_slot(cc, o)
+            batch_AL(BPC * c, o)
+            batch_AL(BPC * c + 1, o)
+            a("s_bitcmp1_b32 s28, 8")                # still a barrier to pass (reads went ahead of it)?
+            a(f"s_cbranch_scc0 LS{BPC * c}%=")
+            stamp_barrier_begin()
+            advance()
+            stamp_barrier_end()
+            a(f"s_branch LS{BPC * c}%=")
+        # an empty round (a visit nobody has work in yet: the first two of a part)
+        a("LEMPTY%=:")
+        a("s_bitcmp1_b32 s28, 8")
+        a("s_cbranch_scc0 LEMPTY2%=")
+        stamp_barrier_begin()
+        advance()
+        stamp_barrier_end()
+        a("LEMPTY2%=:")
+        for c in range(4):
+            reload_slot(c, o)
+        if not DMA_TOP:
+            for i_ in range(5):
+                dma(i_, o)
+        a("s_branch LBND%=")
     a("LDONE%=:")
     if PRIO:
         a("s_setprio 0")
