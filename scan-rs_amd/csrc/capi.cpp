@@ -112,6 +112,52 @@ void *landing_slot(size_t bytes) {
     if (at + need > RING) at = 0;
     return ring + at;
 }
+namespace {
+struct LandingArea {
+    std::mutex mu; // one user at a time (these copies are small and rare: histograms, factor verdicts, axis sums, small panels)
+    char *p = nullptr;
+    static constexpr size_t BYTES = 8u << 20;
+};
+LandingArea &landing_area() {
+    static LandingArea *a = [] {
+        auto *x = new LandingArea(); // never destroyed
+        void *q = nullptr;
+        if (hipHostMalloc(&q, LandingArea::BYTES, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            q = malloc(LandingArea::BYTES);
+        }
+        x->p = static_cast<char *>(q);
+        return x;
+    }();
+    return *a;
+}
+} // namespace
+void d2h_landed_2d(void *dst, const void *dsrc, size_t src_pitch, size_t row_bytes, size_t rows, hipStream_t s, const char *func, const char *file, int line) {
+    if (!rows || !row_bytes) return;
+    LandingArea &a = landing_area();
+    if (!a.p) fail(SCANRS_ERR_DEVICE, "no host staging area for device-to-host copies");
+    if (row_bytes > LandingArea::BYTES) fail(SCANRS_ERR_ARGUMENT, "a row of %zu bytes does not fit the host staging area", row_bytes);
+    std::lock_guard<std::mutex> lk(a.mu);
+    const size_t rows_per = std::max<size_t>(1, LandingArea::BYTES / row_bytes);
+    for (size_t r0 = 0; r0 < rows; r0 += rows_per) {
+        const size_t nr = std::min(rows_per, rows - r0);
+        const char *src = static_cast<const char *>(dsrc) + r0 * src_pitch;
+        if (src_pitch == row_bytes)
+            SCANRS_HIP(hipMemcpyAsync(a.p, src, nr * row_bytes, hipMemcpyDeviceToHost, s));
+        else
+            SCANRS_HIP(hipMemcpy2DAsync(a.p, row_bytes, src, src_pitch, row_bytes, nr, hipMemcpyDeviceToHost, s));
+        wait_stream(s, func, file, line);
+        memcpy(static_cast<char *>(dst) + r0 * row_bytes, a.p, nr * row_bytes);
+    }
+}
+void d2h_landed(void *dst, const void *dsrc, size_t bytes, hipStream_t s, const char *func, const char *file, int line) {
+    if (!bytes) return;
+    const size_t piece = std::min<size_t>(bytes, 1u << 20);
+    const size_t whole = bytes / piece;
+    d2h_landed_2d(dst, dsrc, piece, piece, whole, s, func, file, line);
+    if (bytes > whole * piece)
+        d2h_landed_2d(static_cast<char *>(dst) + whole * piece, static_cast<const char *>(dsrc) + whole * piece, bytes - whole * piece, bytes - whole * piece, 1, s, func, file, line);
+}
 static bool device_recovered();
 CurrentHandle::CurrentHandle(const Storage *st, bool waits_only) : prev(tl_handle) {
     if (!waits_only && device_lost() && !device_recovered())
@@ -1151,8 +1197,7 @@ static uint32_t select_kth(Storage &st, const uint32_t *d, uint64_t n_local, uin
     for (int pass = 0; pass < 3; pass++) {
         launch_hist12(st, d, n_local, shifts[pass], (1u << bits[pass]) - 1u, mask, prefix, hist);
         allreduce_u64(st, hist, 4096);
-        SCANRS_HIP(hipMemcpyAsync(h.data(), hist, 4096 * 8, hipMemcpyDeviceToHost, st.stream));
-        SCANRS_SYNC(st.stream);
+        SCANRS_D2H(h.data(), hist, 4096 * 8, st.stream);
         const uint32_t nb = 1u << bits[pass];
         uint32_t bin = 0;
         for (; bin < nb; bin++) {
@@ -1516,10 +1561,10 @@ static void host_axis_sums(scanrs_mat *m, int axis, int mode, std::vector<double
     double *sumsq = st.scratch.get<double>("mom_sumsq", std::max<uint64_t>(1, n));
     axis_sums(m, axis, mode, sum, sumsq);
     s.resize(n);
-    if (n) SCANRS_HIP(hipMemcpyAsync(s.data(), sum, n * 8, hipMemcpyDeviceToHost, st.stream));
+    SCANRS_D2H(s.data(), sum, n * 8, st.stream);
     if (mode == 2) {
         s2.resize(n);
-        if (n) SCANRS_HIP(hipMemcpyAsync(s2.data(), sumsq, n * 8, hipMemcpyDeviceToHost, st.stream));
+        SCANRS_D2H(s2.data(), sumsq, n * 8, st.stream);
     }
     SCANRS_SYNC(st.stream);
 }
@@ -1591,7 +1636,7 @@ int scanrs_mat_sum_axis_u32(scanrs_mat *m, int axis, uint32_t *out) {
         memset(&raw, 0, sizeof(raw));
         uint32_t *d = st.scratch.get<uint32_t>("sum_u32", std::max<uint64_t>(1, cp.n_outer));
         launch_row_reduce(st, cp, raw, 0, d, nullptr, nullptr);
-        if (cp.n_outer) SCANRS_HIP(hipMemcpyAsync(out, d, cp.n_outer * 4, hipMemcpyDeviceToHost, st.stream));
+        SCANRS_D2H(out, d, cp.n_outer * 4, st.stream);
         SCANRS_SYNC(st.stream);
     });
 }
@@ -1635,8 +1680,7 @@ int scanrs_mat_to_dense(scanrs_mat *m, double *out) {
         SCANRS_HIP(hipMemsetAsync(d, 0, R * C * 8, st.stream));
         SparseCopy &cp = copy_outer_view_rows(m, true);
         launch_densify(st, cp, m->dev_map(true), true, C, d);
-        SCANRS_HIP(hipMemcpyAsync(out, d, R * C * 8, hipMemcpyDeviceToHost, st.stream));
-        SCANRS_SYNC(st.stream);
+        SCANRS_D2H(out, d, R * C * 8, st.stream);
         if (m->off_rank) { // u.dot(&v) + mat  (low_rank_offset.rs:55-57)
             std::vector<double> u((size_t)R * m->off_rank), vt((size_t)C * m->off_rank);
             SCANRS_HIP(hipMemcpy(u.data(), m->off_u->p, u.size() * 8, hipMemcpyDeviceToHost));
@@ -1677,8 +1721,7 @@ static void dot_host(scanrs_mat *m, bool transpose, const double *h_in, uint32_t
     SCANRS_SYNC(st.stream);
     mat_apply(m, transpose, dX, ld, l, dY, ld);
     std::vector<double> res((size_t)n_out * l);
-    if (n_out)
-        SCANRS_HIP(hipMemcpy2DAsync(res.data(), (size_t)l * 8, dY, (size_t)ld * 8, (size_t)l * 8, n_out, hipMemcpyDeviceToHost, st.stream));
+    SCANRS_D2H_2D(res.data(), dY, (size_t)ld * 8, (size_t)l * 8, n_out, st.stream);
     SCANRS_SYNC(st.stream);
     if (in_is_l_by_n) {
         for (uint64_t j = 0; j < n_out; j++)
@@ -1727,8 +1770,7 @@ static void dot_host_u32(scanrs_mat *m, bool transpose, const uint32_t *h_in, ui
     SparseCopy &cp = copy_outer_view_rows(m, !transpose);
     launch_spmm_u32(st, cp, dX, ld, l, dY, ld);
     std::vector<uint32_t> res((size_t)n_out * l);
-    if (n_out)
-        SCANRS_HIP(hipMemcpy2DAsync(res.data(), (size_t)l * 4, dY, (size_t)ld * 4, (size_t)l * 4, n_out, hipMemcpyDeviceToHost, st.stream));
+    SCANRS_D2H_2D(res.data(), dY, (size_t)ld * 4, (size_t)l * 4, n_out, st.stream);
     SCANRS_SYNC(st.stream);
     if (transpose) {
         for (uint64_t j = 0; j < n_out; j++)
@@ -2211,10 +2253,9 @@ int scanrs_mat_chol_rinv(scanrs_mat *m, const double *g, uint32_t n, uint64_t ro
         launch_chol_rinv(st, dG, n, rows, pass, false, dCtl, dR, dInfo);
         int ctl[2];
         double info[2];
-        SCANRS_HIP(hipMemcpyAsync(rinv, dR, (size_t)n * n * 8, hipMemcpyDeviceToHost, st.stream));
-        SCANRS_HIP(hipMemcpyAsync(ctl, dCtl, sizeof ctl, hipMemcpyDeviceToHost, st.stream));
-        SCANRS_HIP(hipMemcpyAsync(info, dInfo, sizeof info, hipMemcpyDeviceToHost, st.stream));
-        SCANRS_SYNC(st.stream);
+        SCANRS_D2H(rinv, dR, (size_t)n * n * 8, st.stream);
+        SCANRS_D2H(ctl, dCtl, sizeof ctl, st.stream);
+        SCANRS_D2H(info, dInfo, sizeof info, st.stream);
         if (done) *done = ctl[0];
         if (status) *status = ctl[1];
         if (err) *err = info[0];

@@ -64,6 +64,14 @@ struct CurrentHandle {
 // timeout unwinds would land in whatever lives there later): the copy goes into a slot of a process-wide pinned ring and is read from
 // there behind the wait; when the wait gives up, the slot is simply not read.
 void *landing_slot(size_t bytes); // capi.cpp: 8-byte aligned, from a pinned ring of 1 MB that is never unmapped
+// Device -> host for arrays: through a pinned staging area that is never unmapped, in pieces of at most 8 MB, each piece waited for
+// (bounded) before it is copied on into `dst`. If a wait gives up, the copy still in flight lands in the staging area — not in a
+// vector or a caller's array whose frame has unwound meanwhile. `src_pitch` / `row_bytes` / `rows`: a 2-D copy into a
+// compact destination.
+void d2h_landed(void *dst, const void *dsrc, size_t bytes, hipStream_t s, const char *func, const char *file, int line);
+void d2h_landed_2d(void *dst, const void *dsrc, size_t src_pitch, size_t row_bytes, size_t rows, hipStream_t s, const char *func, const char *file, int line);
+#define SCANRS_D2H(dst, dsrc, bytes, stream) ::scanrs::d2h_landed((dst), (dsrc), (bytes), (stream), __PRETTY_FUNCTION__, __FILE__, __LINE__)
+#define SCANRS_D2H_2D(dst, dsrc, pitch, row_bytes, rows, stream) ::scanrs::d2h_landed_2d((dst), (dsrc), (pitch), (row_bytes), (rows), (stream), __PRETTY_FUNCTION__, __FILE__, __LINE__)
 template <typename T>
 inline T d2h_value(const T *d, hipStream_t s, const char *func, const char *file, int line) {
     T *slot = static_cast<T *>(landing_slot(sizeof(T)));

@@ -1531,7 +1531,7 @@ static void ensure_order(Storage &st, SparseCopy &cp) {
     SCANRS_HIP(rocprim::radix_sort_pairs_desc(tmp.p, tmp_bytes, keys_a.p, keys_b.p, ids_a.p, cp.order.p, (size_t)cp.n_outer, 0u, 32u,
                                               st.stream));
     cp.sorted_len.resize(cp.n_outer);
-    SCANRS_HIP(hipMemcpyAsync(cp.sorted_len.data(), keys_b.p, cp.n_outer * 4, hipMemcpyDeviceToHost, st.stream));
+    SCANRS_D2H(cp.sorted_len.data(), keys_b.p, cp.n_outer * 4, st.stream);
     SCANRS_SYNC(st.stream);
 }
 

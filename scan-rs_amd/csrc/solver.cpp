@@ -211,10 +211,7 @@ struct Ctx {
         SCANRS_HIP(hipMemcpyAsync(d, h, n * 8, hipMemcpyHostToDevice, s));
         sync(); // host staging buffers are pageable and reused
     }
-    void d2h(double *h, const double *d, size_t n) {
-        SCANRS_HIP(hipMemcpyAsync(h, d, n * 8, hipMemcpyDeviceToHost, s));
-        sync();
-    }
+    void d2h(double *h, const double *d, size_t n) { SCANRS_D2H(h, d, n * 8, s); }
 };
 
 // Everything launched through the handle inside the scope goes to `other` (kernels, scratch zero-fills, events);
@@ -311,11 +308,7 @@ static void download_panel_staged(Ctx &c, const double *d, uint32_t ld, uint64_t
 static void download_panel(Ctx &c, const double *d, uint32_t ld, uint64_t rows, uint32_t l, double *h) {
     if (rows == 0 || l == 0) return;
     if (rows * (uint64_t)l * 8 >= (8u << 20)) return download_panel_staged(c, d, ld, rows, l, h);
-    if (ld == l)
-        SCANRS_HIP(hipMemcpyAsync(h, d, (size_t)rows * l * 8, hipMemcpyDeviceToHost, c.s));
-    else
-        SCANRS_HIP(hipMemcpy2DAsync(h, (size_t)l * 8, d, (size_t)ld * 8, (size_t)l * 8, rows, hipMemcpyDeviceToHost, c.s));
-    c.sync();
+    SCANRS_D2H_2D(h, d, (size_t)ld * 8, (size_t)l * 8, rows, c.s);
 }
 
 // Gram matrix of two panels that live on the same side; reduced across ranks when that side is sharded.
@@ -1096,11 +1089,10 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
             // the one look at what the device-side factorizations did, together with the coefficients
             std::vector<int> ctl(2 * (size_t)od.used);
             std::vector<double> info(2 * (size_t)od.used);
-            SCANRS_HIP(hipMemcpy2DAsync(cfull.data(), (size_t)q * 8, cfull_d, (size_t)ldq * 8, (size_t)q * 8, q, hipMemcpyDeviceToHost, c.s));
-            SCANRS_HIP(hipMemcpyAsync(ctl.data(), od.ctl, ctl.size() * sizeof(int), hipMemcpyDeviceToHost, c.s));
-            SCANRS_HIP(hipMemcpyAsync(info.data(), od.info, info.size() * sizeof(double), hipMemcpyDeviceToHost, c.s));
             stage_mark("bk verdict sync");
-            c.sync();
+            SCANRS_D2H_2D(cfull.data(), cfull_d, (size_t)ldq * 8, (size_t)q * 8, q, c.s);
+            SCANRS_D2H(ctl.data(), od.ctl, ctl.size() * sizeof(int), c.s);
+            SCANRS_D2H(info.data(), od.info, info.size() * sizeof(double), c.s);
             stage_mark("bk verdict synced");
             for (uint32_t sl = 0; sl < od.used; sl++) {
                 if (ctl[2 * sl + 1] == 2) fail(SCANRS_ERR_NUMERICAL, "orthonormalisation: non-finite Gram matrix");
