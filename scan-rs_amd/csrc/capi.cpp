@@ -1104,10 +1104,17 @@ void mat_apply(scanrs_mat *m, bool transpose, const double *dX, uint32_t ldx, ui
         off_a = transpose ? m->off_v->p : m->off_u->p;           // n_out x rank
         ldw = even_up(l);
         double *w = st.scratch.get<double>("off_w", (size_t)m->off_rank * ldw);
-        launch_weighted_colsum(st, B, m->off_rank, dX, ldx, cp.n_inner, l, w, ldw);
+        // the dense tile product stages a compact copy of the panel: written here, from the read the column sums make anyway
+        double *xc = dXs == dX ? tile_panel_copy_target(st, cp, l) : nullptr;
+        launch_weighted_colsum(st, B, m->off_rank, dX, ldx, cp.n_inner, l, w, ldw, xc, l);
+        if (xc) {
+            st.tile_xc_src = dX;
+            st.tile_xc_l = l;
+        }
         off_w = w;
     }
     launch_spmm_f64(st, cp, map, dXs, ldx, l, dOut, ldo, off_a, m->off_rank, off_w, ldw);
+    st.tile_xc_src = nullptr;
     // contraction over the sharded dimension -> partial sums on every rank
     const bool contraction_sharded = transpose ? rows_sharded(m) : cols_sharded(m);
     if (contraction_sharded) allreduce_f64(st, dOut, (uint64_t)cp.n_outer * ldo);

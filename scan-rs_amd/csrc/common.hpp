@@ -347,6 +347,8 @@ struct Storage {
     size_t ov_tile_bytes = 0;             // hybrid product: panel slice per step of the overflow gather (0 = twice l2_tile_bytes)
     double tile_max_overflow = 0.35;      // auto path: an orientation whose layout would leave more than this share of the nonzeros to the overflow gather stays on the gather kernels
     int tile_auto = 1;                    // auto path may use the hybrid product (0: only spmm_path 3 does)
+    const double *tile_xc_src = nullptr;  // the panel whose compact copy "tile_xc" already holds (set and cleared by mat_apply around one product)
+    uint32_t tile_xc_l = 0;
     int tile_hint = 0;                    // > 0 while a solver that repeats the same products is running (svd_bk, svd_rand)
     int tile_overlap = 1;                 // hybrid product: 1 = the overflow gather runs beside the tile kernel (own stream); 0 = after it (measurement)
     int panel_precision = 0;              // 0: f64 panels (default); 1: gathered panels rounded to f32, f64 sums (opt-in)
@@ -442,7 +444,10 @@ void launch_row_reduce(Storage &st, SparseCopy &cp, const DevMap &map, int mode,
                        double *out_sumsq);
 // w[rank x l] (ld ldw) = B^T X, B: n x rank row-major, X: n x l (ld ldx)
 void launch_weighted_colsum(Storage &st, const double *B, uint32_t rank, const double *X, uint32_t ldx, uint64_t n,
-                            uint32_t l, double *w, uint32_t ldw);
+                            uint32_t l, double *w, uint32_t ldw, double *Xc = nullptr, uint32_t ldc = 0);
+// where the dense tile product of (cp, l) will stage its compact panel copy from — when the caller can fill it while it reads the
+// panel anyway (mat_apply: the column sums of the offset term) — or nullptr (another path, a layout about to be rebuilt, odd l)
+double *tile_panel_copy_target(Storage &st, SparseCopy &cp, uint32_t l);
 // C[n x m] (row-major, ld = m) = X^T Y over `rows` rows (f64 MFMA, slab + ordered reduce)
 void launch_gram(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *Y, uint32_t ldy, uint32_t m,
                  uint64_t rows, double *C);

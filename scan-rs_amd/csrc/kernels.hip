@@ -911,7 +911,7 @@ __global__ void row_reduce_finish_kernel(const MultiRow *__restrict__ multi, uin
 __global__ __launch_bounds__(256) void weighted_colsum_partial_kernel(const double *__restrict__ B, uint32_t rank,
                                                                       const double *__restrict__ X, uint32_t ldx,
                                                                       uint64_t n, uint32_t l, uint64_t rows_per_block,
-                                                                      double *__restrict__ partial) {
+                                                                      double *__restrict__ partial, double *__restrict__ Xc, uint32_t ldc) {
     __shared__ d2 part[3][64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_block;
@@ -931,6 +931,10 @@ __global__ __launch_bounds__(256) void weighted_colsum_partial_kernel(const doub
                         x[u] = *reinterpret_cast<const d2 *>(X + (i + 4u * u) * ldx + col);
                         b[u] = B[(i + 4u * u) * rank + q];
                     }
+                    if (Xc && q == 0u) { // the compact copy of the panel that the tile product stages, from the same read
+#pragma unroll
+                        for (int u = 0; u < 8; u++) *reinterpret_cast<d2 *>(Xc + (i + 4u * u) * ldc + col) = x[u];
+                    }
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         acc.x = fma(b[u], x[u].x, acc.x);
@@ -940,6 +944,7 @@ __global__ __launch_bounds__(256) void weighted_colsum_partial_kernel(const doub
                 for (; i < r1; i += 4u) {
                     const d2 x = *reinterpret_cast<const d2 *>(X + i * ldx + col);
                     const double b = B[i * rank + q];
+                    if (Xc && q == 0u) *reinterpret_cast<d2 *>(Xc + i * ldc + col) = x;
                     acc.x = fma(b, x.x, acc.x);
                     acc.y = fma(b, x.y, acc.y);
                 }
@@ -2103,8 +2108,9 @@ void launch_row_reduce(Storage &st, SparseCopy &cp, const DevMap &map, int mode,
     SCANRS_HIP(hipGetLastError());
 }
 
+// Xc (optional): a compact copy of X's first l columns in rows of ldc, written from the same read (l even: the lanes move column pairs)
 void launch_weighted_colsum(Storage &st, const double *B, uint32_t rank, const double *X, uint32_t ldx, uint64_t n,
-                            uint32_t l, double *w, uint32_t ldw) {
+                            uint32_t l, double *w, uint32_t ldw, double *Xc, uint32_t ldc) {
     if (rank == 0 || l == 0) return;
     uint32_t nblocks = (uint32_t)std::min<uint64_t>(1024, (n + 255) / 256);
     if (nblocks == 0) nblocks = 1;
@@ -2112,7 +2118,7 @@ void launch_weighted_colsum(Storage &st, const double *B, uint32_t rank, const d
     double *partial = st.scratch.get<double>("wcs_partial", (size_t)nblocks * rank * l);
     ProfScope ps(st, "weighted_colsum", (double)n * l * 8.0 + (double)n * rank * 8.0);
     hipLaunchKernelGGL(weighted_colsum_partial_kernel, dim3(nblocks), dim3(256), 0, st.stream, B, rank, X, ldx, n, l, rpb,
-                       partial);
+                       partial, Xc, ldc);
     hipLaunchKernelGGL(weighted_colsum_finish_kernel, grid1((uint64_t)rank * l, 64), dim3(256), 0, st.stream, partial,
                        nblocks, rank, l, w, ldw);
     SCANRS_HIP(hipGetLastError());

@@ -1665,11 +1665,14 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     // The tile kernel always reads the library's own compact copy: its staging never switches a lane off, so it reads up to two
     // tiles past the panel's end (spmm_tile_body) — the copy has that much slack behind it.
     double *xc = st.scratch.get<double>("tile_xc", ((size_t)cp.n_inner + 3u * sh.T) * ldc); // (the dense kernel stages one tile further: a part ends with a visit of its own)
+    // (mat_apply may have filled the copy while it read the panel for the offset term's column sums: tile_panel_copy_target)
+    const bool copied = st.tile_xc_src == X && st.tile_xc_l == l && ldc == l && tl.dense && !tl.unit_mode;
+    st.tile_xc_src = nullptr;
     if (tl.unit_mode) { // unit mode: the tile kernel's panel carries the per-inner factor of the unit weight
         const uint64_t n = cp.n_inner * (uint64_t)ldc;
         hipLaunchKernelGGL(tile_scale_panel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, X, ldx, cp.n_inner, l, ldc, tl.vi.p, xc);
     } else {
-        launch_copy_cols(st, X, ldx, xc, ldc, cp.n_inner, l);
+        if (!copied) launch_copy_cols(st, X, ldx, xc, ldc, cp.n_inner, l);
         if (ldx != ldc) Xov = xc;
     }
     X = xc;
@@ -1728,6 +1731,12 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     hipLaunchKernelGGL(tile_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, pbuf, sh.n_parts, part_stride, tl.slot_first.p, tl.slot_pos.p, ovout,
                        cp.n_outer, l, ldc, ldo, out, off_a, rank, off_w, ldw);
     SCANRS_HIP(hipGetLastError());
+}
+
+double *tile_panel_copy_target(Storage &st, SparseCopy &cp, uint32_t l) {
+    if ((l & 1u) || l < 16u || l > TL_LMAX || !cp.tiles || !cp.tiles->dense || cp.tiles->unit_mode || !cp.tiles->structure_matches(st)) return nullptr;
+    if (!(st.spmm_path == 3 || (st.spmm_path == 0 && st.tile_auto && st.panel_precision == 0))) return nullptr;
+    return st.scratch.get<double>("tile_xc", ((size_t)cp.n_inner + 3u * cp.tiles->sh.T) * l); // (the size launch_spmm_tiles asks for: the same buffer)
 }
 
 // scanrs_init(): one empty launch per translation unit makes the runtime load this file's code object now instead of inside the
