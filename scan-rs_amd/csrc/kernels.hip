@@ -1733,14 +1733,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     const uint64_t row0 = task * NV;
     if (row0 >= n_outer) return;
     uint32_t len_l = 0, blo = 0, bhi = 0;
+    bool any_l = false; // the vector has overflow nonzeros at all: only such rows of `out` are ever written, and tile_finish_kernel reads only those
     if (lane < (uint32_t)NV && row0 + lane < n_outer) {
         const uint32_t *bd = bounds + (row0 + lane) * (nb + 1);
         const uint32_t o0 = bd[b0];
         len_l = bd[b1] - o0;
-        const uint64_t base = indptr[row0 + lane] + o0;
+        const uint64_t i0 = indptr[row0 + lane];
+        any_l = indptr[row0 + lane + 1] > i0;
+        const uint64_t base = i0 + o0;
         blo = (uint32_t)base;
         bhi = (uint32_t)(base >> 32);
     }
+    const uint64_t any_m = __builtin_amdgcn_ballot_w64(any_l);
     uint32_t start[NV + 1];
     uint64_t base[NV];
     start[0] = 0;
@@ -1750,7 +1754,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
         base[r] = ((uint64_t)rdlane(bhi, r) << 32) | rdlane(blo, r);
     }
     const uint32_t total = start[NV];
-    if (total == 0 && !first) return;
+    if (total == 0 && (!first || any_m == 0ull)) return;
     const bool act = lane * 2u < l;
     const uint32_t lcol = act ? lane * 2u : 0u;
     d2 acc[NV];
@@ -1801,7 +1805,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     if (act) {
 #pragma unroll
         for (int r = 0; r < NV; r++)
-            if (row0 + r < n_outer && (first || start[r + 1] > start[r])) *reinterpret_cast<d2 *>(out + (row0 + r) * ldo + lcol) = acc[r];
+            if (row0 + r < n_outer && ((first && ((any_m >> r) & 1ull)) || start[r + 1] > start[r])) *reinterpret_cast<d2 *>(out + (row0 + r) * ldo + lcol) = acc[r];
     }
 }
 

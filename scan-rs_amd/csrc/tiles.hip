@@ -1498,7 +1498,7 @@ __global__ __launch_bounds__(256) void tile_finish_kernel(const double *__restri
                                                           const uint32_t *__restrict__ slot_first, const uint32_t *__restrict__ slot_pos,
                                                           const double *__restrict__ ovout, uint64_t n_outer,
                                                           uint32_t l, uint32_t ldp, uint32_t ldo, double *__restrict__ out, const double *__restrict__ off_a,
-                                                          uint32_t rank, const double *__restrict__ off_w, uint32_t ldw) {
+                                                          uint32_t rank, const double *__restrict__ off_w, uint32_t ldw, const uint64_t *__restrict__ ov_indptr) {
     const uint32_t hp = (l + 1u) / 2u; // column pairs
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_outer * hp) return;
@@ -1521,7 +1521,7 @@ __global__ __launch_bounds__(256) void tile_finish_kernel(const double *__restri
             s.y += t.y;
         }
     }
-    if (ovout) {
+    if (ovout && ov_indptr[o + 1] > ov_indptr[o]) { // (the gather writes the rows of vectors that have overflow nonzeros, and only those)
         const d2 t = *reinterpret_cast<const d2 *>(ovout + o * ldp + c);
         s.x += t.x;
         s.y += t.y;
@@ -1729,7 +1729,7 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     if (ovout && st.tile_overlap) SCANRS_HIP(hipStreamWaitEvent(st.stream, st.ev_ov, 0));
     const uint64_t n = cp.n_outer * (uint64_t)((l + 1u) / 2u);
     hipLaunchKernelGGL(tile_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, pbuf, sh.n_parts, part_stride, tl.slot_first.p, tl.slot_pos.p, ovout,
-                       cp.n_outer, l, ldc, ldo, out, off_a, rank, off_w, ldw);
+                       cp.n_outer, l, ldc, ldo, out, off_a, rank, off_w, ldw, tl.ov.indptr.p);
     SCANRS_HIP(hipGetLastError());
 }
 
