@@ -63,7 +63,9 @@ def main():
     import hashlib
 
     hsrc = hashlib.sha256()
-    for rel in ("scan-rs_amd/csrc/tiles.hip", "scan-rs_amd/csrc/kernels.hip", "scan-rs_amd/csrc/device_map.hpp"):
+    # (the same list, in the same order, as bench.py's KERNEL_SOURCES)
+    for rel in ("scan-rs_amd/csrc/tiles.hip", "scan-rs_amd/csrc/tiles_dense.inc", "scan-rs_amd/csrc/tile_dense_body.inc", "scan-rs_amd/csrc/kernels.hip",
+                "scan-rs_amd/csrc/device_map.hpp"):
         with open(rel, "rb") as f:
             hsrc.update(f.read())
     src_hash = hsrc.hexdigest()[:16]
