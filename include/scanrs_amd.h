@@ -415,11 +415,13 @@ int scanrs_init(void);
 /* Optional: one allocation of `bytes` made now, on the calling thread's current device, from which the library carves its later
  * large buffers (about 70 bytes per nonzero for a matrix that goes through normalize + PCA with the hybrid product). A caller who
  * knows the size of the matrix before it is loaded takes the allocation's latency — on a device whose memory was just freed by
- * another process the driver is still scrubbing it, and an allocation waits for that — out of the first PCA. Blocks carved from
- * a reserve return to the library's cache, the reserve itself goes back to the driver with scanrs_release_cached_memory once
- * none of it is in use. */
+ * another process the driver is still scrubbing it, and an allocation waits for that — out of the first PCA. The reserve is an
+ * arena: blocks carved from it return to it when the work queued before their release has run, neighbouring holes merge, and a
+ * later request of any size is carved from them again; the reserve itself goes back to the driver with
+ * scanrs_release_cached_memory once none of it is in use. */
 int scanrs_reserve_device_memory(uint64_t bytes);
-/* Gives the cached device blocks (see "device_cache_fraction") back to the driver / reports how much is cached. */
+/* Gives the cached device blocks (see "device_cache_fraction") back to the driver / reports how much is cached on the calling
+ * thread's current device. */
 int scanrs_release_cached_memory(void);
 int scanrs_cached_memory_bytes(uint64_t *bytes);
 /* Device memory in the library's buffers right now, all handles of the process (blocks waiting in the cache not counted). */

@@ -503,7 +503,9 @@ static void device_free_flush_impl(const Storage *owner, bool owner_gone, bool e
             Reserve *home = nullptr;
             for (Reserve &r : g.reserves)
                 if (r.owns(p)) home = &r;
-            const bool to_cache = home || (b.size >= CACHE_MIN && g.idle_bytes + b.size <= cap);
+            size_t idle_dev = 0; // what the cache holds for THIS block's device (the limit is a share of one device's memory)
+            for (auto ii = g.idle.lower_bound(std::make_pair(b.dev, (size_t)0)); ii != g.idle.end() && ii->first.first == b.dev; ++ii) idle_dev += ii->first.second;
+            const bool to_cache = home || (b.size >= CACHE_MIN && idle_dev + b.size <= cap);
             if (!to_cache && cache_only) { // in the middle of a call: hipFree would wait for the whole device, the block stays on the list
                 keep.push_back(db);
                 continue;
@@ -591,11 +593,15 @@ void device_cache_set_fraction(double f) {
     }
     if (f <= 0.0) device_cache_release();
 }
-size_t device_cache_bytes() {
+size_t device_cache_bytes() { // cached blocks of the CURRENT device (a single-process multi-GPU program has one cache per device in the same map)
     DeviceMemory &g = devmem();
     device_free_flush_impl(nullptr, false, false, true); // released blocks whose events have completed count
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(g.mu);
-    return g.idle_bytes;
+    size_t n = 0;
+    for (auto it = g.idle.lower_bound(std::make_pair(dev, (size_t)0)); it != g.idle.end() && it->first.first == dev; ++it) n += it->first.second;
+    return n;
 }
 // what scanrs_reserve_device_memory set aside on this device and nobody has been handed yet
 size_t device_reserve_unused_bytes() {
