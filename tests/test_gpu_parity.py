@@ -1346,6 +1346,42 @@ def test_set_option_refuses_values_that_cannot_be_cast(sa):
         g.chol_rinv(np.eye(4), rows=0)
 
 
+def test_released_blocks_are_not_reused_while_queued_work_names_them(sa):
+    """a block released while kernels that use it are still queued (a scratch panel that grows between two asynchronous
+    products, a tile layout replaced by an option change) must not reach another handle's allocation before those kernels have run.
+    Round 5 records one event per stream of the releasing handle at the release. Two handles on one device, asynchronous products
+    whose scratch buffers are released and re-requested in alternation: every result equals the one computed alone."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    m = _synth(60_000, 3000, 0.05, 4)  # 9 M nonzeros
+    mk = lambda: sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+    a, b = mk(), mk()
+    for h in (a, b):
+        h.set_spmm_path(2)  # the gather kernels with their per-width scratch panels
+        h.compose_scale_axis(1, np.linspace(0.5, 1.5, m.shape[0])).apply(sa.FN_LOG2_1P)
+    widths = (24, 64, 40, 96, 16, 80)
+    xs = {l: torch.randn(m.shape[0], l, device=dev, dtype=torch.float64) for l in widths}
+    ref = {}
+    for l in widths:  # alone, synchronised
+        o = torch.zeros(m.shape[1], l, device=dev, dtype=torch.float64)
+        a.dot_device(False, xs[l].data_ptr(), l, l, o.data_ptr(), l)  # (3000 x 60000) x (60000 x l)
+        a.sync()
+        ref[l] = o.clone()
+    sa.release_cached_memory()
+    for rep in range(3):
+        outs = []
+        for i, l in enumerate(widths):  # nothing waits in here: growth of one handle's scratch releases blocks the other may be handed
+            h = (a, b)[i & 1]
+            o = torch.zeros(m.shape[1], l, device=dev, dtype=torch.float64)
+            h.dot_device(False, xs[l].data_ptr(), l, l, o.data_ptr(), l)
+            outs.append((l, o))
+        a.sync()
+        b.sync()
+        for l, o in outs:
+            assert torch.equal(o, ref[l]), (rep, l)
+
+
 def test_device_memory_cache_reserve_and_accounting(sa):
     """Round 4's allocator (include/scanrs_amd.h: "device_cache_fraction", scanrs_reserve_device_memory): released blocks of 1 MB and
     more wait in a cache for the next allocation of about their size, a reserve made ahead of time serves the large buffers of a
