@@ -466,3 +466,15 @@ def test_dense_tile_kernel_leaves_registers_for_a_gather_wave(tmp_path):
     assert found, "spmm_tile_dense_kernel not found in the library's gfx950 code objects"
     for name, (vgprs, spills) in found.items():
         assert vgprs <= 216 and spills == 0, (name, vgprs, spills)
+
+
+def test_generated_tile_kernel_stream_is_the_generators_output(tmp_path):
+    """scan-rs_amd/csrc/tile_dense_body.inc is committed next to its generator (tools/gen_tile_dense_asm.py): the file in the tree must
+    be what the generator writes with its default settings — which also runs the generator's own check of the DPP wait states."""
+    import subprocess
+
+    out = tmp_path / "body.inc"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("GEN_")}
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tile_dense_asm.py"), str(out)], check=True, capture_output=True, env=env)
+    with open(os.path.join(ROOT, "scan-rs_amd", "csrc", "tile_dense_body.inc")) as f:
+        assert f.read() == out.read_text()

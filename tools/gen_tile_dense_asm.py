@@ -429,10 +429,44 @@ def gen():
     return o
 
 
+def check_dpp_hazards(lines):
+    """gfx950: a VALU write of a VGPR needs two wait states before a DPP instruction reads it, a VALU write of EXEC five. The compiler's
+    hazard recognizer does not look into an asm statement, so the stream is checked here: the DPP sources of every
+    v_fmac_f64_dpp (weights v40-v47: written by ds_bpermute_b32; rows v56-v87: written by ds_read_b128) must not be the destination
+    of one of the two vector-ALU instructions in front of it, and no vector instruction may write EXEC at all."""
+    import re
+
+    def regs(tok):
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.fullmatch(r"v(\d+)", tok)
+        return {int(m.group(1))} if m else set()
+
+    insts = [ln for ln in lines if not ln.endswith(":")]
+    for i, ln in enumerate(insts):
+        ops = [t.strip() for t in ln.split(None, 1)[1].split(",")] if " " in ln else []
+        if ln.startswith("v_") and ops and ops[0].startswith("exec"):
+            raise SystemExit(f"vector write of EXEC: {ln}")
+        if not ln.startswith("v_fmac_f64_dpp"):
+            continue
+        src = regs(ops[1]) | regs(ops[2].split()[0])
+        for back in (1, 2):
+            if i - back < 0:
+                break
+            prev = insts[i - back]
+            if not prev.startswith("v_") or prev.startswith("v_readfirstlane"):
+                continue
+            pops = [t.strip() for t in prev.split(None, 1)[1].split(",")]
+            if regs(pops[0]) & src:
+                raise SystemExit(f"DPP hazard: '{prev}' writes a source of '{ln}' {back} instruction(s) earlier")
+
+
 def main():
     lines = gen()
+    check_dpp_hazards(lines)
     here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(here, "..", "scan-rs_amd", "csrc", "tile_dense_body.inc")
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "scan-rs_amd", "csrc", "tile_dense_body.inc")
     with open(path, "w") as f:
         f.write("// generated by tools/gen_tile_dense_asm.py - do not edit\n")
         for ln in lines:
