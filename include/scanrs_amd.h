@@ -371,6 +371,8 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *   "tile_one_walk" (1)  dense tile layout: 1 = built in ONE walk over the matrix (the (group, part) blocks of the tile-sorted record
  *                       list start at the prefix sums of their capacities, found by binary searches; counts above 255 leave through
  *                       a bounded list); 0 = a counting walk and a filling walk. The same layout bit for bit.
+ *   "tile_big_list_cap" (0)  dense tile layout, one-walk build: entries of the list that carries the nonzeros with counts above 255 to the
+ *                       overflow part (0: max(4 M, nnz / 64)); a matrix with more of them is built by the two-walk form instead.
  *   "tile_emit_staged" (1)  dense tile layout, diagnostic: 0 makes the emission of the record streams search its per-visit tables in global
  *                       memory instead of LDS - the form taken by itself when a part has more than 4 000 tiles. Same layout.
  *   "tile_builder" (1)  1: wave-level builder of the tile layout (default tile shape); 0: per-thread walk (reference form)
