@@ -448,6 +448,10 @@ int scanrs_mat_chol_rinv(scanrs_mat *m, const double *g, uint32_t n, uint64_t ro
 int scanrs_debug_wait_never(double timeout_s);
 /* ... and the barrier between the shard threads of the single-process multi-GPU form, entered by one thread of `world` alone */
 int scanrs_debug_barrier_alone(uint32_t world);
+/* ... and the bookkeeping of a reserve made by scanrs_reserve_device_memory (no device needed: the arena is driven on a made-up address
+ * range): `rounds` random rounds of carving and giving back blocks; SCANRS_OK when no two live blocks ever overlapped, every block
+ * stayed inside the range, neighbouring holes always merged and the arena was whole again at the end. */
+int scanrs_debug_arena_selftest(uint32_t rounds, uint64_t seed);
 
 /* ---- host-side dense helpers (no device needed; used by the solvers where the reference calls
  * LAPACK on k x k matrices, exposed so the CPU test-suite can check them) ------------------------- */

@@ -574,6 +574,14 @@ def device_memory_in_use() -> int:
     return int(n.value)
 
 
+def debug_arena_selftest(rounds: int = 20000, seed: int = 1):
+    """The bookkeeping of a device-memory reserve driven on a made-up address range (no device needed): raises when blocks overlap,
+    holes fail to merge or the arena is not whole at the end."""
+    _lib.scanrs_debug_arena_selftest.argtypes = [ctypes.c_uint32, ctypes.c_uint64]
+    _lib.scanrs_debug_arena_selftest.restype = ctypes.c_int
+    _check(_lib.scanrs_debug_arena_selftest(ctypes.c_uint32(rounds), ctypes.c_uint64(seed)))
+
+
 def debug_wait_never(timeout_s: float):
     """The library's bounded wait on an event that is never signalled (no device needed): raises ScanrsError(DEVICE) after
     `timeout_s` seconds, with the report of a real stuck wait."""
@@ -902,7 +910,7 @@ EXPORTED_SYMBOLS = [
     "scanrs_pca_bk", "scanrs_pca_rand", "scanrs_pca_irlba", "scanrs_pca_result_device", "scanrs_knn_device", "scanrs_omega_fill", "scanrs_mat_set_shard", "scanrs_mat_set_shard_comm", "scanrs_comm_get_unique_id", "scanrs_comm_create", "scanrs_comm_free",
     "scanrs_multi_create", "scanrs_multi_free", "scanrs_multi_n_shards", "scanrs_multi_shard", "scanrs_multi_normalize", "scanrs_multi_pca_bk", "scanrs_multi_pca_rand", "scanrs_multi_pca_irlba", "scanrs_multi_log_normalize",
     "scanrs_plan_shards", "scanrs_profile_enable", "scanrs_profile_reset", "scanrs_profile_get", "scanrs_mat_sync", "scanrs_mat_set_spmm_path", "scanrs_mat_set_option", "scanrs_set_global_option", "scanrs_mat_set_panel_precision",
-    "scanrs_mat_chol_rinv", "scanrs_mat_get_counter", "scanrs_host_chol_upper", "scanrs_host_inv_upper", "scanrs_host_sym_eig", "scanrs_host_sym_eig_topk", "scanrs_debug_wait_never", "scanrs_debug_barrier_alone", "scanrs_init", "scanrs_release_cached_memory", "scanrs_cached_memory_bytes", "scanrs_reserve_device_memory", "scanrs_device_memory_in_use",
+    "scanrs_mat_chol_rinv", "scanrs_mat_get_counter", "scanrs_host_chol_upper", "scanrs_host_inv_upper", "scanrs_host_sym_eig", "scanrs_host_sym_eig_topk", "scanrs_debug_wait_never", "scanrs_debug_barrier_alone", "scanrs_debug_arena_selftest", "scanrs_init", "scanrs_release_cached_memory", "scanrs_cached_memory_bytes", "scanrs_reserve_device_memory", "scanrs_device_memory_in_use",
     "scanrs_h5_read_csc_matrix", "scanrs_h5_read_adaptive_csr_matrix", "scanrs_h5_read_matrix_metadata", "scanrs_h5_matrix_free",
     "scanrs_h5_matrix_shape", "scanrs_h5_matrix_arrays", "scanrs_h5_matrix_n_strings", "scanrs_h5_matrix_string", "scanrs_h5_matrix_removed",
     "scanrs_h5_read_umi_counts", "scanrs_h5_get_clustering_keys", "scanrs_h5_get_clustering", "scanrs_h5_get_differential_expression",

@@ -2283,6 +2283,61 @@ int scanrs_mat_chol_rinv(scanrs_mat *m, const double *g, uint32_t n, uint64_t ro
 // The bounded wait on an event that is never signalled: the library's own poll loop (poll_until + the timeout report) over a
 // query that always answers "not ready" — no HIP call is made, so it runs without a device. Returns SCANRS_ERR_DEVICE after
 // `timeout_s` with the message a real stuck wait would leave in scanrs_last_error().
+int scanrs_debug_arena_selftest(uint32_t rounds, uint64_t seed) {
+    return guard([&] {
+        constexpr size_t UNIT = 2u << 20;
+        Reserve r{reinterpret_cast<char *>((uintptr_t)1 << 40), 512 * UNIT, 0, {}};
+        r.holes.emplace(0, r.size);
+        std::map<char *, size_t> live; // base -> length
+        uint64_t z = seed * 0x9E3779B97F4A7C15ull + 1;
+        auto rnd = [&]() {
+            z ^= z << 13;
+            z ^= z >> 7;
+            z ^= z << 17;
+            return z;
+        };
+        auto check = [&]() {
+            size_t held = 0;
+            char *prev_end = r.base;
+            for (auto &b : live) {
+                if (b.first < prev_end || b.first + b.second > r.base + r.size) fail(SCANRS_ERR_NUMERICAL, "arena selftest: a live block overlaps its neighbour or leaves the range");
+                prev_end = b.first + b.second;
+                held += b.second;
+            }
+            if (held + r.unused() != r.size) fail(SCANRS_ERR_NUMERICAL, "arena selftest: %zu bytes held + %zu unused != %zu", held, r.unused(), r.size);
+            size_t end_prev = (size_t)-1;
+            for (auto &h : r.holes) {
+                if (h.second == 0 || h.first == end_prev) fail(SCANRS_ERR_NUMERICAL, "arena selftest: an empty hole, or two holes that should have merged");
+                end_prev = h.first + h.second;
+                for (auto &b : live) // no hole inside a live block
+                    if (r.base + h.first < b.first + b.second && b.first < r.base + h.first + h.second) fail(SCANRS_ERR_NUMERICAL, "arena selftest: a hole overlaps a live block");
+            }
+        };
+        for (uint32_t i = 0; i < rounds; i++) {
+            if (live.empty() || (rnd() % 3u) != 0u) {
+                const size_t want = (1 + rnd() % 40) * UNIT;
+                if (void *p = r.take(want)) {
+                    live[static_cast<char *>(p)] = want;
+                } else { // no hole holds it: then no hole may be that large
+                    for (auto &h : r.holes)
+                        if (h.second >= want) fail(SCANRS_ERR_NUMERICAL, "arena selftest: a request was refused although a hole holds it");
+                }
+            } else {
+                auto it = live.begin();
+                std::advance(it, (long)(rnd() % live.size()));
+                r.give(it->first, it->second);
+                live.erase(it);
+            }
+            check();
+        }
+        while (!live.empty()) {
+            r.give(live.begin()->first, live.begin()->second);
+            live.erase(live.begin());
+            check();
+        }
+        if (r.holes.size() != 1 || r.holes.begin()->first != 0 || r.holes.begin()->second != r.size) fail(SCANRS_ERR_NUMERICAL, "arena selftest: the arena is not whole at the end");
+    });
+}
 int scanrs_debug_wait_never(double timeout_s) {
     return guard([&] {
         if (!(timeout_s > 0.0)) fail(SCANRS_ERR_ARGUMENT, "timeout must be positive");

@@ -478,3 +478,11 @@ def test_generated_tile_kernel_stream_is_the_generators_output(tmp_path):
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tile_dense_asm.py"), str(out)], check=True, capture_output=True, env=env)
     with open(os.path.join(ROOT, "scan-rs_amd", "csrc", "tile_dense_body.inc")) as f:
         assert f.read() == out.read_text()
+
+
+def test_reserve_arena_bookkeeping(sa):
+    """scanrs_reserve_device_memory's reserve is an arena since round 5 (best-fit carving, blocks given back, neighbouring holes merged).
+    Its bookkeeping driven on a made-up address range — no device needed: thousands of random rounds with all invariants checked after
+    every step (include/scanrs_amd.h: scanrs_debug_arena_selftest)."""
+    for seed in (1, 2, 3):
+        sa.debug_arena_selftest(4000, seed)
