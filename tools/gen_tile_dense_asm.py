@@ -32,9 +32,10 @@ import sys
 
 PRIO = int(os.environ.get("GEN_PRIO") or 0)  # experiments (no gain, profiles/HISTORY.md): 1 = waves 4-7 at priority 1, 2 = two copies of the round whose priorities alternate per batch, opposite in the two waves of a SIMD
 STAMP = bool(os.environ.get("GEN_STAMP"))  # diagnostic build: s_memtime stamps around the round's body, the staging wait and the barrier, summed per wave
-SKIP = set((os.environ.get("GEN_SKIP") or "").split(","))  # timing experiments (wrong results): w = weights, r = records, b = barrier, d = staging
+SKIP = set((os.environ.get("GEN_SKIP") or "").split(","))  # timing experiments (wrong results): w = weights, r = records, b = barrier, d = staging, p = weight spreading (ds_bpermute)
 
 PRE = (os.environ.get("GEN_PRE") or "0") != "0"  # experiment (slower by 0.3 ms per pass, profiles/HISTORY.md): the row reads of a round's first two batches are issued at the boundary in front of it (0: in the round's prologue)
+WDIRECT = (os.environ.get("GEN_WDIRECT") or "1") != "0"  # a round's weights are loaded in the form the FMAs read (lane L: weight L % 16 of each chunk: four loads); 0: one load + eight ds_bpermute_b32
 DMA_TOP = (os.environ.get("GEN_DMA") or "tail") == "top"  # staging loads at the round's start instead of in its last batches
 BP = int(os.environ.get("GEN_BP") or 4)   # positions per batch (two batches of row reads in flight); 8 is as fast but takes 40 registers more
 NB = 64 // BP     # batches per round
@@ -101,8 +102,15 @@ def dma(i, out):
     out.append(f"s_add_u32 s30, s17, {i * 8192}")
     out.append("s_min_u32 s30, s30, s31")
     out.append("s_add_u32 m0, s30, s35")
-    out.append("s_nop 0")
-    out.append(f"global_load_lds_dwordx4 v{31 + i}, s[24:25]")
+    if WDIRECT:
+        # (the chunk's offset goes into the scalar base - VCC is free between two rounds' tops - and every chunk uses the one lane offset v34:
+        # the five offset registers of the first form hold the next round's weights now)
+        out.append("s_add_u32 vcc_lo, s24, s30")
+        out.append("s_addc_u32 vcc_hi, s25, 0")
+        out.append("global_load_lds_dwordx4 v34, vcc")
+    else:
+        out.append("s_nop 0")
+        out.append(f"global_load_lds_dwordx4 v{31 + i}, s[24:25]")
 
 
 def reload_slot(c, out):
@@ -146,12 +154,15 @@ def gen():
     a("v_mov_b32 v39, %[pwhi]")
     a("v_mov_b32 v36, %[ring]")
     a("v_mov_b32 v37, %[rowb]")
-    a("v_and_b32 v30, 60, %[lane4]")  # 4 (lane % 16): ds_bpermute address of this lane's weight inside a chunk
-    a("v_lshlrev_b32 v28, 2, %[lane4]")  # 16 x lane (v28: free until the first round)
-    for i in range(5):  # source offsets of the wave's five staging chunks: min((wave + 8 i) 1024, tile bytes - 1024) + 16 lane
-        a(f"s_add_u32 s30, s17, {i * 8192}")
-        a("s_min_u32 s30, s30, s31")
-        a(f"v_add_u32 v{31 + i}, s30, v28")
+    if WDIRECT:
+        a("v_lshlrev_b32 v34, 2, %[lane4]")  # 16 x lane: the lane's offset inside a 1 KB staging chunk
+    else:
+        a("v_and_b32 v30, 60, %[lane4]")  # 4 (lane % 16): ds_bpermute address of this lane's weight inside a chunk
+        a("v_lshlrev_b32 v28, 2, %[lane4]")  # 16 x lane (v28: free until the first round)
+        for i in range(5):  # source offsets of the wave's five staging chunks: min((wave + 8 i) 1024, tile bytes - 1024) + 16 lane
+            a(f"s_add_u32 s30, s17, {i * 8192}")
+            a("s_min_u32 s30, s30, s31")
+            a(f"v_add_u32 v{31 + i}, s30, v28")
     if PRIO == 1:
         a("s_cmp_ge_u32 s17, 0x1000")
         a("s_cbranch_scc0 LP0%=")
@@ -177,7 +188,11 @@ def gen():
     a("s_lshl_b32 s30, s29, 7")
     a("v_add_co_u32 v38, vcc, s30, v38")
     a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
-    a("global_load_dwordx2 v[26:27], v[38:39], off offset:-512")  # weights of round 0
+    if WDIRECT:
+        for c in range(4):
+            a(f"global_load_dwordx2 v[{26 + 2 * c}:{27 + 2 * c}], v[38:39], off offset:{-512 + 128 * c}")  # weights of round 0
+    else:
+        a("global_load_dwordx2 v[26:27], v[38:39], off offset:-512")  # weights of round 0
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")           # ... and the item's first tile (staged by the caller)
     if not PRE:
         if "b" not in SKIP:
@@ -205,7 +220,16 @@ def gen():
         a("s_lshl_b32 s30, s100, 7")
         a("v_add_co_u32 v38, vcc, s30, v38")         # behind the next round's weights
         a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
-        a("global_load_dwordx2 v[26:27], v[38:39], off offset:-512" if "w" not in SKIP else "s_nop 0")
+        if "w" in SKIP:
+            a("s_nop 0")
+        elif WDIRECT:
+            # lane L: weight L % 16 of each of the next round's four chunk slots (v[38:39] carries 8 (L % 16)): the form the FMAs' DPP
+            # broadcast reads. Four loads of 128 distinct bytes each where one load + eight ds_bpermute_b32 stood: the permutes cost
+            # 1.5 ms per pass (timing experiment GEN_SKIP=p), at the top of every round, in front of its first FMA
+            for c in range(4):
+                a(f"global_load_dwordx2 v[{26 + 2 * c}:{27 + 2 * c}], v[38:39], off offset:{-512 + 128 * c}")
+        else:
+            a("global_load_dwordx2 v[26:27], v[38:39], off offset:-512")
         a("s_lshl_b32 s30, s100, 6")                 # where the next round's four chunk slots come from
         a("s_add_u32 s32, s20, s30")
         a("s_addc_u32 s33, s21, 0")
@@ -216,9 +240,12 @@ def gen():
             # without it a boundary waits for slot 3's load to come from HBM, +350 clk per round). An LDS-DMA load into 256 scratch bytes of
             # this wave behind the ring: it needs no register to land in, and it is this round's OLDEST vector-memory operation
             # (v48: an address register; an instruction reads its address operand at issue, so the row reads that named it are past it)
-            a("s_min_u32 s30, s17, s31")
-            a("v_sub_u32 v48, v31, s30")             # 16 x lane
-            a("v_lshrrev_b32 v48, 2, v48")           # 4 x lane: 256 bytes = four chunk slots
+            if WDIRECT:
+                a("v_lshrrev_b32 v48, 2, v34")       # 4 x lane: 256 bytes = four chunk slots
+            else:
+                a("s_min_u32 s30, s17, s31")
+                a("v_sub_u32 v48, v31, s30")         # 16 x lane
+                a("v_lshrrev_b32 v48, 2, v48")       # 4 x lane: 256 bytes = four chunk slots
             a("s_lshr_b32 s30, s17, 2")
             a("s_add_u32 s30, s30, s19")
             a("s_add_u32 m0, s30, 0x400")            # behind the ring and the row of zeros
@@ -230,8 +257,14 @@ def gen():
         a("s_load_dword s12, s[22:23], 0xc")         # header three rounds ahead
 
     def spread_weights():
+        if WDIRECT:
+            for i_ in range(8):
+                a(f"v_mov_b32 v{W0 + i_}, v{26 + i_}")   # (vector moves: more than the two wait states a DPP read of them needs lie before the first FMA)
+            return
         a("v_mov_b32 v28, v26")
         a("v_mov_b32 v29, v27")
+        if "p" in SKIP:  # timing experiment (wrong results): no spreading of the weights through ds_bpermute
+            return
         for c in range(4):
             a(f"ds_bpermute_b32 v{W0 + 2 * c}, v30, v28 offset:{64 * c}")
             a(f"ds_bpermute_b32 v{W0 + 2 * c + 1}, v30, v29 offset:{64 * c}")
