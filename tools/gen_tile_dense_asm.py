@@ -13,11 +13,12 @@ read with v_readfirstlane_b32):
   v[56:87]    panel rows of 8 positions in flight (4 registers each)
   v[48:55]    their LDS addresses (v48 also: the offset of the records' "touch" load at the round's start)
   v[40:47]    weights of the round's 4 chunks: lane L holds weight L % 16 of the chunk (one register pair per chunk)
-  v[38:39]    this lane's address in the weight stream: 8 L behind the END of the NEXT round's weights
+  v[38:39]    this lane's address in the weight stream: 8 (L % 16) behind the END of the NEXT round's weights
   v36 ring base of the lane (LDS address of its column pair in ring row 0), v37 row pitch in bytes
-  v[31:35]    LDS-DMA source offsets of the wave's 5 staging chunks
-  v30         4 x (lane % 16): the ds_bpermute address of this lane's weight inside a chunk
-  v[28:29]    this round's 64 weights as loaded (lane L: weight L), v[26:27] the NEXT round's
+  v[26:33]    the NEXT round's weights as loaded: one register pair per chunk, lane L: weight L % 16 of the chunk (moved to v[40:47] at the
+              round's start). v34 16 x lane: the lane's offset inside a 1 KB staging chunk (the chunk's own offset rides in the scalar base)
+              (GEN_WDIRECT=0, the round's first form: v[26:27] next weights lane L = weight L, v[28:29] this round's, v30 the ds_bpermute
+              address 4 x (lane % 16), v[31:35] the five staging chunks' offsets)
   (216 registers in all: two tile waves per SIMD leave 80 for a wave of the overflow gather, which runs beside this kernel)
   s[36:99]    the round's records: bits 7:0 = 4 x slot (the VGPR index), 15:8 = raw count (weight refresh only), 31:16 = ring row
   s[13:16]    copies of the last batch's four records (their chunk slot is reloaded before its FMAs)
@@ -128,8 +129,9 @@ def gen():
         of the last batch, whose four accumulator indices are copied to s[13:16] first). Scalar loads return out of order, so only the
         boundary's lgkmcnt(0) certifies them; the counted waits of the row reads in between stay correct (a count that includes scalar
         loads can only wait for MORE row reads than needed, one per scalar load still in flight);
-      * weights: one 512-byte load per round into v[24:25] (lane L: weight L of the 64 positions that end at the next round's last
-        one), moved to v[28:29] and spread by eight ds_bpermute_b32 at the next round's start (every row of 16 lanes = one chunk);
+      * weights: four 128-byte loads per round into v[26:33] (lane L: weight L % 16 of each of the four chunk slots that end at the next
+        round's last one), moved to v[40:47] by eight v_mov at the next round's start (every row of 16 lanes then holds a chunk's 16
+        weights, which v_fmac_f64_dpp row_newbcast picks from);
       * panel tiles: five LDS-DMA loads per wave and round, in the round's last four batches and behind it. A round that is not the
         first of its visit stages the same tile once more (same bytes, same place; nobody reads it before the visit after the next):
         with the same five loads in every round the boundary's vmcnt(5) means the same thing everywhere;
