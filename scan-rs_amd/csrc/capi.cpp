@@ -2153,6 +2153,8 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.tile_dense = value != 0.0;
         } else if (k == "tile_sort_slots") {
             st.tile_sort_slots = value != 0.0;
+        } else if (k == "tile_fold") {
+            st.tile_fold = value != 0.0;
         } else if (k == "tile_big_list_cap") {
             if (!(value >= 0.0) || value > 4.0e9) fail(SCANRS_ERR_ARGUMENT, "tile_big_list_cap must be in 0..4e9");
             st.tile_big_list_cap = (uint64_t)value;

@@ -341,6 +341,7 @@ struct Storage {
     int tile_dense = 1;                   // tile layout of the default shape: 1 = dense record streams, accumulators picked through VGPR index mode (round 5, tiles_dense.inc); 0 = fixed positions per (slot, visit) (round 4)
     int tile_sort_slots = 1;              // dense tile layout: slots placed in the order of their load (0: in vector order)
     int tile_emit_staged = 1;             // dense tile layout: the stream emission keeps its tables in LDS (0: searches them in global memory, the form for parts of > 4 000 tiles)
+    int tile_fold = 1;                    // dense tile layout, separable map: the factor of the side without the nonlinear links stays out of the per-position weights (0: both factors in every weight)
     uint64_t tile_big_list_cap = 0;       // dense tile layout, one-walk build: capacity of the list of nonzeros with counts above 255 (0: max(4 M, nnz / 64)); beyond it the two-walk build takes over
     int tile_one_walk = 1;                // dense tile layout: built in one walk over the matrix (0: count walk + fill walk; the same layout)
     int tile_builder = 1;                 // layout builder: 1 = wave-level (a lane per vector, visits in lock-step, rows written whole; default shape only), 0 = per-thread walk

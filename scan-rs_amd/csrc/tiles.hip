@@ -845,6 +845,7 @@ struct TileLayout {
     DevBuf<uint32_t> slot_order;   // dense: the slot at place p of the layout (group p / 32, accumulator p % 32), slots sorted by load; empty: place = slot
     DevBuf<uint32_t> slot_pos;     // ... and the place of slot s
     DevBuf<double> w_place, w_inner; // dense, separable map: the weight's factor by place ([8] per place when the outer side owns the nonlinear links) / [8] per inner position otherwise
+    bool fold_inner = false, fold_outer = false; // dense, separable map: the side without the nonlinear links keeps its factor out of the weights (tiles_dense.inc, dense_weights_kernel)
     bool separable = false;        // dense: the map's count-1 value is uo[outer] vi[inner] (tables in uo / vi / ratio_tab)
     // identity of the map the weights were evaluated under (MapOp ids are never reused); -1: none yet
     int sig_n = -1;
@@ -1498,7 +1499,8 @@ __global__ __launch_bounds__(256) void tile_finish_kernel(const double *__restri
                                                           const uint32_t *__restrict__ slot_first, const uint32_t *__restrict__ slot_pos,
                                                           const double *__restrict__ ovout, uint64_t n_outer,
                                                           uint32_t l, uint32_t ldp, uint32_t ldo, double *__restrict__ out, const double *__restrict__ off_a,
-                                                          uint32_t rank, const double *__restrict__ off_w, uint32_t ldw, const uint64_t *__restrict__ ov_indptr) {
+                                                          uint32_t rank, const double *__restrict__ off_w, uint32_t ldw, const uint64_t *__restrict__ ov_indptr,
+                                                          const double *__restrict__ uo) {
     const uint32_t hp = (l + 1u) / 2u; // column pairs
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_outer * hp) return;
@@ -1520,6 +1522,11 @@ __global__ __launch_bounds__(256) void tile_finish_kernel(const double *__restri
             s.x += t.x;
             s.y += t.y;
         }
+    }
+    if (uo) { // dense layout, outer side's factor kept out of the weights (TileLayout::fold_outer)
+        const double f = uo[o];
+        s.x *= f;
+        s.y *= f;
     }
     if (ovout && ov_indptr[o + 1] > ov_indptr[o]) { // (the gather writes the rows of vectors that have overflow nonzeros, and only those)
         const d2 t = *reinterpret_cast<const d2 *>(ovout + o * ldp + c);
@@ -1666,9 +1673,9 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     // tiles past the panel's end (spmm_tile_body) — the copy has that much slack behind it.
     double *xc = st.scratch.get<double>("tile_xc", ((size_t)cp.n_inner + 3u * sh.T) * ldc); // (the dense kernel stages one tile further: a part ends with a visit of its own)
     // (mat_apply may have filled the copy while it read the panel for the offset term's column sums: tile_panel_copy_target)
-    const bool copied = st.tile_xc_src == X && st.tile_xc_l == l && ldc == l && tl.dense && !tl.unit_mode;
+    const bool copied = st.tile_xc_src == X && st.tile_xc_l == l && ldc == l && tl.dense && !tl.unit_mode && !tl.fold_inner;
     st.tile_xc_src = nullptr;
-    if (tl.unit_mode) { // unit mode: the tile kernel's panel carries the per-inner factor of the unit weight
+    if (tl.unit_mode || (tl.dense && tl.fold_inner)) { // the tile kernel's panel carries the per-inner factor of the weight
         const uint64_t n = cp.n_inner * (uint64_t)ldc;
         hipLaunchKernelGGL(tile_scale_panel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, X, ldx, cp.n_inner, l, ldc, tl.vi.p, xc);
     } else {
@@ -1729,12 +1736,12 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     if (ovout && st.tile_overlap) SCANRS_HIP(hipStreamWaitEvent(st.stream, st.ev_ov, 0));
     const uint64_t n = cp.n_outer * (uint64_t)((l + 1u) / 2u);
     hipLaunchKernelGGL(tile_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st.stream, pbuf, sh.n_parts, part_stride, tl.slot_first.p, tl.slot_pos.p, ovout,
-                       cp.n_outer, l, ldc, ldo, out, off_a, rank, off_w, ldw, tl.ov.indptr.p);
+                       cp.n_outer, l, ldc, ldo, out, off_a, rank, off_w, ldw, tl.ov.indptr.p, (tl.dense && tl.fold_outer) ? tl.uo.p : (const double *)nullptr);
     SCANRS_HIP(hipGetLastError());
 }
 
 double *tile_panel_copy_target(Storage &st, SparseCopy &cp, uint32_t l) {
-    if ((l & 1u) || l < 16u || l > TL_LMAX || !cp.tiles || !cp.tiles->dense || cp.tiles->unit_mode || !cp.tiles->structure_matches(st)) return nullptr;
+    if ((l & 1u) || l < 16u || l > TL_LMAX || !cp.tiles || !cp.tiles->dense || cp.tiles->unit_mode || cp.tiles->fold_inner || !cp.tiles->structure_matches(st)) return nullptr;
     if (!(st.spmm_path == 3 || (st.spmm_path == 0 && st.tile_auto && st.panel_precision == 0))) return nullptr;
     return st.scratch.get<double>("tile_xc", ((size_t)cp.n_inner + 3u * cp.tiles->sh.T) * l); // (the size launch_spmm_tiles asks for: the same buffer)
 }
