@@ -33,7 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 LDS_PEAK_TBS = 150.0   # MI355X_MICROARCH.md, LDS: ds_read_b128 = 256 B/clk/CU, "aggregate with every CU streaming (~2.4 GHz): ~150 TB/s"
 LDS_SURVEY_TBS = 78.6  # SURVEY.md §8d's estimate (128 B/clk/CU x 256 CUs x 2.4 GHz), kept beside it
 PMC_PROFILE = "r05f_pmc_traffic.json"  # committed PMC passes (separate --pmc runs) the `traffic` field is read from
-KERNEL_SOURCES = ("scan-rs_amd/csrc/tiles.hip", "scan-rs_amd/csrc/tiles_dense.inc", "scan-rs_amd/csrc/tile_dense_body.inc", "scan-rs_amd/csrc/kernels.hip",
+KERNEL_SOURCES = ("scan-rs_amd/csrc/tiles.hip", "scan-rs_amd/csrc/tiles_dense.inc", "scan-rs_amd/csrc/tile_dense_body.inc", "scan-rs_amd/csrc/tile_dense_body_tabo.inc",
+                  "scan-rs_amd/csrc/tile_dense_body_tabi.inc", "scan-rs_amd/csrc/kernels.hip",
                   "scan-rs_amd/csrc/device_map.hpp")
 
 
@@ -690,6 +691,26 @@ def main():
         alg_per_launch = st["algorithmic_bytes"] / max(1, st["launches"])
         lds_per_launch = st["onchip_gather_bytes"] / max(1, st["launches"])
         avg_s = st["total_ms"] / max(1, st["launches"]) * 1e-3
+        # SURVEY.md section 8(d), to the letter: B_pass(l) = 8 Z + 8 (R + 1) + 2 G l 8 with R cells, G genes - the gene-side panel read
+        # once and written once, the cell-side panel NOT counted (the survey's pass is the fused X^T (X B); this build runs its two
+        # halves as two launches, each of which moves one gene-side and one cell-side panel: `algorithmic_bytes_per_launch_unfused`).
+        # One launch of the dominant kernel works the share of the nonzeros the tile layout serves.
+        l_pass = 2 * args.k
+        z_loc, r_loc, g_all = float(nnz_local), float(n_local), float(args.genes)
+        served = 1.0 - mat.counter("tile_overflow_nonzeros") / max(1, 2 * nnz_local) if name.startswith("spmm_tile_kernel") else 1.0
+        b_pass = lambda l: 8.0 * z_loc + 8.0 * (r_loc + 1.0) + 16.0 * g_all * l
+        alg_8d = b_pass(l_pass) * served if name.startswith("spmm_tile_kernel") else alg_per_launch
+        # the whole PCA by the survey's schedule: 2 statistics passes + n_iter fused passes at l = b + 1 fused pass at l = 5 b + 1 projection pass
+        pca_8d = ((8.0 * z_loc + 8.0 * (r_loc + 1.0) + 4.0 * r_loc) + (8.0 * z_loc + 8.0 * (r_loc + 1.0) + 8.0 * r_loc + 16.0 * g_all)
+                  + 5.0 * b_pass(l_pass) + b_pass(5 * l_pass) + (8.0 * z_loc + 8.0 * g_all * args.k + 8.0 * r_loc * args.k))
+        prof_ms = None  # the same kernel's average duration in the committed rocprofv3 kernel trace (same source-hash rule as `traffic`)
+        try:
+            with open(os.path.join(ROOT, "profiles", PMC_PROFILE.replace("traffic", "counters"))) as f:
+                cj0 = json.load(f)
+            if cj0.get("kernel_source_sha256_16") == kernel_source_hash():
+                prof_ms = cj0.get("avg_launch_ms", {}).get(name.split("/")[0])
+        except (OSError, ValueError, KeyError):
+            prof_ms = None
         # LDS-array and vector-pipe occupancy of the same kernel from the committed counter passes (same source-hash rule as `traffic`):
         # SQ_LDS_IDX_ACTIVE = LDS-array cycles (4 per ds_read_b128, idle lanes included), SQ_INSTS_VALU x 4 clk per SIMD, against the
         # cycles the launch had at the shader clock the run held (SQ_BUSY_CYCLES / 32 shader engines / duration: the kernel is
@@ -715,17 +736,31 @@ def main():
         roof = {
             "bound": "hbm",
             "kernel": name,
-            "achieved": round(achieved, 2),
+            # achieved / frac follow SURVEY.md section 8(d)'s bytes; the unfused count this build's launches
+            # really move (both panels of a half pass) stands beside them under its own name
+            "achieved": round(alg_8d / avg_s / 1e9, 2) if avg_s > 0 else 0.0,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5),
+            "frac": round(alg_8d / avg_s / 1e9 / HBM_PEAK_GBS, 5) if avg_s > 0 else 0.0,
+            "frac_8d": round(alg_8d / avg_s / 1e9 / HBM_PEAK_GBS, 5) if avg_s > 0 else 0.0,
             "traffic": traffic,
             "traffic_source": traffic_src,
             "launches_per_step": st["launches"] / args.steps,
             "avg_launch_ms": round(st["total_ms"] / max(1, st["launches"]), 4),
-            "algorithmic_bytes_per_launch": round(st["algorithmic_bytes"] / max(1, st["launches"])),
+            "avg_launch_ms_is": "HIP events on the library's stream around every launch of the timed steps, in this run",
+            "avg_launch_ms_rocprof": prof_ms,
+            "avg_launch_ms_rocprof_is": f"the same kernel in profiles/{PMC_PROFILE.replace('traffic', 'counters')} (rocprofv3 --kernel-trace of this command, first-call launches included; null when the kernel sources differ)",
+            "algorithmic_bytes_per_launch": round(alg_8d),
+            "algorithmic_bytes_per_launch_is": "SURVEY 8(d): (8 Z + 8 (R + 1) + 16 G l) x the share of the nonzeros the tile layout serves; l = 2 k",
+            "algorithmic_bytes_per_launch_unfused": round(alg_per_launch),
+            "achieved_unfused": round(achieved, 2),
+            "frac_unfused": round(achieved / HBM_PEAK_GBS, 5),
+            "unfused_is": "8 Z + 8 (R + 1) + 8 G l + 8 R l: a half pass also reads or writes the cell-side panel, which the survey's fused pass keeps on chip",
+            # the whole PCA by the survey's schedule (2 statistics + 5 fused + 1 wide + 1 projection pass) over the step's wall time
+            "pca": {"bytes_8d": round(pca_8d), "achieved": round(pca_8d / (ms_per_step * 1e-3) / 1e9, 2), "unit": "GB/s",
+                    "frac": round(pca_8d / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world, 5)},
             # HBM bytes the counters saw per algorithmic byte (re-reads, staging through L2 misses): the first thing to fix when >> 1
-            "wasted_traffic_ratio": round(traffic / alg_per_launch, 2) if traffic and alg_per_launch else None,
+            "wasted_traffic_ratio": round(traffic / alg_8d, 2) if traffic and alg_8d else None,
             # the ceiling that actually binds this kernel: panel rows read from LDS (one 16-byte read per lane and record position)
             # against the LDS bandwidth of the chip; HBM is far from it by construction (800 B of panel row per 8 B of matrix)
             "onchip": {

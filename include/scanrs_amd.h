@@ -369,14 +369,19 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *   "tile_sort_slots" (1)  dense tile layout: the slots take their places (workgroup item, wave, accumulator) in the order of their load,
  *                       heaviest first, so that the 8 waves of an item carry about the same number of records per visit (0: vector order)
  *   "tile_one_walk" (1)  dense tile layout: 1 = built in ONE walk over the matrix (the (group, part) blocks of the tile-sorted record
- *                       list start at the prefix sums of their capacities, found by binary searches; counts above 255 leave through
+ *                       list start at the prefix sums of their capacities, found by binary searches; counts above 15 leave through
  *                       a bounded list); 0 = a counting walk and a filling walk. The same layout bit for bit.
  *   "tile_fold" (1)     dense tile layout under a map whose count-1 value is a product of a per-row and a per-column factor (every
  *                       normalisation of the reference): 1 = the weight of a record position holds only the factor of the side that owns
  *                       the logarithm (with the count's ratio); the other side's factor rides in the staged panel (columns of the
  *                       product's inner side) or is applied when a vector's sums are collected (outer side) - one table lookup per
  *                       position in the weight refresh instead of two; 0 = both factors in every weight. Same products to rounding.
- *   "tile_big_list_cap" (0)  dense tile layout, one-walk build: entries of the list that carries the nonzeros with counts above 255 to the
+ *   "tile_wtab" (1)     dense tile layout under such a map (with tile_fold 1): 1 = the product kernel evaluates the map itself - it gathers a
+ *                       record position's weight from a table of 16 entries by count per place of the layout (or per inner position),
+ *                       addressed by the record's own count and slot / ring row; no per-position weight exists in memory and a normalize
+ *                       rewrites only the table. Counts above 15 are served by the overflow part, where the chain is evaluated per
+ *                       nonzero. 0 = one f64 weight per record position, rewritten by every normalize (the form every other map takes)
+ *   "tile_big_list_cap" (0)  dense tile layout, one-walk build: entries of the list that carries the nonzeros with counts above 15 to the
  *                       overflow part (0: max(4 M, nnz / 64)); a matrix with more of them is built by the two-walk form instead.
  *   "tile_emit_staged" (1)  dense tile layout, diagnostic: 0 makes the emission of the record streams search its per-visit tables in global
  *                       memory instead of LDS - the form taken by itself when a part has more than 4 000 tiles. Same layout.

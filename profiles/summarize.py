@@ -64,7 +64,8 @@ def main():
 
     hsrc = hashlib.sha256()
     # (the same list, in the same order, as bench.py's KERNEL_SOURCES)
-    for rel in ("scan-rs_amd/csrc/tiles.hip", "scan-rs_amd/csrc/tiles_dense.inc", "scan-rs_amd/csrc/tile_dense_body.inc", "scan-rs_amd/csrc/kernels.hip",
+    for rel in ("scan-rs_amd/csrc/tiles.hip", "scan-rs_amd/csrc/tiles_dense.inc", "scan-rs_amd/csrc/tile_dense_body.inc", "scan-rs_amd/csrc/tile_dense_body_tabo.inc",
+                  "scan-rs_amd/csrc/tile_dense_body_tabi.inc", "scan-rs_amd/csrc/kernels.hip",
                 "scan-rs_amd/csrc/device_map.hpp"):
         with open(rel, "rb") as f:
             hsrc.update(f.read())

@@ -70,10 +70,12 @@ bool device_lost() { return g_device_lost.load(std::memory_order_acquire); }
 // the handles of this process (registered by Storage's constructor): "is every stream the library owns idle?" walks them
 static std::mutex g_storages_mu;
 static std::set<const Storage *> g_storages;
+static std::atomic<int> g_storages_dying{0}; // handles inside their destructor: out of the set (nobody may walk their members), their streams possibly still draining
 static hipStream_t storage_side_stream(const Storage &st); // the helper thread's stream, if a helper exists (defined behind SideBuild)
 static bool storage_streams_idle(const Storage *st);
 static bool all_library_streams_idle() {
     std::lock_guard<std::mutex> lk(g_storages_mu);
+    if (g_storages_dying.load(std::memory_order_acquire) > 0) return false;
     for (const Storage *st : g_storages)
         if (!storage_streams_idle(st)) return false;
     return true;
@@ -113,32 +115,55 @@ void *landing_slot(size_t bytes) {
     return ring + at;
 }
 namespace {
-struct LandingArea {
-    std::mutex mu; // one user at a time (these copies are small and rare: histograms, factor verdicts, axis sums, small panels)
-    char *p = nullptr;
+// Pinned staging areas of 8 MB for the array copies (histograms, factor verdicts, axis sums, small panels). A copy takes one for
+// itself for as long as it waits and hands it back afterwards: the pool's mutex is held only to take and to give (one
+// area under one mutex held across the wait made every handle and shard thread queue behind the stream with the longest backlog).
+// An area whose wait timed out is NOT given back - the abandoned copy may still land in it. Never unmapped.
+struct LandingPool {
+    std::mutex mu;
+    std::vector<char *> idle;
     static constexpr size_t BYTES = 8u << 20;
 };
-LandingArea &landing_area() {
-    static LandingArea *a = [] {
-        auto *x = new LandingArea(); // never destroyed
-        void *q = nullptr;
-        if (hipHostMalloc(&q, LandingArea::BYTES, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            q = malloc(LandingArea::BYTES);
-        }
-        x->p = static_cast<char *>(q);
-        return x;
-    }();
+LandingPool &landing_pool() {
+    static LandingPool *a = new LandingPool(); // never destroyed
     return *a;
 }
+struct LandingLease {
+    char *p = nullptr;
+    bool keep = true; // cleared when the lease ends in order: a timed-out wait unwinds past `done()` and the area stays out of the pool
+    LandingLease() {
+        LandingPool &g = landing_pool();
+        {
+            std::lock_guard<std::mutex> lk(g.mu);
+            if (!g.idle.empty()) {
+                p = g.idle.back();
+                g.idle.pop_back();
+            }
+        }
+        if (!p) {
+            void *q = nullptr;
+            if (hipHostMalloc(&q, LandingPool::BYTES, hipHostMallocPortable) != hipSuccess) {
+                (void)hipGetLastError();
+                q = malloc(LandingPool::BYTES);
+            }
+            p = static_cast<char *>(q);
+        }
+    }
+    void done() { keep = false; }
+    ~LandingLease() {
+        if (!p || keep) return;
+        LandingPool &g = landing_pool();
+        std::lock_guard<std::mutex> lk(g.mu);
+        g.idle.push_back(p);
+    }
+};
 } // namespace
 void d2h_landed_2d(void *dst, const void *dsrc, size_t src_pitch, size_t row_bytes, size_t rows, hipStream_t s, const char *func, const char *file, int line) {
     if (!rows || !row_bytes) return;
-    LandingArea &a = landing_area();
+    LandingLease a;
     if (!a.p) fail(SCANRS_ERR_DEVICE, "no host staging area for device-to-host copies");
-    if (row_bytes > LandingArea::BYTES) fail(SCANRS_ERR_ARGUMENT, "a row of %zu bytes does not fit the host staging area", row_bytes);
-    std::lock_guard<std::mutex> lk(a.mu);
-    const size_t rows_per = std::max<size_t>(1, LandingArea::BYTES / row_bytes);
+    if (row_bytes > LandingPool::BYTES) fail(SCANRS_ERR_ARGUMENT, "a row of %zu bytes does not fit the host staging area", row_bytes);
+    const size_t rows_per = std::max<size_t>(1, LandingPool::BYTES / row_bytes);
     for (size_t r0 = 0; r0 < rows; r0 += rows_per) {
         const size_t nr = std::min(rows_per, rows - r0);
         const char *src = static_cast<const char *>(dsrc) + r0 * src_pitch;
@@ -149,6 +174,7 @@ void d2h_landed_2d(void *dst, const void *dsrc, size_t src_pitch, size_t row_byt
         wait_stream(s, func, file, line);
         memcpy(static_cast<char *>(dst) + r0 * row_bytes, a.p, nr * row_bytes);
     }
+    a.done();
 }
 void d2h_landed(void *dst, const void *dsrc, size_t bytes, hipStream_t s, const char *func, const char *file, int line) {
     if (!bytes) return;
@@ -313,9 +339,10 @@ static bool device_ok() {
     }
     return cached == 1;
 }
-// After a timed-out wait: is the device idle again? One non-blocking question (the null stream is ordered behind every blocking stream
-// and hipDeviceSynchronize would be an unbounded wait); the library's non-blocking streams are asked one by one through their handles
-// when those are used again. Clears the flag when the legacy stream reports idle twice in a row 10 ms apart.
+// After a timed-out wait: is the device idle again? Non-blocking questions only (hipDeviceSynchronize would be an unbounded wait): the
+// null stream is ordered behind every blocking stream, and the library's own streams - the overflow gather's and the helper
+// thread's are non-blocking, the legacy stream says nothing about them - are asked one by one through the handles of
+// this process. Clears the flag when all of them report idle twice in a row 10 ms apart.
 static bool device_recovered() {
     if (!device_lost()) return true;
     for (int i = 0; i < 2; i++) {
@@ -323,6 +350,7 @@ static bool device_recovered() {
             (void)hipGetLastError();
             return false;
         }
+        if (!all_library_streams_idle()) return false;
         std::this_thread::sleep_for(std::chrono::milliseconds(10));
     }
     g_device_lost.store(false, std::memory_order_release);
@@ -388,11 +416,13 @@ struct DeadBlock {
     const Storage *owner; // the handle that was current on the releasing thread (nullptr: none)
     hipEvent_t ev[5];     // recorded at the release on every stream of the owner: work queued before the release is done when they are
     int n_ev;
+    int ev_dev;           // the device those events belong to (an event records only on streams of the device it was created on)
 };
 struct DeviceMemory {
     std::mutex mu;
     std::vector<DeadBlock> dead;                        // released by their owners, waiting for their release events
-    std::vector<hipEvent_t> release_events;             // spare events (created once, reused)
+    std::map<int, std::vector<hipEvent_t>> release_events; // spare events by device (created once, reused; ADVICE r5: one pool for all devices handed a shard thread another device's event)
+    size_t ownerless = 0;                               // entries of `dead` without an owner: they wait for a moment at which every library stream is idle
     std::map<void *, std::pair<size_t, int>> live;      // every block handed out: pointer -> (size, device)
     std::vector<Reserve> reserves;                      // blocks carved from a reserve go back into it (Reserve::give), never to the driver one by one
     std::multimap<std::pair<int, size_t>, void *> idle; // cached blocks by (device, size)
@@ -413,8 +443,9 @@ size_t round_block(size_t bytes) { return bytes >= CACHE_MIN ? (bytes + (2u << 2
 // list flushed by whoever saw its own main stream idle did not.)
 void device_free_later(void *p, size_t) {
     if (!p) return;
-    DeadBlock db{p, tl_handle, {nullptr, nullptr, nullptr, nullptr, nullptr}, 0};
+    DeadBlock db{p, tl_handle, {nullptr, nullptr, nullptr, nullptr, nullptr}, 0, 0};
     DeviceMemory &g = devmem();
+    (void)hipGetDevice(&db.ev_dev); // (the handle's streams live on the device that is current on the thread that works for it)
     if (!tl_handle && tl_dying) {
         db.owner = tl_dying; // a member of a handle that is being destroyed: its destructor has drained every stream that could name the block
     } else if (const Storage *st = tl_handle) {
@@ -424,9 +455,10 @@ void device_free_later(void *p, size_t) {
             hipEvent_t e = nullptr;
             {
                 std::lock_guard<std::mutex> lk(g.mu);
-                if (!g.release_events.empty()) {
-                    e = g.release_events.back();
-                    g.release_events.pop_back();
+                auto &pool = g.release_events[db.ev_dev];
+                if (!pool.empty()) {
+                    e = pool.back();
+                    pool.pop_back();
                 }
             }
             if ((!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) || hipEventRecord(e, q) != hipSuccess) {
@@ -439,6 +471,7 @@ void device_free_later(void *p, size_t) {
         }
     }
     std::lock_guard<std::mutex> lk(g.mu);
+    if (!db.owner) g.ownerless++;
     g.dead.push_back(db);
 }
 // every stream a handle queues work on (main, the two auxiliary ones, the overflow gather's, the helper thread's) has run dry
@@ -466,6 +499,21 @@ static void device_free_flush_impl(const Storage *owner, bool owner_gone, bool e
     DeviceMemory &g = devmem();
     if (device_lost()) return; // kernels of a timed-out call may still use them: leaked on purpose
     std::vector<Block> to_free;
+    // Blocks released while no handle was current carry no events (every reset_map + normalize cycle stranded the old map
+    // arrays until an out-of-memory retry wiped the cache). They may go once every stream of the library has been seen idle: work
+    // queued before their release is done then, work queued later cannot name them. (Asked outside the lock: the handles' own mutex.)
+    bool ownerless_done = everything;
+    if (!ownerless_done && !cache_only) {
+        bool any = false;
+        {
+            std::lock_guard<std::mutex> lk(g.mu);
+            any = g.ownerless > 0;
+        }
+        if (any) {
+            ownerless_done = hipStreamQuery(nullptr) == hipSuccess && all_library_streams_idle();
+            if (!ownerless_done) (void)hipGetLastError();
+        }
+    }
     {
         std::lock_guard<std::mutex> lk(g.mu);
         if (g.dead.empty()) return;
@@ -478,7 +526,7 @@ static void device_free_flush_impl(const Storage *owner, bool owner_gone, bool e
         for (DeadBlock &db : g.dead) {
             // done with: its release events have all completed / its owner is gone (streams drained by the destructor) / the caller has
             // just seen the whole device idle. A block released outside any handle waits for the last case.
-            bool done = everything || (owner_gone && db.owner == owner);
+            bool done = everything || (owner_gone && db.owner == owner) || (ownerless_done && db.owner == nullptr);
             if (!done && db.owner != nullptr) {
                 done = true;
                 for (int i = 0; i < db.n_ev && done; i++) {
@@ -495,8 +543,9 @@ static void device_free_flush_impl(const Storage *owner, bool owner_gone, bool e
             }
             void *p = db.p;
             auto it = g.live.find(p);
+            if (!db.owner && g.ownerless) g.ownerless--;
             if (it == g.live.end()) { // not ours (cannot happen)
-                for (int i = 0; i < db.n_ev; i++) g.release_events.push_back(db.ev[i]);
+                for (int i = 0; i < db.n_ev; i++) g.release_events[db.ev_dev].push_back(db.ev[i]);
                 continue;
             }
             const Block b{p, it->second.first, it->second.second};
@@ -507,10 +556,11 @@ static void device_free_flush_impl(const Storage *owner, bool owner_gone, bool e
             for (auto ii = g.idle.lower_bound(std::make_pair(b.dev, (size_t)0)); ii != g.idle.end() && ii->first.first == b.dev; ++ii) idle_dev += ii->first.second;
             const bool to_cache = home || (b.size >= CACHE_MIN && idle_dev + b.size <= cap);
             if (!to_cache && cache_only) { // in the middle of a call: hipFree would wait for the whole device, the block stays on the list
+                if (!db.owner) g.ownerless++;
                 keep.push_back(db);
                 continue;
             }
-            for (int i = 0; i < db.n_ev; i++) g.release_events.push_back(db.ev[i]);
+            for (int i = 0; i < db.n_ev; i++) g.release_events[db.ev_dev].push_back(db.ev[i]);
             g.live.erase(it);
             if (home) {
                 home->give(p, b.size);
@@ -542,9 +592,14 @@ void device_cache_release() noexcept {
     {
         bool idle = false;
         if (!device_lost()) {
-            const hipError_t e = poll_until([&] { return hipStreamQuery(nullptr); }, sync_timeout_s(), nullptr);
+            // (the other shard threads of a single-process multi-GPU run rarely all pause at the instant of ONE question: polled, bounded)
+            const hipError_t e = poll_until([&] {
+                const hipError_t q = hipStreamQuery(nullptr);
+                if (q != hipSuccess) return q;
+                return all_library_streams_idle() ? hipSuccess : hipErrorNotReady;
+            }, sync_timeout_s(), nullptr);
             if (e != hipSuccess) (void)hipGetLastError();
-            idle = e == hipSuccess && all_library_streams_idle();
+            idle = e == hipSuccess;
         }
         if (!idle) return;
         device_free_flush_impl(nullptr, false, true);
@@ -839,7 +894,10 @@ void Storage::side_join_if(const SparseCopy *target, bool need_layout) {
         }
     }
     if (all) { // the helper is done (or failed): take it down
-        side = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_storages_mu); // (all_library_streams_idle reads `side` under this mutex: it sees the helper's stream or nothing, never a destroyed one)
+            side = nullptr;
+        }
         if (sb->th.joinable()) sb->th.join();
         if (sb->stream) (void)hipStreamDestroy(sb->stream);
         const int code = sb->code;
@@ -853,6 +911,16 @@ void Storage::side_join_if(const SparseCopy *target, bool need_layout) {
     t_side_wait_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
 }
 Storage::~Storage() {
+    // Out of the set of handles FIRST (another thread's all_library_streams_idle walked a storage whose streams were
+    // already destroyed); while this destructor drains the streams the process counts as busy.
+    {
+        std::lock_guard<std::mutex> lk(g_storages_mu);
+        g_storages.erase(this);
+        g_storages_dying.fetch_add(1, std::memory_order_acq_rel);
+    }
+    struct Done {
+        ~Done() { g_storages_dying.fetch_sub(1, std::memory_order_acq_rel); }
+    } done_;
     if (side) {
         try {
             side_join_if(nullptr, true);
@@ -878,8 +946,6 @@ Storage::~Storage() {
         (void)wait_stream_quiet(stream);
         (void)hipStreamDestroy(stream);
     }
-    std::lock_guard<std::mutex> lk(g_storages_mu);
-    g_storages.erase(this);
 }
 // Four streams per handle: the main stream (sparse products: the persistent tile kernel must get its CUs first) at the default
 // priority, the overflow gather (fills the registers the tile kernel leaves) and the two auxiliary streams (dense work nothing
@@ -1042,7 +1108,10 @@ void prepare_second_orientation(scanrs_mat *m, bool transpose_second, bool solve
     }
     sb->order[n] = second;
     sb->want_layout[n] = second_layout;
-    st.side = sb;
+    {
+        std::lock_guard<std::mutex> lk(g_storages_mu);
+        st.side = sb;
+    }
     Storage *stp = &st;
     sb->th = std::thread([stp, sb, dev] {
         const auto t0 = std::chrono::steady_clock::now();
@@ -1477,7 +1546,10 @@ void scanrs_mat_free(scanrs_mat *m) {
     const Storage *owner = m->st.get();
     const bool last = m->st.use_count() == 1;
     tl_dying = last ? owner : nullptr;
+    const Storage *prev = tl_handle;
+    if (!last) tl_handle = owner; // a view's own buffers (map arrays, offset): release events on the storage's streams, which live on
     delete m;
+    tl_handle = prev;
     tl_dying = nullptr;
     // the handle's buffers (when this was the last view of its storage): its streams were drained by the destructor, nobody else queued work on them
     if (last) device_free_flush_owner_gone(owner);
@@ -1522,6 +1594,7 @@ int scanrs_mat_storage(const scanrs_mat *m, int *storage) {
 int scanrs_mat_reset_map(scanrs_mat *m) {
     return guard([&] {
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
+        CurrentHandle cur(m->st.get(), true); // the map's arrays and the offset go back with release events on this handle's streams (released outside any handle they were stranded)
         m->ops.clear();
         m->off_rank = 0;
         m->off_u.reset();
@@ -2153,8 +2226,10 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.tile_dense = value != 0.0;
         } else if (k == "tile_sort_slots") {
             st.tile_sort_slots = value != 0.0;
-        } else if (k == "tile_fold") {
-            st.tile_fold = value != 0.0;
+        } else if (k == "tile_wtab" || k == "tile_fold") {
+            (k == "tile_wtab" ? st.tile_wtab : st.tile_fold) = value != 0.0;
+            tile_layout_forget_weights(st.primary.tiles.get()); // (the form of the weights follows these two)
+            tile_layout_forget_weights(st.other.tiles.get());
         } else if (k == "tile_big_list_cap") {
             if (!(value >= 0.0) || value > 4.0e9) fail(SCANRS_ERR_ARGUMENT, "tile_big_list_cap must be in 0..4e9");
             st.tile_big_list_cap = (uint64_t)value;

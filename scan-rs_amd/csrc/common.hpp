@@ -166,8 +166,8 @@ struct Scratch {
         auto &b = bufs[key];
         size_t bytes = count * sizeof(T);
         if (bytes > b.n) {
-            // (an eighth more, so that a slightly larger request does not reallocate - up to 256 MB: the two 30 GB projection panels of a
-            // PCA of a 3.75 M-cell shard carried 7.5 GB of it)
+            // (an eighth more, so that a slightly larger request does not reallocate - up to 32 MB (uncapped, the two 30 GB projection panels of a
+            // PCA of a 3.75 M-cell shard carried 7.5 GB of it))
             b.alloc(bytes + std::min<size_t>(bytes / 8, (size_t)32 << 20) + 256);
             SCANRS_HIP(hipMemsetAsync(b.p, 0, b.n, stream)); // padding columns of panels start out as zeros
         }
@@ -229,6 +229,7 @@ struct MultiRow {
 // overflow matrix — what the hybrid LDS-tile + gather product walks
 struct TileLayout;
 void tile_layout_free(TileLayout *t);
+void tile_layout_forget_weights(TileLayout *t);
 void tile_layout_stats(const TileLayout *t, uint64_t out[3]); // positions per pass, served nonzeros, overflow nonzeros
 
 // A compressed orientation: n_outer vectors over n_inner positions.
@@ -341,6 +342,7 @@ struct Storage {
     int tile_dense = 1;                   // tile layout of the default shape: 1 = dense record streams, accumulators picked through VGPR index mode (round 5, tiles_dense.inc); 0 = fixed positions per (slot, visit) (round 4)
     int tile_sort_slots = 1;              // dense tile layout: slots placed in the order of their load (0: in vector order)
     int tile_emit_staged = 1;             // dense tile layout: the stream emission keeps its tables in LDS (0: searches them in global memory, the form for parts of > 4 000 tiles)
+    int tile_wtab = 1;                    // dense tile layout, folded separable map: the product kernel gathers a position's weight from the map's table by the record itself - the map evaluated inside the kernel, no weight stream (0: one f64 per position, refreshed per normalize)
     int tile_fold = 1;                    // dense tile layout, separable map: the factor of the side without the nonlinear links stays out of the per-position weights (0: both factors in every weight)
     uint64_t tile_big_list_cap = 0;       // dense tile layout, one-walk build: capacity of the list of nonzeros with counts above 255 (0: max(4 M, nnz / 64)); beyond it the two-walk build takes over
     int tile_one_walk = 1;                // dense tile layout: built in one walk over the matrix (0: count walk + fill walk; the same layout)

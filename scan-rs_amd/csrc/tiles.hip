@@ -847,13 +847,16 @@ struct TileLayout {
     DevBuf<double> w_place, w_inner; // dense, separable map: the weight's factor by place ([8] per place when the outer side owns the nonlinear links) / [8] per inner position otherwise
     bool fold_inner = false, fold_outer = false; // dense, separable map: the side without the nonlinear links keeps its factor out of the weights (tiles_dense.inc, dense_weights_kernel)
     bool separable = false;        // dense: the map's count-1 value is uo[outer] vi[inner] (tables in uo / vi / ratio_tab)
+    int wsrc = 0;                  // dense: where the product kernel takes a position's weight from - 0 the stream pw, 1 wtab by (place, count), 2 wtab by (count, inner position): the map evaluated inside the kernel (round 6)
+    DevBuf<double> wtab;           // ... the table: 16 doubles per place of every workgroup item / 192 zeros + 16 planes of wtab_stride inner positions
+    uint64_t wtab_stride = 0;
     // identity of the map the weights were evaluated under (MapOp ids are never reused); -1: none yet
     int sig_n = -1;
     uint32_t sig_id[MAX_OPS] = {};
     int sig_outer[MAX_OPS] = {};
     double bytes() const {
         return (double)prow.n * 2.0 + (double)pcnt.n + (double)pw.n * 8.0 + (double)ov.nnz * 16.0 + (double)ratio_tab.n * 8.0 + (double)drec.n * 4.0 + (double)cmeta.n * 8.0 +
-               (double)rtab.n * 4.0;
+               (double)rtab.n * 4.0 + (double)wtab.n * 8.0 + (double)(w_place.n + w_inner.n) * 8.0;
     }
     bool structure_matches(const Storage &st) const {
         if (dense != tile_dense_wanted(st)) return false;
@@ -872,6 +875,10 @@ struct TileLayout {
 };
 
 void tile_layout_free(TileLayout *t) { delete t; }
+// an option that changes the FORM of the weights (tile_fold, tile_wtab) was set: the next product evaluates them again
+void tile_layout_forget_weights(TileLayout *t) {
+    if (t) t->sig_n = -1;
+}
 // record positions the tile kernel works per pass, nonzeros among them, nonzeros left to the overflow gather (scanrs_mat_get_counter)
 void tile_layout_stats(const TileLayout *t, uint64_t out[3]) {
     out[0] = out[1] = out[2] = 0;

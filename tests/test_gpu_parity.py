@@ -734,6 +734,51 @@ def test_dense_record_layout_equals_round4_layout_and_is_placement_independent(s
             assert np.array_equal(outs[2][0], outs[4][0]) and np.array_equal(outs[2][1], outs[4][1]), (rows, cols, fill, storage)
 
 
+def test_map_evaluated_inside_the_tile_kernel_equals_the_weight_stream_and_the_oracle(sa):
+    """Round 6: under a separable map the tile kernel evaluates the map itself — a record position's weight is
+    gathered inside the round loop from a table of 16 entries by count, addressed by the record's own (slot, count) when the outer side
+    owns the logarithm ("tabo") or (ring row, count) when the inner side does ("tabi") — as `sqz/src/prod.rs:138-146` applies the
+    closure to the stored count; no per-position weight exists. Against the weight-stream form (`tile_wtab` 0) on the same layout
+    (1e-12: counts 1..8 read the same table values, 9..15 are evaluated directly there) and against the oracle (1e-10), with the
+    logarithm's scale on either axis and either storage order — which puts both table forms under both `dot` and `rdot` — counts
+    above 15 (overflow part), several parts, visits beyond a multiple of four ring turns, empty vectors, a re-normalization on the
+    same handle (the table follows the map, the records stay), and raw counts (no map: the table holds the counts)."""
+    rng = np.random.default_rng(96)
+    for rows, cols, fill, vmax in ((1, 1, 1.0, 3), (33, 97, 0.9, 2), (65, 4800, 0.6, 20), (257, 2000, 0.05, 400), (700, 1000, 0.03, 3),
+                                   (97, 20000, 0.02, 17), (2000, 193, 0.2, 300), (300, 400, 0.004, 2), (130, 9000, 0.3, 3), (520, 3000, 0.9, 5)):
+        dense = random_counts(rng, rows, cols, fill, vmax)
+        dense[rng.random(rows) < 0.2, :] = 0
+        dense[0, 0] = 1
+        q = np.cos(np.arange(cols * 40, dtype=np.float64)).reshape(cols, 40)
+        ql = np.sin(np.arange(rows * 24, dtype=np.float64)).reshape(24, rows)
+        for storage in (so.CSR, so.CSC):
+            for log_axis in (0, 1, None):
+                hs = []
+                for wtab in (1, 0):
+                    g, o = pair(sa, dense, storage)
+                    g.set_spmm_path(3).set_option("tile_wtab", wtab).set_option("tile_split_min", 0.3)
+                    hs.append(g)
+                fa, fb = np.linspace(0.5, 1.5, cols if log_axis == 1 else rows), np.linspace(0.7, 1.3, rows if log_axis == 1 else cols)
+                if log_axis is not None:
+                    for g in hs:
+                        g.compose_scale_axis(log_axis, fa).apply(sa.FN_LOG2_1P).compose_scale_axis(1 - log_axis, fb)
+                    o = o.compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=log_axis, a=fa)).apply(so.OP_LOG2_1P).compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=1 - log_axis, a=fb))
+                outs = [(g.dot(q), g.rdot(ql)) for g in hs]
+                ref = (o.dot(q), o.rdot(ql))
+                for k in (0, 1):
+                    assert_close(outs[0][k], ref[k], rtol=1e-10, atol=1e-9)
+                    assert_close(outs[0][k], outs[1][k], rtol=1e-12, atol=1e-11)
+                assert np.array_equal(outs[0][0], hs[0].dot(q)) and np.array_equal(outs[0][1], hs[0].rdot(ql))  # repeatable
+                if log_axis == 1:  # another map on the same handles: only the table is rewritten
+                    for g in hs:
+                        g.reset_map()
+                        g.compose_scale_axis(1, fa[::-1].copy()).apply(sa.FN_LN_1P)
+                    o2 = pair(sa, dense, storage)[1].compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=1, a=fa[::-1].copy())).apply(so.OP_LN_1P)
+                    a, b = hs[0].dot(q), hs[1].dot(q)
+                    assert_close(a, o2.dot(q), rtol=1e-10, atol=1e-9)
+                    assert_close(a, b, rtol=1e-12, atol=1e-11)
+
+
 def test_invalid_sparse_input_is_refused(sa):
     """create validates on the device in two streaming passes (round 4): indices ascending inside a vector — a descent at the first
     nonzero of a vector is fine — and in range, indptr not decreasing; the reference panics on such input (sprs structure checks)."""
@@ -1433,6 +1478,32 @@ def test_device_memory_cache_reserve_and_accounting(sa):
     gc.collect()
     assert sa.cached_memory_bytes() == 0
     sa.set_global_option("device_cache_fraction", 0.5)
+
+
+def test_renormalizing_a_live_handle_strands_no_device_memory(sa):
+    """`scanrs_mat_reset_map` and the free of a non-last view released the map's arrays and the offset while no handle was
+    current — such blocks carried no release events and were only retired by a whole-device release, so every reset_map + normalize
+    cycle on a live handle grew the library's count of live device memory (bench.py's resident bytes) by the old map. Now they go back
+    with release events on the handle's streams (and ownerless blocks at the next moment every stream is idle): the count is flat."""
+    import gc
+
+    m = _synth(40_000, 3000, 0.05, 4)
+    g = sa.AdaptiveMat.from_csmat(m.shape[1], m.shape[0], sa.CSC, m.indptr, m.indices, m.data)
+    x = np.ones((m.shape[0], 4))
+    marks = []
+    for cycle in range(6):
+        g.reset_map()
+        sa.normalize(g, sa.Normalization.CellRanger)
+        v = g.view()  # a view with a map of its own, dropped while the storage lives on
+        v.reset_map()
+        sa.log_normalize_with_size_factor(v, None, sa.FN_LN_1P)
+        v.dot(x)
+        del v
+        gc.collect()
+        g.dot(x)
+        g.sync()
+        marks.append(sa.device_memory_in_use())
+    assert max(marks[2:]) == min(marks[2:]), marks  # (the first cycles may still grow scratch buffers)
 
 
 def test_helper_thread_build_gives_the_same_result(sa):

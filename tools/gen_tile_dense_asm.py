@@ -27,6 +27,18 @@ read with v_readfirstlane_b32):
   s28 header of the current round (7:0 chunks, bit 8 = first round of a visit), s29 its chunk count, s34 / s101 / s12 the next
   three headers, s100 chunks of the next round, s30 / s[32:33] scratch (s[32:33]: where the next round's chunk slots come from)
   (stamp build: s[2:9] time stamps and sums, s[10:11] saved EXEC)
+
+GEN_WSRC=tabo / tabi (round 6): the map is evaluated INSIDE the kernel - no weight stream. A position's weight is one entry of a table the
+normalize refreshes (16 doubles per place of the layout when the outer side owns the map's nonlinear links, "tabo"; 16 planes over the
+inner positions otherwise, "tabi"; entry 0 = 0.0 for null records, counts above 15 live in the overflow part), gathered by the
+record's own (slot, count) or (ring row, count). Per round ONE vector load of the 64 records of the round after next (lane L = record
+L of its four chunk slots; it also pulls them into L2 for the scalar loads, the stream form's "touch"), ONE 64-lane gather of the next
+round's weights (lane L = weight of position L), and at the round's start the gathered register pair is spread into the form the
+FMAs read (every row of 16 lanes = one chunk's 16 weights) by v_permlane16_swap / v_permlane32_swap (gfx950), no LDS involved:
+  v[26:27]    the NEXT round's weights as gathered (lane L: position L); v28 the records of the round after next (lane L: record L)
+  v[29:31]    address arithmetic; v32 tabi: 8 x plane stride; v33 4 x lane; v35 tabi: -1536 (one ring of 192 rows back, in bytes)
+  v[38:39]    the table's base for this wave (tabo: the 32 places of its group; tabi: plane 0)
+  s31         tabi: visit index of the current round (the staging code derives tile bytes - 1024 where it needs it)
 """
 import os
 import sys
@@ -36,9 +48,13 @@ STAMP = bool(os.environ.get("GEN_STAMP"))  # diagnostic build: s_memtime stamps 
 SKIP = set((os.environ.get("GEN_SKIP") or "").split(","))  # timing experiments (wrong results): w = weights, r = records, b = barrier, d = staging, p = weight spreading (ds_bpermute)
 
 PRE = (os.environ.get("GEN_PRE") or "0") != "0"  # experiment (slower by 0.3 ms per pass, profiles/HISTORY.md): the row reads of a round's first two batches are issued at the boundary in front of it (0: in the round's prologue)
+WSRC = os.environ.get("GEN_WSRC") or "stream"  # where a position's weight comes from: stream = one f64 per position (pw, refreshed per normalize); tabo / tabi = gathered from the map's table by the record itself (see above)
+TAB = WSRC in ("tabo", "tabi")
+assert WSRC in ("stream", "tabo", "tabi")
 WDIRECT = (os.environ.get("GEN_WDIRECT") or "1") != "0"  # a round's weights are loaded in the form the FMAs read (lane L: weight L % 16 of each chunk: four loads); 0: one load + eight ds_bpermute_b32
 DMA_TOP = (os.environ.get("GEN_DMA") or "tail") == "top"  # staging loads at the round's start instead of in its last batches
 BP = int(os.environ.get("GEN_BP") or 4)   # positions per batch (two batches of row reads in flight); 8 is as fast but takes 40 registers more
+assert not TAB or (WDIRECT and not PRE and not DMA_TOP and BP == 4)
 NB = 64 // BP     # batches per round
 BPC = 16 // BP    # batches per chunk
 ACC0 = 88
@@ -101,7 +117,11 @@ def dma(i, out):
         out.append("s_nop 0")
         return
     out.append(f"s_add_u32 s30, s17, {i * 8192}")
-    out.append("s_min_u32 s30, s30, s31")
+    if TAB:
+        out.append("s_sub_u32 vcc_lo, s27, 0x400")
+        out.append("s_min_u32 s30, s30, vcc_lo")
+    else:
+        out.append("s_min_u32 s30, s30, s31")
     out.append("s_add_u32 m0, s30, s35")
     if WDIRECT:
         # (the chunk's offset goes into the scalar base - VCC is free between two rounds' tops - and every chunk uses the one lane offset v34:
@@ -117,6 +137,65 @@ def dma(i, out):
 def reload_slot(c, out):
     """records of chunk slot c for the NEXT round (s[32:33]: 256 bytes in front of its last record's end)"""
     out.append(f"s_load_dwordx16 s[{R0 + 16 * c}:{R0 + 16 * c + 15}], s[32:33], {hex(64 * c)}")
+
+
+def tab_gather(out, next_round):
+    """v[26:27] <- the table entries of the 64 records in v28 (lane L: record L of a round's four chunk slots).
+    tabo: byte offset = slot x 128 + count x 8 inside the wave's 4 KB of the place table (16 doubles per place).
+    tabi: entry = plane count, inner position = ring row + 192 q - (192 if the row's buffer index lies above m), with u' = visit - 1,
+    q = u' / 4, m = u' % 4: the record's tile is the latest one at or below u' that sits in its ring buffer (the tiles a visit reads are
+    u' and u' - 1). The compare works on the whole record (ring row = its upper half), row x 8 = record >> 13 (counts stay below 32).
+    next_round: the visit is the NEXT round's (s31 + bit 8 of its header s34); else the current one (entry: round 0)."""
+    a = out.append
+    if WSRC == "tabo":
+        a("v_and_b32 v30, 0xfc, v28")               # 4 x slot
+        a("v_bfe_u32 v29, v28, 8, 8")               # count
+        a("v_lshlrev_b32 v29, 3, v29")
+        a("v_lshl_add_u32 v30, v30, 5, v29")        # slot x 128 + count x 8
+    else:
+        if next_round:
+            a("s_bfe_u32 s30, s34, 0x10008")        # the next round opens a visit?
+            a("s_add_u32 s30, s31, s30")
+        else:
+            a("s_mov_b32 s30, s31")
+        a("s_max_u32 s30, s30, 1")
+        a("s_sub_u32 s30, s30, 1")                  # u' (a part's first visit has no records: clamped)
+        a("s_lshr_b32 m0, s30, 2")
+        a("s_mul_i32 m0, m0, 0x600")                # 192 q rows, in bytes
+        a("s_and_b32 s30, s30, 3")
+        a("s_add_u32 s30, s30, 1")
+        a("s_mul_i32 s30, s30, 0x300000")           # 48 (m + 1) << 16: first ring row of the buffers above m, as a record
+        a("v_bfe_u32 v29, v28, 8, 8")               # count
+        a("v_mul_lo_u32 v29, v29, v32")             # plane
+        a("v_lshrrev_b32 v30, 13, v28")             # ring row x 8
+        a("v_cmp_le_u32 vcc, s30, v28")
+        a("v_cndmask_b32 v31, 0, v35, vcc")         # -1536: the buffer holds a tile of the ring's previous turn
+        a("v_add3_u32 v30, v30, v29, v31")
+        a("v_add_u32 v30, m0, v30")
+    a("v_add_co_u32 v30, vcc, v38, v30")            # (address pairs are even-aligned on gfx90a and later)
+    a("v_addc_co_u32 v31, vcc, 0, v39, vcc")
+    a("global_load_dwordx2 v[26:27], v[30:31], off")
+
+
+def tab_spread(out):
+    """v[26:27] (lane L = weight of position L: row c of 16 lanes = chunk slot c) -> v[40 + 2 c : 41 + 2 c] = chunk c's row in all four
+    rows. v_permlane16_swap a, b: a's odd rows <-> b's even rows; v_permlane32_swap a, b: a's upper half <-> b's lower half.
+    [r0 r1 r2 r3] x 2 -> [r0 r0 r2 r2], [r1 r1 r3 r3] -> copies -> [r0 x 4], [r2 x 4], [r1 x 4], [r3 x 4]. A swap may not read a
+    register a vector instruction wrote in the two instructions in front of it (check_swap_hazards)."""
+    a = out.append
+    w = lambda c, h: f"v{W0 + 2 * c + h}"
+    for h in (0, 1):
+        a(f"v_mov_b32 {w(0, h)}, v{26 + h}")
+        a(f"v_mov_b32 {w(1, h)}, v{26 + h}")
+    a(f"v_permlane16_swap_b32 {w(0, 0)}, {w(1, 0)}")
+    a("s_nop 0")
+    a(f"v_permlane16_swap_b32 {w(0, 1)}, {w(1, 1)}")
+    for h in (0, 1):
+        a(f"v_mov_b32 {w(2, h)}, {w(0, h)}")
+        a(f"v_mov_b32 {w(3, h)}, {w(1, h)}")
+    for h in (0, 1):
+        a(f"v_permlane32_swap_b32 {w(0, h)}, {w(2, h)}")
+        a(f"v_permlane32_swap_b32 {w(1, h)}, {w(3, h)}")
 
 
 def gen():
@@ -146,14 +225,28 @@ def gen():
     a("v_readfirstlane_b32 s26, %[nrounds]")  # (uniform values handed over in vector registers: the compiler has few scalar ones left for operands)
     a("v_readfirstlane_b32 s27, %[rowb]")
     a("s_mul_i32 s27, s27, 48")  # bytes of a tile of 48 rows
-    a("v_readfirstlane_b32 s35, %[dst]")  # (uniform values handed over in vector registers: the compiler has few scalar ones left for operands)
+    if TAB:
+        a("v_readfirstlane_b32 s31, %[t0]")  # first visit of the item (tabi: the visit counter); the ring buffer of its first tile follows from it
+    else:
+        a("v_readfirstlane_b32 s35, %[dst]")  # (uniform values handed over in vector registers: the compiler has few scalar ones left for operands)
     a("v_readfirstlane_b32 s17, %[wave10]")  # (uniform values handed over in vector registers: the compiler has few scalar ones left for operands)
     a("v_readfirstlane_b32 s18, %[lds0]")  # (uniform values handed over in vector registers: the compiler has few scalar ones left for operands)
     a("s_lshl_b32 s19, s27, 2")
     a("s_add_u32 s19, s19, s18")
-    a("s_sub_u32 s31, s27, 0x400")
-    a("v_mov_b32 v38, %[pwlo]")
-    a("v_mov_b32 v39, %[pwhi]")
+    if TAB:
+        a("s_and_b32 s30, s31, 3")
+        a("s_mul_i32 s30, s30, s27")
+        a("s_add_u32 s35, s18, s30")
+        a("v_mov_b32 v38, %[tablo]")
+        a("v_mov_b32 v39, %[tabhi]")
+        a("v_mov_b32 v33, %[lane4]")
+        if WSRC == "tabi":
+            a("v_mov_b32 v32, %[stride8]")
+            a("v_mov_b32 v35, 0xfffffa00")
+    else:
+        a("s_sub_u32 s31, s27, 0x400")
+        a("v_mov_b32 v38, %[pwlo]")
+        a("v_mov_b32 v39, %[pwhi]")
     a("v_mov_b32 v36, %[ring]")
     a("v_mov_b32 v37, %[rowb]")
     if WDIRECT:
@@ -187,13 +280,26 @@ def gen():
     a("s_subb_u32 s33, s21, 0")
     for c in range(4):
         reload_slot(c, o)
-    a("s_lshl_b32 s30, s29, 7")
-    a("v_add_co_u32 v38, vcc, s30, v38")
-    a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
-    if WDIRECT:
+    if TAB:
+        a("global_load_dword v28, v33, s[32:33]")   # the records of round 0, lane L = record L of its four chunk slots
+        a("s_waitcnt vmcnt(0)")
+        tab_gather(o, next_round=False)             # weights of round 0
+        a("s_and_b32 s100, s34, 0xff")
+        a("s_lshl_b32 s30, s100, 6")
+        a("s_add_u32 vcc_lo, s32, s30")
+        a("s_addc_u32 vcc_hi, s33, 0")
+        a("s_nop 3")                                # (a vector write of VCC five wait states in front of a vector-memory read of it)
+        a("global_load_dword v28, v33, vcc")        # the records of round 1
+    elif WDIRECT:
+        a("s_lshl_b32 s30, s29, 7")
+        a("v_add_co_u32 v38, vcc, s30, v38")
+        a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
         for c in range(4):
             a(f"global_load_dwordx2 v[{26 + 2 * c}:{27 + 2 * c}], v[38:39], off offset:{-512 + 128 * c}")  # weights of round 0
     else:
+        a("s_lshl_b32 s30, s29, 7")
+        a("v_add_co_u32 v38, vcc, s30, v38")
+        a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
         a("global_load_dwordx2 v[26:27], v[38:39], off offset:-512")  # weights of round 0
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")           # ... and the item's first tile (staged by the caller)
     if not PRE:
@@ -219,6 +325,20 @@ def gen():
     def top():
         """what a round starts for the rounds behind it: the next round's weights, the touch of the records two rounds ahead, the header three ahead"""
         a("s_and_b32 s100, s34, 0xff")               # chunks of the next round
+        if TAB:
+            a("s_lshl_b32 s30, s100, 6")                 # where the next round's four chunk slots come from
+            a("s_add_u32 s32, s20, s30")
+            a("s_addc_u32 s33, s21, 0")
+            a("s_sub_u32 s32, s32, 0x100")
+            a("s_subb_u32 s33, s33, 0")
+            tab_gather(o, next_round=True)               # the next round's weights, by its records (loaded a round ago)
+            a("s_and_b32 s30, s101, 0xff")               # ... and the records of the round after it: its four chunk slots end 64 x its chunks further on
+            a("s_lshl_b32 s30, s30, 6")
+            a("s_load_dword s12, s[22:23], 0xc")         # header three rounds ahead
+            a("s_add_u32 vcc_lo, s32, s30")
+            a("s_addc_u32 vcc_hi, s33, 0")
+            a("global_load_dword v28, v33, vcc")         # (this load is also what pulls those records into L2 for their scalar loads: the stream form's touch)
+            return
         a("s_lshl_b32 s30, s100, 7")
         a("v_add_co_u32 v38, vcc, s30, v38")         # behind the next round's weights
         a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
@@ -259,6 +379,9 @@ def gen():
         a("s_load_dword s12, s[22:23], 0xc")         # header three rounds ahead
 
     def spread_weights():
+        if TAB:
+            tab_spread(o)
+            return
         if WDIRECT:
             for i_ in range(8):
                 a(f"v_mov_b32 v{W0 + i_}, v{26 + i_}")   # (vector moves: more than the two wait states a DPP read of them needs lie before the first FMA)
@@ -295,6 +418,9 @@ def gen():
 
     def rotate():
         a("s_waitcnt lgkmcnt(0)")                    # the next round's records and the header
+        if WSRC == "tabi":
+            a("s_bfe_u32 s30, s34, 0x10008")         # the visit counter follows the round that becomes current
+            a("s_add_u32 s31, s31, s30")
         a("s_mov_b32 s28, s34")
         a("s_mov_b32 s34, s101")
         a("s_mov_b32 s101, s12")
@@ -497,11 +623,36 @@ def check_dpp_hazards(lines):
                 raise SystemExit(f"DPP hazard: '{prev}' writes a source of '{ln}' {back} instruction(s) earlier")
 
 
+def check_swap_hazards(lines):
+    """gfx950: v_permlane16_swap_b32 / v_permlane32_swap_b32 read (and write) both operands; a vector-ALU write of either needs two wait
+    states before the swap (the compiler puts s_nop 1 there; it does not look into an asm statement)."""
+    import re
+
+    insts = [ln for ln in lines if not ln.endswith(":")]
+    for i, ln in enumerate(insts):
+        if not ln.startswith("v_permlane"):
+            continue
+        ops = {t.strip() for t in ln.split(None, 1)[1].split(",")}
+        states = 0
+        for back in range(1, 4):
+            if i - back < 0 or states >= 2:
+                break
+            prev = insts[i - back]
+            m = re.fullmatch(r"s_nop (\d+)", prev)
+            if prev.startswith("v_") and not prev.startswith("v_readfirstlane"):
+                dst = {t.strip() for t in prev.split(None, 1)[1].split(",")[: 2 if prev.startswith("v_permlane") else 1]}
+                if dst & ops:
+                    raise SystemExit(f"swap hazard: '{prev}' writes an operand of '{ln}' {states} wait state(s) earlier")
+            states += 1 + (int(m.group(1)) if m else 0)
+
+
 def main():
     lines = gen()
     check_dpp_hazards(lines)
+    check_swap_hazards(lines)
     here = os.path.dirname(os.path.abspath(__file__))
-    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "scan-rs_amd", "csrc", "tile_dense_body.inc")
+    name = "tile_dense_body.inc" if WSRC == "stream" else f"tile_dense_body_{WSRC}.inc"
+    path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "scan-rs_amd", "csrc", name)
     with open(path, "w") as f:
         f.write("// generated by tools/gen_tile_dense_asm.py - do not edit\n")
         for ln in lines:

@@ -1,6 +1,7 @@
 """Time of one sparse pass (b-wide product) in both orientations under the CellRanger map (scale, log2, centre / scale),
 for a list of product configurations: `path[:tile_k:tile_s:tile_t:tile_b:overlap]`, e.g. `0 3:2:32:48:4` (0 = default,
-2 = L2-blocked gather, 3 = hybrid LDS tiles + gather). usage: pass_bench.py [cells] [l] config..."""
+2 = L2-blocked gather, 3 = hybrid LDS tiles + gather); a configuration may carry handle options of its own behind slashes,
+`0/tile_wtab=0` (A/B in one process, results compared with the first configuration's). usage: pass_bench.py [cells] [l] config..."""
 import os
 import sys
 import time
@@ -14,9 +15,9 @@ from scanrs_amd.synth import synth_counts_torch
 
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 genes, l = 33_000, int(sys.argv[2]) if len(sys.argv) > 2 else 100
-kw = {k: float(v) for k, v in (a.split("=") for a in sys.argv[3:] if "=" in a and not a.startswith("opt."))}  # gene_shape=0.1 shared_profile=1: a heavy-tailed model
+kw = {k: float(v) for k, v in (a.split("=") for a in sys.argv[3:] if "=" in a and "/" not in a and not a.startswith("opt."))}  # gene_shape=0.1 shared_profile=1: a heavy-tailed model
 opts = {k[4:]: float(v) for k, v in (a.split("=") for a in sys.argv[3:] if a.startswith("opt."))}  # opt.tile_split_x=1.7: handle options
-configs = [a for a in sys.argv[3:] if "=" not in a] or ["0"]
+configs = [a for a in sys.argv[3:] if "=" not in a or "/" in a] or ["0"]
 dev = torch.device("cuda", 0)
 ip, ix, vv = synth_counts_torch(cells, genes, 0.03, 0, dev, **kw)
 if kw:
@@ -31,12 +32,13 @@ oc = torch.zeros(cells, l, device=dev, dtype=torch.float64)
 ref = {}
 
 for cfg in configs:
-    parts = [int(x) for x in cfg.split(":")]
+    own = {k: float(v) for k, v in (a.split("=") for a in cfg.split("/")[1:])}
+    parts = [int(x) for x in cfg.split("/")[0].split(":")]
     m = sa.AdaptiveMat.from_device(genes, cells, sa.CSC, ip.data_ptr(), ix.data_ptr(), vv.data_ptr())
     m.set_spmm_path(parts[0])
     for key, val in zip(("tile_k", "tile_s", "tile_t", "tile_b", "tile_overlap", "tile_ku", "ov_tile_kb"), parts[1:]):
         m.set_option(key, val)
-    for key, val in opts.items():
+    for key, val in {**opts, **own}.items():
         m.set_option(key, val)
     sa.normalize(m, sa.Normalization.CellRanger)
 
@@ -69,6 +71,6 @@ for cfg in configs:
     m.sync()
     prof = "; ".join(f"{name} x{st['launches']} {st['total_ms']:.2f} ms" for name, st in m.profile_get().items() if st["total_ms"] > 0.3)
     m.profile_enable(False)
-    print(f"{cfg:10s} gene-major pass {a:7.2f} ms ({a*1e6*256/nnz:5.2f} ns/nnz/CU, first call {fa:7.1f} ms)   "
+    print(f"{cfg:14s} gene-major pass {a:7.2f} ms ({a*1e6*256/nnz:5.2f} ns/nnz/CU, first call {fa:7.1f} ms)   "
           f"cell-major pass {b:7.2f} ms ({b*1e6*256/nnz:5.2f} ns/nnz/CU, first call {fb:7.1f} ms){err}\n           {prof}", flush=True)
     del m
