@@ -83,7 +83,7 @@ def parse():
     ap.add_argument("--no-reserve", action="store_true", help="do not reserve device memory ahead of the handle (scanrs_reserve_device_memory)")
     ap.add_argument("--reserve-bytes-per-nnz", type=float, default=None,
                     help="size of that reserve per nonzero of the shard (+ 1 GB). Default: computed from what the handle keeps after its first PCA - per nonzero "
-                         "both copies of the matrix 16 B, both tile layouts 2 x 13.2 B, 4 B of small change; per cell the solver's two projection panels "
+                         "both copies of the matrix 16 B, both tile layouts 2 x 4.7 B (records only: the map is evaluated inside the kernel since round 6), 2 B of small change; per cell the solver's two projection panels "
                          "(2 x 8 B x 2 k n_iter) and six b-wide panels - with the builds' temporaries in the room the panels take later")
     ap.add_argument("--no-heavy-tailed", action="store_true", help="skip the second, clearly labelled measurement on the heavy-tailed gene profile")
     ap.add_argument("--no-host-delivery", action="store_true", help="leave U and V in HBM in every step (value is then the device-resident rate)")
@@ -314,7 +314,7 @@ def main():
             reserve_bytes = int(args.reserve_bytes_per_nnz * nnz_local)
         else:
             b_cols = 2 * args.k  # BkSvd: k_multiplier 2, n_iter 5
-            reserve_bytes = int(46.5 * nnz_local) + n_local * (2 * 8 * b_cols * 5 + 6 * 8 * b_cols)
+            reserve_bytes = int(27.5 * nnz_local) + n_local * (2 * 8 * b_cols * 5 + 6 * 8 * b_cols)
         sa.reserve_device_memory(reserve_bytes + (1 << 30))
     t_reserve = time.perf_counter() - t_r
     # genes x cells (Cell Ranger orientation), stored cell-major = CSC

@@ -50,6 +50,10 @@ SKIP = set((os.environ.get("GEN_SKIP") or "").split(","))  # timing experiments 
 PRE = (os.environ.get("GEN_PRE") or "0") != "0"  # experiment (slower by 0.3 ms per pass, profiles/HISTORY.md): the row reads of a round's first two batches are issued at the boundary in front of it (0: in the round's prologue)
 WSRC = os.environ.get("GEN_WSRC") or "stream"  # where a position's weight comes from: stream = one f64 per position (pw, refreshed per normalize); tabo / tabi = gathered from the map's table by the record itself (see above)
 TAB = WSRC in ("tabo", "tabi")
+SYNC = os.environ.get("GEN_SYNC") or "bar"  # how the 8 waves of an item hand ring buffers to one another: bar = one s_barrier per visit; cnt = readiness / release counters in LDS (table forms only, see sync_* below)
+CNT = SYNC == "cnt"
+assert SYNC in ("bar", "cnt") and (not CNT or WSRC in ("tabo", "tabi"))
+SPIN_MAX = int(os.environ.get("GEN_SPIN_MAX") or (1 << 22))  # polls of a counter before a wave gives up waiting (no hang on a bug: the result is then wrong and the parity tests say so)
 assert WSRC in ("stream", "tabo", "tabi")
 WDIRECT = (os.environ.get("GEN_WDIRECT") or "1") != "0"  # a round's weights are loaded in the form the FMAs read (lane L: weight L % 16 of each chunk: four loads); 0: one load + eight ds_bpermute_b32
 DMA_TOP = (os.environ.get("GEN_DMA") or "tail") == "top"  # staging loads at the round's start instead of in its last batches
@@ -137,6 +141,56 @@ def dma(i, out):
 def reload_slot(c, out):
     """records of chunk slot c for the NEXT round (s[32:33]: 256 bytes in front of its last record's end)"""
     out.append(f"s_load_dwordx16 s[{R0 + 16 * c}:{R0 + 16 * c + 15}], s[32:33], {hex(64 * c)}")
+
+
+# ---- ring hand-over by counters (GEN_SYNC=cnt) -------------------------------------------------------------------------------
+# One s_barrier per visit makes the 8 waves of an item wait for the slowest at every tile (420 clk of a round's 2 780, lopsided: the
+# older wave of a SIMD wins every issue conflict, arrives early and waits while its partner runs alone). What the barrier orders is
+# narrower: (1) a tile staged by all 8 waves during visit v - 1 may be read from visit v + 1 on; (2) the buffer of tile v - 3 may be
+# overwritten (tile v + 1, during visit v) once all 8 waves have finished visit v - 1. Two arrays of four counters behind the ring:
+#   ready[b] += 1 by a wave when its share of the tile in buffer b has landed (certified by the counted vmcnt wait of the boundary
+#               one round after the staging round - never a wait for a load of the round it closes);
+#   done[b]  += 1 by a wave when it has finished a visit v with (v - 2) % 4 == b (its last read of that tile has returned).
+# The counters only grow; the item's prologue presets them as if every visit before the part's first had happened, so the thresholds
+# do not depend on the part: entering visit v a wave needs ready[(v - 1) % 4] >= 8 ((v - 1) / 4 + 1); before its staging loads of
+# visit v it needs done[(v + 1) % 4] >= 8 ((v - 1) / 4 + 1). A wave can run ahead of the slowest by about a round; both polls are
+# issued early (their LDS round trip runs beside other work) and re-polled with s_sleep only when the early value falls short.
+# Staging happens in the FIRST round of a visit only (the barrier form re-stages the same tile in every round of a visit so that one
+# vmcnt count fits all boundaries).
+CNT_READY = 0x400   # byte offsets behind the ring's end (s19): ready[4]; the row of zeros sits in the first KB
+CNT_DONE = 0x410
+
+
+def sync_signal(out, addr_s):
+    """one lane adds 1 to the counter at LDS address `addr_s` (v29 / v30: free between a round's top and the next)"""
+    a = out.append
+    a(f"v_mov_b32 v29, {addr_s}")
+    a("v_mov_b32 v30, 1")
+    a("s_mov_b64 exec, 1")
+    a("ds_add_u32 v29, v30")
+    a("s_mov_b64 exec, -1")
+
+
+def sync_wait(out, tag, addr_s, thr_s, early_reg=None):
+    """until counter[addr_s] >= thr_s. early_reg: a register that already holds a value read earlier (its ds_read has returned)"""
+    a = out.append
+    if early_reg:
+        a(f"v_readfirstlane_b32 s13, {early_reg}")
+        a(f"s_cmp_ge_u32 s13, {thr_s}")
+        a(f"s_cbranch_scc1 LW{tag}OK%=")
+    a(f"v_mov_b32 v29, {addr_s}")
+    a(f"s_mov_b32 vcc_hi, {SPIN_MAX}")
+    a(f"LW{tag}%=:")
+    a("ds_read_b32 v30, v29")
+    a("s_waitcnt lgkmcnt(0)")
+    a("v_readfirstlane_b32 s13, v30")  # (s13: a copy register of the last batch, free everywhere else)
+    a(f"s_cmp_ge_u32 s13, {thr_s}")
+    a(f"s_cbranch_scc1 LW{tag}OK%=")
+    a("s_sleep 1")
+    a("s_sub_u32 vcc_hi, vcc_hi, 1")
+    a("s_cmp_eq_u32 vcc_hi, 0")
+    a(f"s_cbranch_scc0 LW{tag}%=")
+    a(f"LW{tag}OK%=:")
 
 
 def tab_gather(out, next_round):
@@ -301,20 +355,50 @@ def gen():
         a("v_add_co_u32 v38, vcc, s30, v38")
         a("v_addc_co_u32 v39, vcc, 0, v39, vcc")
         a("global_load_dwordx2 v[26:27], v[38:39], off offset:-512")  # weights of round 0
+    if CNT:
+        # The ring's hand-over counters, preset by wave 0 as if every visit before the item's first (t0) had happened, so that the
+        # thresholds do not depend on the part: lanes 0-3 ready[b] = 8 x tiles below t0 that live in buffer b (+ 8 for tile t0 itself:
+        # staged by the caller, certified by the wait and the barrier below), lanes 4-7 done[b] = 8 x visits v below t0 with
+        # (v - 2) % 4 == b. tiles / visits below t0 congruent to c modulo 4: (t0 + 3 - c) / 4.
+        a("s_cmp_eq_u32 s17, 0")
+        a("s_cbranch_scc0 LINITX%=")
+        a("v_mbcnt_lo_u32_b32 v29, -1, 0")
+        a("v_mbcnt_hi_u32_b32 v29, -1, v29")         # lane
+        a("v_and_b32 v30, 3, v29")                   # b
+        a("v_add_u32 v31, 2, v30")
+        a("v_and_b32 v31, 3, v31")                   # (b + 2) % 4
+        a("v_cmp_gt_u32 vcc, 4, v29")
+        a("v_cndmask_b32 v31, v31, v30, vcc")        # c = b for the ready counters, (b + 2) % 4 for the done counters
+        a("s_add_u32 s30, s31, 3")
+        a("v_sub_u32 v31, s30, v31")
+        a("v_lshrrev_b32 v31, 2, v31")
+        a("s_and_b32 s30, s31, 3")
+        a("v_cmp_eq_u32 vcc, s30, v29")              # the ready counter of tile t0's buffer (lanes 4-7 never match: t0 % 4 < 4)
+        a("v_addc_co_u32 v31, vcc, 0, v31, vcc")
+        a("v_lshlrev_b32 v31, 3, v31")
+        a("v_lshlrev_b32 v29, 2, v29")
+        a(f"s_add_u32 s30, s19, {CNT_READY}")
+        a("v_add_u32 v29, s30, v29")
+        a("s_mov_b64 exec, 0xff")
+        a("ds_write_b32 v29, v31")
+        a("s_mov_b64 exec, -1")
+        a("LINITX%=:")
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")           # ... and the item's first tile (staged by the caller)
     if not PRE:
         if "b" not in SKIP:
-            a("s_barrier")                            # round 0 is the first of its visit
+            a("s_barrier")                            # round 0 is the first of its visit (the counter form keeps this one: it publishes the item's preset counters)
         a("s_add_u32 s24, s24, s27")
         a("s_addc_u32 s25, s25, 0")
         a("s_add_u32 s35, s35, s27")
         a("s_cmp_eq_u32 s35, s19")
         a("s_cselect_b32 s35, s18, s35")
+        if CNT:
+            a("s_mov_b32 s29, 0")                     # s29: the ready counter this wave bumps at the next boundary (0: none). The round's chunk count is taken from its header where needed
     else:
         a("s_branch LENTER%=")                        # round 0 is the first of its visit: barrier, then its first row reads
 
     def advance():
-        if "b" not in SKIP:
+        if "b" not in SKIP and not CNT:
             a("s_barrier")
         a("s_add_u32 s24, s24, s27")
         a("s_addc_u32 s25, s25, 0")
@@ -338,6 +422,17 @@ def gen():
             a("s_add_u32 vcc_lo, s32, s30")
             a("s_addc_u32 vcc_hi, s33, 0")
             a("global_load_dword v28, v33, vcc")         # (this load is also what pulls those records into L2 for their scalar loads: the stream form's touch)
+            if CNT:
+                # first round of a visit: it will stage tile v + 1 over tile v - 3 - the release counter of that buffer, read now, is in v29 when the staging block asks
+                a("s_bitcmp1_b32 s28, 8")
+                a("s_cbranch_scc0 LT2%=")
+                a("s_add_u32 s30, s31, 1")
+                a("s_and_b32 s30, s30, 3")
+                a("s_lshl_b32 s30, s30, 2")
+                a("s_add_u32 s30, s30, s19")
+                a("v_mov_b32 v29, s30")
+                a(f"ds_read_b32 v29, v29 offset:{CNT_DONE}")
+                a("LT2%=:")
             return
         a("s_lshl_b32 s30, s100, 7")
         a("v_add_co_u32 v38, vcc, s30, v38")         # behind the next round's weights
@@ -394,6 +489,27 @@ def gen():
             a(f"ds_bpermute_b32 v{W0 + 2 * c}, v30, v28 offset:{64 * c}")
             a(f"ds_bpermute_b32 v{W0 + 2 * c + 1}, v30, v29 offset:{64 * c}")
 
+    def stage_block(tag):
+        """counter form: the five staging loads of a visit, in its first round only, once the buffer's last readers are through"""
+        a("s_bitcmp1_b32 s28, 8")
+        a(f"s_cbranch_scc0 LSTX{tag}%=")
+        a("s_max_u32 s30, s31, 1")
+        a("s_sub_u32 s30, s30, 1")
+        a("s_lshr_b32 s30, s30, 2")
+        a("s_add_u32 s30, s30, 1")
+        a("s_lshl_b32 s30, s30, 3")                   # 8 ((v - 1) / 4 + 1): every wave has finished visit v - 1
+        a("s_cmp_eq_u32 s31, 0")
+        a("s_cselect_b32 s30, 0, s30")                # (visit 0 overwrites nothing)
+        a("s_add_u32 vcc_lo, s31, 1")
+        a("s_and_b32 vcc_lo, vcc_lo, 3")
+        a("s_lshl_b32 vcc_lo, vcc_lo, 2")
+        a("s_add_u32 vcc_lo, vcc_lo, s19")
+        a(f"s_add_u32 vcc_lo, vcc_lo, {CNT_DONE}")
+        sync_wait(o, "D" + tag, "vcc_lo", "s30", early_reg="v29")
+        for i_ in range(5):
+            dma(i_, o)
+        a(f"LSTX{tag}%=:")
+
     def batches():
         for b in range(NB):
             a(f"LS{b}%=:")
@@ -409,16 +525,19 @@ def gen():
                 batch_F(b, o)
             if b % BPC == BPC - 1 and b // BPC < 3:
                 reload_slot(b // BPC, o)
-            if b >= NB - 4 and not DMA_TOP:
+            if CNT:
+                if b == NB - 4:
+                    stage_block("b")
+            elif b >= NB - 4 and not DMA_TOP:
                 dma(b - (NB - 4), o)
             if b + 2 < NB:
                 batch_AL(b + 2, o)
-        if not DMA_TOP:
+        if not DMA_TOP and not CNT:
             dma(4, o)
 
     def rotate():
         a("s_waitcnt lgkmcnt(0)")                    # the next round's records and the header
-        if WSRC == "tabi":
+        if WSRC == "tabi" or CNT:
             a("s_bfe_u32 s30, s34, 0x10008")         # the visit counter follows the round that becomes current
             a("s_add_u32 s31, s31, s30")
         a("s_mov_b32 s28, s34")
@@ -426,8 +545,9 @@ def gen():
         a("s_mov_b32 s101, s12")
         a("s_add_u32 s22, s22, 4")
         a("s_addc_u32 s23, s23, 0")
-        a("s_mov_b32 s29, s100")
-        a("s_lshl_b32 s30, s29, 6")
+        if not CNT:
+            a("s_mov_b32 s29, s100")
+        a("s_lshl_b32 s30, s100, 6")
         a("s_add_u32 s20, s20, s30")
         a("s_addc_u32 s21, s21, 0")
 
@@ -449,18 +569,25 @@ def gen():
             a("s_memtime s[2:3]")
         spread_weights()
         top()
-        a("s_cmp_eq_u32 s29, 4")
+        nch = "s29"
+        if CNT:
+            a("s_and_b32 s30, s28, 0xff")
+            nch = "s30"
+        a(f"s_cmp_eq_u32 {nch}, 4")
         a("s_cbranch_scc1 LPRO0%=")
-        a("s_cmp_eq_u32 s29, 3")
+        a(f"s_cmp_eq_u32 {nch}, 3")
         a("s_cbranch_scc1 LPRO1%=")
-        a("s_cmp_eq_u32 s29, 2")
+        a(f"s_cmp_eq_u32 {nch}, 2")
         a("s_cbranch_scc1 LPRO2%=")
-        a("s_cmp_eq_u32 s29, 1")
+        a(f"s_cmp_eq_u32 {nch}, 1")
         a("s_cbranch_scc1 LPRO3%=")
         # an empty round (a visit nobody has work in yet: the first two of a part)
         for c in range(4):
             reload_slot(c, o)
-        if not DMA_TOP:
+        if CNT:
+            a("s_waitcnt lgkmcnt(0)")                 # (the early poll)
+            stage_block("e")
+        elif not DMA_TOP:
             for i_ in range(5):
                 dma(i_, o)
         a("s_branch LBND%=")
@@ -485,14 +612,63 @@ def gen():
         a("s_sub_u32 s26, s26, 1")
         a("s_cmp_eq_u32 s26, 0")
         a("s_cbranch_scc1 LDONE%=")
-        a("s_waitcnt vmcnt(5)")                      # the next round's weights; every staging load but this round's five
+        if CNT:
+            # early poll for the case that the next round opens a visit: ready counter of the tile that visit reads first (tile v of visit v + 1)
+            a("s_and_b32 s30, s31, 3")
+            a("s_lshl_b32 s30, s30, 2")
+            a("s_add_u32 s30, s30, s19")
+            a("v_mov_b32 v31, s30")
+            a(f"ds_read_b32 v31, v31 offset:{CNT_READY}")
+            # the next round's weights and records; every staging load but the five of THIS round - which only a visit's first round has
+            a("s_bitcmp1_b32 s28, 8")
+            a("s_cbranch_scc0 LV0%=")
+            a("s_waitcnt vmcnt(5)")
+            a("s_branch LV1%=")
+            a("LV0%=:")
+            a("s_waitcnt vmcnt(0)")
+            a("LV1%=:")
+        else:
+            a("s_waitcnt vmcnt(5)")                      # the next round's weights; every staging load but this round's five
         if STAMP:
             a("s_memtime s[2:3]")
             a("s_waitcnt lgkmcnt(0)")
             a("s_sub_u32 s10, s2, s4")
             a("s_add_u32 s7, s7, s10")   # wait for vector memory (+ the scalar loads the stamp forces)
+        if CNT:
+            # the tile this wave staged a round ago has landed (the wait above covered its loads): tell the others
+            a("s_cmp_eq_u32 s29, 0")
+            a("s_cbranch_scc1 LNP%=")
+            sync_signal(o, "s29")
+            a("LNP%=:")
+            a("s_mov_b32 s29, 0")
+            a("s_bitcmp1_b32 s28, 8")                # this round staged tile v + 1: certified at the next boundary
+            a("s_cbranch_scc0 LNS%=")
+            a("s_add_u32 s30, s31, 1")
+            a("s_and_b32 s30, s30, 3")
+            a("s_lshl_b32 s30, s30, 2")
+            a("s_add_u32 s30, s30, s19")
+            a(f"s_add_u32 s29, s30, {CNT_READY}")
+            a("LNS%=:")
         a("s_bitcmp1_b32 s34, 8")
         a("s_cbranch_scc0 LNB%=")
+        if CNT:
+            # this wave has finished visit v: its last read of tile v - 2 has returned (the last batch's lgkmcnt(0))
+            a("s_sub_u32 s30, s31, 2")
+            a("s_and_b32 s30, s30, 3")
+            a("s_lshl_b32 s30, s30, 2")
+            a("s_add_u32 s30, s30, s19")
+            a(f"s_add_u32 s30, s30, {CNT_DONE}")
+            sync_signal(o, "s30")
+            # visit v + 1 reads tile v: landed for all 8 waves?
+            a("s_lshr_b32 s30, s31, 2")
+            a("s_add_u32 s30, s30, 1")
+            a("s_lshl_b32 s30, s30, 3")               # 8 (v / 4 + 1)
+            a("s_and_b32 vcc_lo, s31, 3")
+            a("s_lshl_b32 vcc_lo, vcc_lo, 2")
+            a("s_add_u32 vcc_lo, vcc_lo, s19")
+            a(f"s_add_u32 vcc_lo, vcc_lo, {CNT_READY}")
+            a("s_waitcnt lgkmcnt(0)")                 # (the early poll; the next round's records too: rotate() would wait for them anyway)
+            sync_wait(o, "R", "vcc_lo", "s30", early_reg="v31")
         advance()                                     # next round = first of a visit: the tile it reads first has landed for everybody, nobody reads the oldest one any more
         stamp_barrier_end()
         a("LNB%=:")
@@ -651,7 +827,7 @@ def main():
     check_dpp_hazards(lines)
     check_swap_hazards(lines)
     here = os.path.dirname(os.path.abspath(__file__))
-    name = "tile_dense_body.inc" if WSRC == "stream" else f"tile_dense_body_{WSRC}.inc"
+    name = "tile_dense_body.inc" if WSRC == "stream" else f"tile_dense_body_{WSRC}{'_cnt' if CNT else ''}.inc"
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "scan-rs_amd", "csrc", name)
     with open(path, "w") as f:
         f.write("// generated by tools/gen_tile_dense_asm.py - do not edit\n")
