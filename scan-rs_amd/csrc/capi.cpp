@@ -2226,6 +2226,8 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
             st.tile_dense = value != 0.0;
         } else if (k == "tile_sort_slots") {
             st.tile_sort_slots = value != 0.0;
+        } else if (k == "tile_flow") {
+            st.tile_flow = value != 0.0;
         } else if (k == "tile_wtab" || k == "tile_fold") {
             (k == "tile_wtab" ? st.tile_wtab : st.tile_fold) = value != 0.0;
             tile_layout_forget_weights(st.primary.tiles.get()); // (the form of the weights follows these two)

@@ -247,6 +247,7 @@ struct SparseCopy {
     DevBuf<uint32_t> order;
     std::vector<uint32_t> sorted_len;
     std::shared_ptr<TileLayout> tiles; // built on first use of the hybrid tile product under a given map (tiles.hip)
+    mutable bool tile_flow_refused = false;    // the flow layout cannot serve this copy (a map that does not separate, more large counts than the one-walk build's list holds): the dense layout takes over
     uint64_t tile_rejected_shape = 0;  // the tile shape (and overflow limit) whose layout was not worth building for this copy (0: none)
     int tsig_n = -1;                   // ... the map the last eligible product came with (auto path: build on the second sighting)
     uint32_t tsig_id[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -276,6 +277,9 @@ struct ShardInfo {
 void *pinned_take(size_t bytes, size_t *got);
 void pinned_give(void *p, size_t bytes) noexcept;
 
+#ifndef SCANRS_TILE_FLOW_DEFAULT
+#define SCANRS_TILE_FLOW_DEFAULT 0
+#endif
 struct Storage {
     uint64_t rows = 0, cols = 0;
     int storage = SCANRS_CSR; // orientation of `primary`: CSR -> outer = rows
@@ -342,6 +346,7 @@ struct Storage {
     int tile_dense = 1;                   // tile layout of the default shape: 1 = dense record streams, accumulators picked through VGPR index mode (round 5, tiles_dense.inc); 0 = fixed positions per (slot, visit) (round 4)
     int tile_sort_slots = 1;              // dense tile layout: slots placed in the order of their load (0: in vector order)
     int tile_emit_staged = 1;             // dense tile layout: the stream emission keeps its tables in LDS (0: searches them in global memory, the form for parts of > 4 000 tiles)
+    int tile_flow = SCANRS_TILE_FLOW_DEFAULT;                    // dense tile layout with the map evaluated in the kernel: 1 = the FLOW form (tiles_flow.inc): tiles of 32 rows in a ring of 6, one record stream per wave cut into rounds of 64 positions whatever tiles they belong to, the ring handed over at ticks through counters in LDS; 0 = the round-5 form (one barrier per tile of 48 rows, a round per visit)
     int tile_wtab = 1;                    // dense tile layout, folded separable map: the product kernel gathers a position's weight from the map's table by the record itself - the map evaluated inside the kernel, no weight stream (0: one f64 per position, refreshed per normalize)
     int tile_fold = 1;                    // dense tile layout, separable map: the factor of the side without the nonlinear links stays out of the per-position weights (0: both factors in every weight)
     uint64_t tile_big_list_cap = 0;       // dense tile layout, one-walk build: capacity of the list of nonzeros with counts above 255 (0: max(4 M, nnz / 64)); beyond it the two-walk build takes over

@@ -814,6 +814,10 @@ __global__ void tile_ovptr_kernel(const unsigned long long *__restrict__ ov_off,
 static inline bool tile_dense_wanted(const Storage &st) {
     return st.tile_dense != 0 && st.tile_builder != 0 && st.tile_k == 2u && st.tile_b == 4u && st.tile_s == 32u && st.tile_t == 48u;
 }
+// ... in its flow form (tiles_flow.inc): the map must come from a table inside the kernel, the build is the one-walk build
+static inline bool tile_flow_wanted(const Storage &st, const SparseCopy &cp) {
+    return tile_dense_wanted(st) && st.tile_flow != 0 && st.tile_wtab != 0 && st.tile_fold != 0 && st.tile_one_walk != 0 && !cp.tile_flow_refused;
+}
 // the tile layout of one orientation under one map
 struct TileLayout {
     TileShape sh{};
@@ -835,6 +839,8 @@ struct TileLayout {
     DevBuf<double> ratio_tab; // unit mode: quotient of the weight of counts 1 .. TL_TABC per position of the side that owns the nonlinear links
     // dense layout (round 5, tiles_dense.inc): record streams [item][wave][chunk][16] instead of fixed positions per (slot, visit)
     bool dense = false;
+    bool flow = false;             // dense, flow form (tiles_flow.inc): sh.T = 32, sh.B = 6, per-wave streams (fwaves), rtab = tick counts per round
+    DevBuf<char> fwaves;           // FlowWave per (item, wave)
     uint32_t dn_wgg = 0, dn_items = 0;
     uint64_t dn_chunks = 0;        // chunks of 16 positions in drec / pw (cmeta: one entry each)
     uint64_t dn_served = 0;        // nonzeros that own a record
@@ -856,10 +862,15 @@ struct TileLayout {
     int sig_outer[MAX_OPS] = {};
     double bytes() const {
         return (double)prow.n * 2.0 + (double)pcnt.n + (double)pw.n * 8.0 + (double)ov.nnz * 16.0 + (double)ratio_tab.n * 8.0 + (double)drec.n * 4.0 + (double)cmeta.n * 8.0 +
-               (double)rtab.n * 4.0 + (double)wtab.n * 8.0 + (double)(w_place.n + w_inner.n) * 8.0;
+               (double)rtab.n * 4.0 + (double)wtab.n * 8.0 + (double)(w_place.n + w_inner.n) * 8.0 + (double)fwaves.n;
     }
-    bool structure_matches(const Storage &st) const {
+    bool structure_matches(const Storage &st, const SparseCopy &cp) const {
         if (dense != tile_dense_wanted(st)) return false;
+        if (flow != tile_flow_wanted(st, cp)) return false;
+        if (flow) { // (its own tile shape, whatever tile_t / tile_b say)
+            const double want_x = st.tile_split ? st.tile_split_x : 0.0, want_min = st.tile_split ? st.tile_split_min : 0.0;
+            return (slot_order.n != 0) == (st.tile_sort_slots != 0 && n_slots > 1) && split_x == want_x && split_min == want_min;
+        }
         if (dense && (slot_order.n != 0) != (st.tile_sort_slots != 0 && n_slots > 1)) return false;
         const bool splittable = st.tile_builder != 0 && sh.K == 2u && sh.B == 4u && sh.S == 32u && sh.T == 48u; // the wave-level builder's shape
         const double want_x = splittable && st.tile_split ? st.tile_split_x : 0.0, want_min = splittable && st.tile_split ? st.tile_split_min : 0.0;
@@ -903,6 +914,7 @@ bool tile_shape_ok(uint32_t K, uint32_t S, uint32_t T, uint32_t B) {
 
 static TileLayout *dense_layout_build(Storage &st, const SparseCopy &cp, double max_overflow, hipStream_t s, std::unique_ptr<TileLayout> tl,
                                       const std::function<void(const char *)> &lap); // tiles_dense.inc
+static thread_local bool tl_flow_fallback = false; // dense_layout_build gave up on the FLOW form (not on the layout): build the dense form instead
 // max_overflow > 0: give up (nullptr) when more than that share of the nonzeros would land in the overflow part — known after the
 // counting pass, before anything large is allocated.
 TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_overflow, hipStream_t stream = nullptr) {
@@ -916,6 +928,11 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     sh.S = st.tile_s;
     sh.T = st.tile_t;
     sh.B = st.tile_b;
+    tl->flow = tile_flow_wanted(st, cp);
+    if (tl->flow) { // the flow form of the dense layout: the same 192 ring rows as 6 tiles of 32 (tiles_flow.inc)
+        sh.T = 32u;
+        sh.B = 6u;
+    }
     sh.sps = 64u / sh.K;
     sh.nset = (sh.S + sh.sps - 1) / sh.sps;
     sh.nt = (uint32_t)((cp.n_inner + sh.T - 1) / sh.T);
@@ -930,7 +947,7 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     };
     lap(nullptr);
     // the wave-level builder serves the default shape; other shapes (experiments) keep the per-thread walk, one slot per vector
-    const bool wave_builder = st.tile_builder != 0 && sh.K == 2u && sh.B == 4u && sh.S == 32u && sh.T == 48u && sh.nset == 1u;
+    const bool wave_builder = st.tile_builder != 0 && sh.K == 2u && ((sh.B == 4u && sh.T == 48u) || tl->flow) && sh.S == 32u && sh.nset == 1u;
     const bool split = wave_builder && st.tile_split != 0;
     tl->split_x = split ? st.tile_split_x : 0.0;
     tl->split_min = split ? st.tile_split_min : 0.0;
@@ -938,7 +955,9 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     if (cp.n_outer + 1 > 0xFFFFFFFFull) fail(SCANRS_ERR_SHAPE, "matrix too large for the tile layout's 32-bit slot index");
     DevBuf<uint32_t> mult(cp.n_outer + 1);
     tl->slot_first.alloc(cp.n_outer + 1);
-    hipLaunchKernelGGL(tile_mult_kernel, grid_1d(cp.n_outer + 1), dim3(256), 0, s, cp.indptr.p, cp.n_outer, (double)sh.T / (double)std::max<uint64_t>(1, cp.n_inner),
+    // (the slot rule is stated in nonzeros per 48 inner positions; the flow form walks tiles of 32 rows but deals its slots by the same densities:
+    // a slot then holds two thirds of the records per tile, and no vector that owned a slot loses it)
+    hipLaunchKernelGGL(tile_mult_kernel, grid_1d(cp.n_outer + 1), dim3(256), 0, s, cp.indptr.p, cp.n_outer, (double)(tl->flow ? 48u : sh.T) / (double)std::max<uint64_t>(1, cp.n_inner),
                        tl->split_x, tl->split_min, sh.S, mult.p);
     size_t tmp_bytes_u = 0;
     SCANRS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes_u, mult.p, tl->slot_first.p, 0u, (size_t)cp.n_outer + 1, rocprim::plus<uint32_t>(), s));
@@ -971,7 +990,17 @@ TileLayout *tile_layout_build(Storage &st, const SparseCopy &cp, double max_over
     if (tl->n_groups * sh.nt > 0xFFFFFFFFull || (sh.nset & (sh.nset - 1u))) fail(SCANRS_ERR_SHAPE, "matrix too large for the tile layout's 32-bit visit index");
     const uint64_t n_seg = cp.n_outer * sh.n_parts;
     lap("slots");
-    if (tile_dense_wanted(st)) return dense_layout_build(st, cp, max_overflow, s, std::move(tl), lap);
+    if (tile_dense_wanted(st)) {
+        const bool was_flow = tl->flow;
+        tl_flow_fallback = false;
+        TileLayout *t = dense_layout_build(st, cp, max_overflow, s, std::move(tl), lap);
+        if (!t && was_flow && tl_flow_fallback) {
+            if (trace_on()) fprintf(stderr, "[scanrs trace] tile layout: the flow form cannot serve this copy -> dense form\n");
+            cp.tile_flow_refused = true;
+            return tile_layout_build(st, cp, max_overflow, stream);
+        }
+        return t;
+    }
     // ---- count the overflow per (vector, part) ----
     // one_pass (the wave builder's default): no counting pass - the fill pass writes the records AND the overflow nonzeros (into
     // temporaries indexed like the source, counted per segment as they come), a compaction moves them to their places; the
@@ -1200,7 +1229,10 @@ static void tile_layout_weights(Storage &st, TileLayout &tl, const SparseCopy &c
     }
 }
 
+static void flow_layout_streams(Storage &st, TileLayout &tl, const uint32_t *cnt, const uint64_t *off, const uint32_t *sorted, uint64_t n_served, hipStream_t s,
+                                const std::function<void(const char *)> &lap); // tiles_flow.inc
 #include "tiles_dense.inc"
+#include "tiles_flow.inc"
 
 // ---- product -------------------------------------------------------------------------------------------------------
 namespace {
@@ -1586,7 +1618,7 @@ static bool tile_auto_candidate(const Storage &st, const SparseCopy &cp) {
 }
 bool tile_layout_build_auto(Storage &st, SparseCopy &cp, hipStream_t s) {
     if (!tile_auto_candidate(st, cp)) return false;
-    if (cp.tiles && cp.tiles->structure_matches(st)) return true;
+    if (cp.tiles && cp.tiles->structure_matches(st, cp)) return true;
     // room: records (11 B per position: row 2, count 1, weight 8) + overflow + the build's temporaries + the partial-sum buffers, and 8 GB for the solver
     const double nt = (double)((cp.n_inner + st.tile_t - 1) / st.tile_t);
     // (dense layout: 12.5 B per position at about 1.1 positions per nonzero, 4 B per nonzero of build temporaries and the per-(group, visit) tables)
@@ -1645,7 +1677,7 @@ bool tile_layout_build_auto(Storage &st, SparseCopy &cp, hipStream_t s) {
 
 bool spmm_tiles_auto(Storage &st, SparseCopy &cp, const DevMap &map) {
     if (!tile_auto_candidate(st, cp)) return false;
-    if (cp.tiles && cp.tiles->structure_matches(st)) return true; // the weights follow the map in one streaming pass
+    if (cp.tiles && cp.tiles->structure_matches(st, cp)) return true; // the weights follow the map in one streaming pass
     bool seen = cp.tsig_n == map.n;
     for (int i = 0; seen && i < map.n; i++) seen = cp.tsig_id[i] == map.ops[i].id && cp.tsig_outer[i] == map.ops[i].a_outer;
     cp.tsig_n = map.n;
@@ -1665,12 +1697,19 @@ void launch_gather2d_ov(Storage &st, hipStream_t s, SparseCopy &ov, const double
 void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const double *X, uint32_t ldx, uint32_t l, double *out,
                        uint32_t ldo, const double *off_a, uint32_t rank, const double *off_w, uint32_t ldw) {
     if ((ldx & 1u) || (ldo & 1u)) fail(SCANRS_ERR_ARGUMENT, "panel leading dimensions must be even");
-    if (!cp.tiles || !cp.tiles->structure_matches(st)) {
+    if (!cp.tiles || !cp.tiles->structure_matches(st, cp)) {
         cp.tiles.reset(); // free the old layout before the new one is allocated
         cp.tiles.reset(tile_layout_build(st, cp, 0.0), tile_layout_free); // forced (spmm_path 3): whatever the overflow
     }
+    if (!cp.tiles->weights_match(map)) tile_layout_weights(st, *cp.tiles, cp, map);
+    if (cp.tiles->flow && cp.tiles->wsrc == 0) { // a map that does not come from a table (GLM-PCA residuals, tile_fold 0): the dense form and its weight stream
+        if (trace_on()) fprintf(stderr, "[scanrs trace] tile layout: the map does not separate -> this orientation is rebuilt in the dense form\n");
+        cp.tile_flow_refused = true;
+        cp.tiles.reset();
+        cp.tiles.reset(tile_layout_build(st, cp, 0.0), tile_layout_free);
+        tile_layout_weights(st, *cp.tiles, cp, map);
+    }
     TileLayout &tl = *cp.tiles;
-    if (!tl.weights_match(map)) tile_layout_weights(st, tl, cp, map);
     const TileShape &sh = tl.sh;
     // the kernels want compact panel rows (a tile is one contiguous run of bytes): a block of a wider panel is copied first
     const uint32_t ldc = even_up(l);
@@ -1724,6 +1763,8 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
 #define SCANRS_TILE(KK, SS, UU) launch_tile_kernel<KK, SS, UU>(st, ta, X, ldx, l, pbuf, ldc, part_stride, n_items, grid)
     const bool um = tl.unit_mode; // a layout with unit positions under a map that does not separate runs the weighted kernel
     if (n_items == 0) { // every vector went to the overflow part: nothing for the tile kernel
+    } else if (tl.flow) {
+        launch_tile_flow_kernel(st, tl, X, ldx, l, pbuf, ldc, part_stride, next_item, grid);
     } else if (tl.dense) {
         launch_tile_dense_kernel(st, tl, X, ldx, l, pbuf, ldc, part_stride, next_item, grid);
     } else if (sh.K == 2 && sh.S == 32)
@@ -1748,7 +1789,7 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
 }
 
 double *tile_panel_copy_target(Storage &st, SparseCopy &cp, uint32_t l) {
-    if ((l & 1u) || l < 16u || l > TL_LMAX || !cp.tiles || !cp.tiles->dense || cp.tiles->unit_mode || cp.tiles->fold_inner || !cp.tiles->structure_matches(st)) return nullptr;
+    if ((l & 1u) || l < 16u || l > TL_LMAX || !cp.tiles || !cp.tiles->dense || cp.tiles->unit_mode || cp.tiles->fold_inner || !cp.tiles->structure_matches(st, cp)) return nullptr;
     if (!(st.spmm_path == 3 || (st.spmm_path == 0 && st.tile_auto && st.panel_precision == 0))) return nullptr;
     return st.scratch.get<double>("tile_xc", ((size_t)cp.n_inner + 3u * cp.tiles->sh.T) * l); // (the size launch_spmm_tiles asks for: the same buffer)
 }

@@ -754,9 +754,11 @@ def test_map_evaluated_inside_the_tile_kernel_equals_the_weight_stream_and_the_o
         for storage in (so.CSR, so.CSC):
             for log_axis in (0, 1, None):
                 hs = []
-                for wtab in (1, 0):
+                # (table gathers in the round-5 layout, its weight stream, and the FLOW layout of round 6: tiles of 32 rows in a ring of 6,
+                # one stream per wave, ticks and LDS counters instead of the barrier - tiles_flow.inc)
+                for wtab, flow in ((1, 0), (0, 0), (1, 1)):
                     g, o = pair(sa, dense, storage)
-                    g.set_spmm_path(3).set_option("tile_wtab", wtab).set_option("tile_split_min", 0.3)
+                    g.set_spmm_path(3).set_option("tile_wtab", wtab).set_option("tile_flow", flow).set_option("tile_split_min", 0.3)
                     hs.append(g)
                 fa, fb = np.linspace(0.5, 1.5, cols if log_axis == 1 else rows), np.linspace(0.7, 1.3, rows if log_axis == 1 else cols)
                 if log_axis is not None:
@@ -768,15 +770,19 @@ def test_map_evaluated_inside_the_tile_kernel_equals_the_weight_stream_and_the_o
                 for k in (0, 1):
                     assert_close(outs[0][k], ref[k], rtol=1e-10, atol=1e-9)
                     assert_close(outs[0][k], outs[1][k], rtol=1e-12, atol=1e-11)
-                assert np.array_equal(outs[0][0], hs[0].dot(q)) and np.array_equal(outs[0][1], hs[0].rdot(ql))  # repeatable
+                    assert_close(outs[2][k], ref[k], rtol=1e-10, atol=1e-9)
+                    assert_close(outs[2][k], outs[0][k], rtol=1e-12, atol=1e-11)
+                for i in (0, 2):
+                    assert np.array_equal(outs[i][0], hs[i].dot(q)) and np.array_equal(outs[i][1], hs[i].rdot(ql))  # repeatable
                 if log_axis == 1:  # another map on the same handles: only the table is rewritten
                     for g in hs:
                         g.reset_map()
                         g.compose_scale_axis(1, fa[::-1].copy()).apply(sa.FN_LN_1P)
                     o2 = pair(sa, dense, storage)[1].compose_map(so.MapOp(so.OP_SCALE_AXIS, axis=1, a=fa[::-1].copy())).apply(so.OP_LN_1P)
-                    a, b = hs[0].dot(q), hs[1].dot(q)
+                    a, b, c = hs[0].dot(q), hs[1].dot(q), hs[2].dot(q)
                     assert_close(a, o2.dot(q), rtol=1e-10, atol=1e-9)
                     assert_close(a, b, rtol=1e-12, atol=1e-11)
+                    assert_close(c, a, rtol=1e-12, atol=1e-11)
 
 
 def test_invalid_sparse_input_is_refused(sa):

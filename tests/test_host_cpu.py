@@ -464,6 +464,11 @@ def test_dense_tile_kernel_leaves_registers_for_a_gather_wave(tmp_path):
         for m in re.finditer(r"\.name:\s+(\S*spmm_tile_dense_kernel\S*)(.*?)\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", notes, re.S):
             found[m.group(1)] = (int(m.group(3)), int(m.group(4)))
     assert len(found) == 3, f"three instances of spmm_tile_dense_kernel (weight stream, tabo, tabi) expected in the library's gfx950 code objects: {sorted(found)}"
+    for co in sorted(tmp_path.glob("lib.so.*gfx950*")):  # the flow layout's kernel (tiles_flow.inc): the same budget
+        notes = subprocess.run([readelf, "--notes", str(co)], capture_output=True, text=True).stdout
+        for m in re.finditer(r"\.name:\s+(\S*spmm_tile_flow_kernel\S*)(.*?)\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", notes, re.S):
+            found[m.group(1)] = (int(m.group(3)), int(m.group(4)))
+    assert len(found) == 5, sorted(found)
     for name, (vgprs, spills) in found.items():
         assert vgprs <= 216 and spills == 0, (name, vgprs, spills)
 
@@ -475,10 +480,15 @@ def test_generated_tile_kernel_stream_is_the_generators_output(tmp_path):
 
     # round 6: three streams - the weight-stream form and the two forms that evaluate the map inside the kernel (table gathers by the
     # record itself: tabo / tabi); the generator also checks the wait states in front of their v_permlane*_swap instructions
-    for wsrc, name in (("stream", "tile_dense_body.inc"), ("tabo", "tile_dense_body_tabo.inc"), ("tabi", "tile_dense_body_tabi.inc")):
+    # ... the same two with the ring handed over by LDS counters (GEN_SYNC=cnt: built, measured slower, not compiled by default) and the
+    # FLOW layout's round loop (GEN_FLOW=1, tiles_flow.inc: per-wave streams, ticks, counters; handle option tile_flow)
+    for wsrc, name, extra in (("stream", "tile_dense_body.inc", {}), ("tabo", "tile_dense_body_tabo.inc", {}), ("tabi", "tile_dense_body_tabi.inc", {}),
+                              ("tabo", "tile_dense_body_tabo_cnt.inc", {"GEN_SYNC": "cnt"}), ("tabi", "tile_dense_body_tabi_cnt.inc", {"GEN_SYNC": "cnt"}),
+                              ("tabo", "tile_flow_body_tabo.inc", {"GEN_FLOW": "1"}), ("tabi", "tile_flow_body_tabi.inc", {"GEN_FLOW": "1"})):
         out = tmp_path / name
         env = {k: v for k, v in os.environ.items() if not k.startswith("GEN_")}
         env["GEN_WSRC"] = wsrc
+        env.update(extra)
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_tile_dense_asm.py"), str(out)], check=True, capture_output=True, env=env)
         with open(os.path.join(ROOT, "scan-rs_amd", "csrc", name)) as f:
             assert f.read() == out.read_text(), name

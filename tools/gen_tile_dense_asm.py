@@ -766,6 +766,328 @@ def gen():
     return o
 
 
+
+# ---- the flow layout's round loop (GEN_FLOW=1; tiles_flow.inc) --------------------------------------------------------------------
+# Every round is 4 chunks of 16 record positions of ONE wave's stream; the ring of 6 tiles of 32 rows is handed over at TICKS in front
+# of chunks (round header: ticks in front of chunk j in bits 2j+1:2j, their sum in bits 11:8). One array of six counters behind the
+# ring, P[u % 6] += 1 when a wave passes tick K(u). Passing K(v) means: the wave has released tile v - 2 (its records lie in front of
+# the tick) and its share of tile v + 1 - staged by its previous tick - has landed (a counted vmcnt wait: behind those loads only the
+# two loads of every round top since). At K(v) a wave
+#   A (in front of the chunk): certifies + announces (one ds_add), reads P[(v - 1) % 6], stages its four KB of tile v + 2 over tile
+#     v - 4 - allowed because its previous tick saw every wave past K(v - 2) - and goes on with the chunk's first 12 positions, which the
+#     builder keeps clear of tile v;
+#   B (one batch later, when the counted LDS wait has covered that read): checks P[(v - 1) % 6] >= 8 ((v - 1) / 6 + 1): every wave is past
+#     K(v - 1), so tile v has landed for all of them and tile v - 3's readers are gone. Polls with s_sleep only if not.
+# A wave may run one tile ahead of the slowest; no wait sits on a tick's fast path except the vmcnt one.
+# Timing experiments on the first form (profiles/HISTORY.md): the round loop WITHOUT ticks runs a pass in 10.6 / 11.2 ms against the
+# dense layout's 14.4 / 15.8 - the ticks are what the flow form costs.
+FLOW = (os.environ.get("GEN_FLOW") or "0") != "0"
+FSKIP = set((os.environ.get("GEN_FSKIP") or "").split(","))  # timing experiments on the flow loop (wrong results): p = no counter check, v = no vmcnt wait in a tick, d = no staging loads, t = no ticks at all
+FL_P = 0x400      # byte offset of P[6] behind the ring's end (s19); the row of zeros sits in the first KB
+FL_GUARD_BATCHES = 3  # batches of a chunk worked before phase B: the builder's FL_GUARD = 4 x this
+MAGIC6 = "0xaaaaaaab"  # x / 6 = (x * 0xaaaaaaab) >> 34
+
+
+def flow_div6(out, q, r, x, tmp):
+    """q = x / 6, r = x % 6 (scalar registers; r may be x)"""
+    a = out.append
+    a(f"s_mul_hi_u32 {q}, {x}, {MAGIC6}")
+    a(f"s_lshr_b32 {q}, {q}, 2")
+    a(f"s_mul_i32 {tmp}, {q}, 6")
+    a(f"s_sub_u32 {r}, {x}, {tmp}")
+
+
+def flow_gather(out, vs_from_header):
+    """v[26:27] <- the table entries of the 64 records in v28 (temporaries v56-v58: row registers, idle at a round's top). tabi: a
+    round's records name tiles vs - 2 .. vs + 3 (vs = the tile the round's first tick opens; at most 4 ticks per round), 6 consecutive
+    ones, so the ring buffer (ring row / 32) says which: with u = vs - 2 = 6 q + m, buffer b holds tile 6 q + b when b >= m and
+    6 (q + 1) + b otherwise. vs_from_header: the NEXT round's (s31 + the ticks of the current one); else the current s31 (entry)."""
+    a = out.append
+    if WSRC == "tabo":
+        a("v_and_b32 v56, 0xfc, v28")               # 4 x slot
+        a("v_bfe_u32 v58, v28, 8, 8")               # count
+        a("v_lshlrev_b32 v58, 3, v58")
+        a("v_lshl_add_u32 v56, v56, 5, v58")        # slot x 128 + count x 8
+    else:
+        if vs_from_header:
+            a("s_bfe_u32 s30, s28, 0x40008")
+            a("s_add_u32 s30, s31, s30")
+        else:
+            a("s_mov_b32 s30, s31")
+        a("s_max_u32 s30, s30, 2")
+        a("s_sub_u32 s30, s30, 2")                  # u
+        flow_div6(out, "m0", "s30", "s30", "vcc_lo")  # q, m
+        a("s_mul_i32 m0, m0, 0x600")                # 192 q rows, in bytes
+        a("s_lshl_b32 s30, s30, 21")                # (32 m) << 16: first ring row of buffer m, as a record
+        a("v_bfe_u32 v58, v28, 8, 8")               # count
+        a("v_mul_lo_u32 v58, v58, s101")            # plane
+        a("v_lshrrev_b32 v56, 13, v28")             # ring row x 8
+        a("v_mov_b32 v57, 0x600")
+        a("v_cmp_gt_u32 vcc, s30, v28")             # a buffer below m: the ring's next turn
+        a("v_cndmask_b32 v57, 0, v57, vcc")
+        a("v_add3_u32 v56, v56, v58, v57")
+        a("v_add_u32 v56, m0, v56")
+    a("v_add_co_u32 v56, vcc, v38, v56")
+    a("v_addc_co_u32 v57, vcc, 0, v39, vcc")
+    a("global_load_dwordx2 v[26:27], v[56:57], off")
+
+
+def flow_spin(out, tag):
+    """until P[(v - 1) % 6] >= s13 for the tick just worked (s31 = v + 1): the slow path of a tick's check"""
+    a = out.append
+    a("s_sub_u32 s14, s31, 2")                      # v - 1 (a tick with v = 0 never comes here: its threshold is 0)
+    flow_div6(out, "s15", "s14", "s14", "s16")
+    a("s_lshl_b32 s14, s14, 2")
+    a("s_add_u32 s14, s14, s19")
+    a("v_mov_b32 v33, s14")
+    a(f"s_mov_b32 vcc_hi, {SPIN_MAX}")
+    a(f"LSP{tag}%=:")
+    a("s_sleep 1")
+    a(f"ds_read_b32 v32, v33 offset:{FL_P}")
+    a("s_waitcnt lgkmcnt(0)")
+    a("v_readfirstlane_b32 s16, v32")
+    a("s_cmp_ge_u32 s16, s13")
+    a(f"s_cbranch_scc1 LSP{tag}X%=")
+    a("s_sub_u32 vcc_hi, vcc_hi, 1")
+    a("s_cmp_eq_u32 vcc_hi, 0")
+    a(f"s_cbranch_scc0 LSP{tag}%=")
+    a(f"LSP{tag}X%=:")
+
+
+def flow_tick_a(out, tag):
+    """phase A of tick K(v), v = s31 (see above). Leaves the check's threshold in s13 and the counter as read in v32; v += 1.
+    Temporaries: s13-s16 (the last batch's copy registers: no tick stands inside a batch), s30, m0, v33."""
+    a = out.append
+    if "v" not in FSKIP:  # the previous tick's staging loads have landed
+        a("s_cmp_eq_u32 s29, 0")
+        a(f"s_cbranch_scc1 LC{tag}0%=")
+        a("s_cmp_eq_u32 s29, 1")
+        a(f"s_cbranch_scc1 LC{tag}1%=")
+        a("s_waitcnt vmcnt(4)")
+        a(f"s_branch LC{tag}X%=")
+        a(f"LC{tag}1%=:")
+        a("s_waitcnt vmcnt(2)")
+        a(f"s_branch LC{tag}X%=")
+        a(f"LC{tag}0%=:")
+        a("s_waitcnt vmcnt(0)")
+        a(f"LC{tag}X%=:")
+    flow_div6(out, "s13", "s14", "s31", "s30")      # q, b
+    a("s_lshl_b32 s15, s14, 2")
+    a("s_add_u32 s15, s15, s19")                    # P[b]
+    a("v_mov_b32 v33, s15")
+    a("s_mov_b64 exec, 1")
+    a(f"ds_add_u32 v33, v34 offset:{FL_P}")         # this wave is past K(v)
+    a("s_mov_b64 exec, -1")
+    a("s_sub_u32 s15, s15, 4")                      # P[(v - 1) % 6]: the counter in front, or the last one
+    a("s_add_u32 s16, s19, 20")
+    a("s_cmp_eq_u32 s14, 0")
+    a("s_cselect_b32 s15, s16, s15")
+    a("s_cselect_b32 s16, 0, 1")
+    a("v_mov_b32 v32, s15")
+    a(f"ds_read_b32 v32, v32 offset:{FL_P}")
+    a("s_add_u32 s13, s13, s16")                    # (v - 1) / 6 + 1 = q + 1, or q when b = 0 (0 for v = 0: nothing to wait for)
+    a("s_lshl_b32 s13, s13, 3")
+    # this wave's KBs of tile v + 2: chunks wave, wave + 8, ... below the tile's end - s17 of them, 3 at 100 columns (4 for wave 0); the first form
+    # issued 4 from every wave, the surplus rewriting the tile's last KB: 32 loads for 25 KB (s12 / s32 / s33 / s100: the chunks' offsets
+    # inside a tile; v29 / v30 / v31 / v35: the same + 16 x lane)
+    a("s_add_u32 s31, s31, 1")
+    a("s_mov_b32 s29, 0")
+    dm = (("s12", "v29"), ("s32", "v30"), ("s33", "v31"), ("s100", "v35"))
+    for i in (3, 2, 1, 0):
+        off, vo = dm[i]
+        a(f"s_cmp_lt_u32 s17, {i + 1}")
+        a(f"s_cbranch_scc1 LDM{tag}{i}%=")
+        a(f"s_add_u32 m0, s35, {off}")
+        a("s_nop 0")                                # (one wait state between a write of M0 and the LDS-DMA that reads it)
+        a(f"global_load_lds_dwordx4 {vo}, s[24:25]" if "d" not in FSKIP else "s_nop 0")
+        a(f"LDM{tag}{i}%=:")
+    a("s_add_u32 s24, s24, s27")
+    a("s_addc_u32 s25, s25, 0")
+    a("s_add_u32 s35, s35, s27")
+    a("s_cmp_eq_u32 s35, s19")
+    a("s_cselect_b32 s35, s18, s35")
+
+
+def flow_tick_b(out, tag):
+    """phase B: the counter read in phase A (v32; its LDS read has returned) against the threshold in s13"""
+    a = out.append
+    if "p" in FSKIP:
+        return
+    a("v_readfirstlane_b32 s16, v32")
+    a("s_cmp_ge_u32 s16, s13")
+    a(f"s_cbranch_scc1 LB{tag}X%=")
+    flow_spin(out, f"B{tag}")
+    a(f"LB{tag}X%=:")
+
+
+def gen_flow():
+    """The flow layout's round loop. Registers as in the table forms of gen() except: s31 = the tile the next tick opens; s29 = round
+    tops since the last tick; s12 / s32 / s33 / s100 = this wave's four chunk offsets inside a tile and v29 / v30 / v31 / v35 the same
+    + 16 x lane (the staging loads' addresses); s101 = tabi: bytes between two planes; s34 the next round's header; s[20:21] = END of
+    the current round's records (= where the next round's begin); v32 a tick's counter as read; v33 a tick's temporary; v34 = 1."""
+    assert TAB and WDIRECT and BP == 4 and not STAMP
+    o = []
+    a = o.append
+    for name, lo in (("rec", 20), ("rtab", 22), ("src", 24)):
+        a(f"v_readfirstlane_b32 s{lo}, %[{name}lo]")
+        a(f"v_readfirstlane_b32 s{lo + 1}, %[{name}hi]")
+    a("v_readfirstlane_b32 s26, %[nrounds]")
+    a("v_readfirstlane_b32 s27, %[rowb]")
+    a("s_lshl_b32 s27, s27, 5")                  # bytes of a tile of 32 rows
+    a("v_readfirstlane_b32 s31, %[t0]")
+    a("v_readfirstlane_b32 s17, %[wave10]")
+    a("v_readfirstlane_b32 s18, %[lds0]")
+    a("s_mul_i32 s19, s27, 6")
+    a("s_add_u32 s19, s19, s18")
+    a("s_add_u32 s30, s31, 2")                   # tile t0 + 2 is staged first: its ring buffer
+    flow_div6(o, "s13", "s14", "s30", "s15")
+    a("s_mul_i32 s14, s14, s27")
+    a("s_add_u32 s35, s18, s14")
+    a("s_sub_u32 s30, s27, 0x400")
+    a("v_lshlrev_b32 v34, 2, %[lane4]")          # 16 x lane: the lane's offset inside a 1 KB staging chunk
+    for i, (r_, vo) in enumerate((("s12", "v29"), ("s32", "v30"), ("s33", "v31"), ("s100", "v35"))):
+        a(f"s_add_u32 {r_}, s17, {i * 8192}")
+        a(f"s_min_u32 {r_}, {r_}, s30")
+        a(f"v_add_u32 {vo}, {r_}, v34")
+    a("v_mov_b32 v38, %[tablo]")
+    a("v_mov_b32 v39, %[tabhi]")
+    a("v_mov_b32 v33, %[lane4]")                 # (4 x lane: the address of the record loads below; a tick's temporary afterwards - the round top makes it again)
+    a("s_mov_b32 s16, s17")                      # (wave << 10, once more: wave 0 presets the counters below)
+    # s17 = the chunks of a tile this wave stages: chunks wave + 8 i below ceil(tile bytes / 1 KB)
+    a("s_add_u32 s30, s27, 0x3ff")
+    a("s_lshr_b32 s30, s30, 10")                 # chunks of a tile
+    a("s_lshr_b32 s15, s17, 10")                 # wave
+    a("s_add_u32 s30, s30, 7")
+    a("s_sub_u32 s30, s30, s15")
+    a("s_lshr_b32 s17, s30, 3")                  # (chunks + 7 - wave) / 8
+    a("s_min_u32 s17, s17, 4")
+    if WSRC == "tabi":
+        a("v_readfirstlane_b32 s101, %[stride8]")
+    a("v_mov_b32 v36, %[ring]")
+    a("v_mov_b32 v37, %[rowb]")
+    a("s_mov_b32 s29, 0")                        # round tops since the last tick
+    a("s_cmp_eq_u32 s26, 0")
+    a("s_cbranch_scc1 LDONE%=")
+    a("s_load_dword s28, s[22:23], 0x0")         # header of round 0
+    for c in range(4):
+        a(f"s_load_dwordx16 s[{R0 + 16 * c}:{R0 + 16 * c + 15}], s[20:21], {hex(64 * c)}")
+    a("global_load_dword v28, v33, s[20:21]")    # the records of round 0, lane L = record L
+    a("s_add_u32 s20, s20, 0x100")
+    a("s_addc_u32 s21, s21, 0")
+    # The counters, preset by wave 0 as if every tick before K(t0) had happened (so that the thresholds do not depend on the part):
+    # P[b] = 8 x ticks u < t0 with u % 6 == b = 8 ((t0 + 5 - b) / 6). (Tiles t0 and t0 + 1 were staged by the caller and are certified by the
+    # wait and the barrier below; every wave's first tick announces tile t0 + 1 like any tile "staged by the tick before".)
+    a("s_cmp_eq_u32 s16, 0")
+    a("s_cbranch_scc0 LINITX%=")
+    a("v_mbcnt_lo_u32_b32 v56, -1, 0")
+    a("v_mbcnt_hi_u32_b32 v56, -1, v56")         # lane = b
+    a("s_add_u32 s30, s31, 5")
+    a("v_sub_u32 v57, s30, v56")
+    a(f"s_mov_b32 s30, {MAGIC6}")
+    a("v_mul_hi_u32 v57, v57, s30")
+    a("v_lshrrev_b32 v57, 2, v57")
+    a("v_lshlrev_b32 v57, 3, v57")
+    a("v_lshlrev_b32 v56, 2, v56")
+    a("v_add_u32 v56, s19, v56")
+    a("s_mov_b64 exec, 0x3f")
+    a(f"ds_write_b32 v56, v57 offset:{FL_P}")
+    a("s_mov_b64 exec, -1")
+    a("LINITX%=:")
+    a("v_mov_b32 v34, 1")                        # (what a tick adds to a counter)
+    a("s_waitcnt vmcnt(0)")                      # (round 0's records as a vector; the caller's two tiles)
+    flow_gather(o, vs_from_header=False)         # weights of round 0
+    a("global_load_dword v28, v33, s[20:21]")    # the records of round 1
+    a("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    a("s_barrier")                               # the only one: it publishes the preset counters, the row of zeros and the first two tiles
+
+    a("LROUND%=:")
+    tab_spread(o)
+    a("s_add_u32 s29, s29, 1")
+    a("s_load_dword s34, s[22:23], 0x4")         # the next round's header
+    flow_gather(o, vs_from_header=True)          # the next round's weights, by its records (loaded a round ago)
+    a("v_subrev_u32 v33, s12, v29")              # 16 x lane
+    a("v_lshrrev_b32 v33, 2, v33")               # 4 x lane
+    a("global_load_dword v28, v33, s[20:21] offset:256")  # the records of the round after it (this load also pulls them into L2 for their scalar loads)
+    batch_AL(0, o)
+    batch_AL(1, o)
+    for b in range(NB):
+        a(f"LS{b}%=:")
+        j = b // BPC
+        fld = hex((2 << 16) | (2 * j))
+        if b % BPC == 0 and "t" not in FSKIP:
+            a(f"s_bfe_u32 s30, s28, {fld}")
+            a("s_cmp_eq_u32 s30, 0")
+            a(f"s_cbranch_scc0 LTK{j}%=")
+            a(f"LTKR{j}%=:")
+        last = b == NB - 1
+        a(f"s_waitcnt lgkmcnt({BP})" if not last else "s_waitcnt lgkmcnt(0)")
+        if b % BPC == FL_GUARD_BATCHES - 2 and "t" not in FSKIP:
+            # phase B of a tick in front of this chunk: its counter read lies behind this batch's rows and in front of the next one's, the
+            # wait above has covered it; the rows of the batch after the next are issued below, behind the check
+            a(f"s_bfe_u32 s30, s28, {fld}")
+            a("s_cmp_eq_u32 s30, 0")
+            a(f"s_cbranch_scc1 LNB{j}%=")
+            flow_tick_b(o, f"{j}")
+            a(f"LNB{j}%=:")
+        if last:
+            for j_ in range(BP):
+                a(f"s_mov_b32 s{13 + j_}, {rec(b * BP + j_)}")
+            a(f"s_load_dwordx16 s[{R0 + 48}:{R0 + 63}], s[20:21], 0xc0")
+            batch_F(b, o, tail=True)
+        else:
+            batch_F(b, o)
+        if b % BPC == BPC - 1 and b // BPC < 3:
+            c = b // BPC
+            a(f"s_load_dwordx16 s[{R0 + 16 * c}:{R0 + 16 * c + 15}], s[20:21], {hex(64 * c)}")
+        if b + 2 < NB:
+            batch_AL(b + 2, o)
+    # ---- boundary ----
+    # the next round's weights and records must have arrived; behind them (newer) only the staging loads of this round's ticks, at least 3
+    # each (a wave that stages fewer - panels below 72 columns - waits for everything)
+    a("s_bfe_u32 s30, s28, 0x40008")
+    a("s_cmp_lt_u32 s17, 3")
+    a("s_cselect_b32 s30, 0, s30")
+    for n, lab in ((0, "LV0"), (1, "LV1"), (2, "LV2")):
+        a(f"s_cmp_eq_u32 s30, {n}")
+        a(f"s_cbranch_scc1 {lab}%=")
+    a("s_waitcnt vmcnt(9)")
+    a("s_branch LVX%=")
+    a("LV2%=:")
+    a("s_waitcnt vmcnt(6)")
+    a("s_branch LVX%=")
+    a("LV1%=:")
+    a("s_waitcnt vmcnt(3)")
+    a("s_branch LVX%=")
+    a("LV0%=:")
+    a("s_waitcnt vmcnt(0)")
+    a("LVX%=:")
+    a("s_sub_u32 s26, s26, 1")
+    a("s_cmp_eq_u32 s26, 0")
+    a("s_cbranch_scc1 LDONE%=")                  # (every tile another wave still reads was announced by the tick behind the one that staged it)
+    a("s_waitcnt lgkmcnt(0)")                    # the next round's records and header
+    a("s_mov_b32 s28, s34")
+    a("s_add_u32 s22, s22, 4")
+    a("s_addc_u32 s23, s23, 0")
+    a("s_add_u32 s20, s20, 0x100")
+    a("s_addc_u32 s21, s21, 0")
+    a("s_branch LROUND%=")
+    # ---- ticks in front of chunk j (out of line) ----
+    for j in range(4):
+        fld = hex((2 << 16) | (2 * j))
+        a(f"LTK{j}%=:")
+        flow_tick_a(o, f"{j}")
+        a(f"s_bfe_u32 s30, s28, {fld}")          # ticks still standing in front of this chunk, the one just worked included
+        a("s_cmp_eq_u32 s30, 1")
+        a(f"s_cbranch_scc1 LTKR{j}%=")           # the last one: its check follows a batch later (phase B)
+        a(f"s_sub_u32 s28, s28, {hex(1 << (2 * j))}")  # one more to go: counted down inside the header (nothing else reads this field; the sum in bits 11:8 stays)
+        a("s_waitcnt lgkmcnt(0)")                # ... and this one's check right here: the next tick stages on the strength of it
+        flow_tick_b(o, f"M{j}")
+        a(f"s_branch LTK{j}%=")
+    a("LDONE%=:")
+    a("s_waitcnt vmcnt(0) lgkmcnt(0)")           # nothing of this statement may land in a register later
+    return o
+
+
 def check_dpp_hazards(lines):
     """gfx950: a VALU write of a VGPR needs two wait states before a DPP instruction reads it, a VALU write of EXEC five. The compiler's
     hazard recognizer does not look into an asm statement, so the stream is checked here: the DPP sources of every
@@ -823,11 +1145,13 @@ def check_swap_hazards(lines):
 
 
 def main():
-    lines = gen()
+    lines = gen_flow() if FLOW else gen()
     check_dpp_hazards(lines)
     check_swap_hazards(lines)
     here = os.path.dirname(os.path.abspath(__file__))
     name = "tile_dense_body.inc" if WSRC == "stream" else f"tile_dense_body_{WSRC}{'_cnt' if CNT else ''}.inc"
+    if FLOW:
+        name = f"tile_flow_body_{WSRC}.inc"
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "..", "scan-rs_amd", "csrc", name)
     with open(path, "w") as f:
         f.write("// generated by tools/gen_tile_dense_asm.py - do not edit\n")
