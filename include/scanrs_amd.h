@@ -266,6 +266,9 @@ typedef struct scanrs_comm scanrs_comm;
 int scanrs_comm_get_unique_id(uint8_t *id /* SCANRS_COMM_ID_BYTES */);
 int scanrs_comm_create(const uint8_t *id, uint32_t rank, uint32_t world, scanrs_comm **out);
 void scanrs_comm_free(scanrs_comm *c);
+/* The group as the transport counts it - ranks and this rank from ncclCommCount / ncclCommUserRank (the single-process form: its own
+ * group) - and the sum all-reduces that went through this communicator so far (calls, payload bytes). Any pointer may be NULL. */
+int scanrs_comm_info(scanrs_comm *c, uint32_t *nranks, uint32_t *rank, uint64_t *n_allreduce, uint64_t *allreduce_bytes);
 int scanrs_mat_set_shard_comm(scanrs_mat *m, scanrs_comm *comm, uint32_t rank, uint32_t world, uint64_t outer_begin,
                               uint64_t outer_global);
 
@@ -381,6 +384,11 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *                       addressed by the record's own count and slot / ring row; no per-position weight exists in memory and a normalize
  *                       rewrites only the table. Counts above 15 are served by the overflow part, where the chain is evaluated per
  *                       nonzero. 0 = one f64 weight per record position, rewritten by every normalize (the form every other map takes)
+ *   "tile_flow" (0)     dense tile layout with tile_wtab 1: 1 = the FLOW form - tiles of 32 rows in a ring of 6 (the same 192 rows of LDS), one
+ *                       record stream per wave cut into rounds of 64 positions whatever tiles they belong to (about 1.01 positions per
+ *                       nonzero), no barrier: the ring is handed over at ticks inside the streams through counters in LDS. Same products to
+ *                       rounding; measured on par with the round-5 form, kept as an option. A map that does not
+ *                       separate, or more counts above 15 than the one-walk build's list holds, makes an orientation fall back to 0.
  *   "tile_big_list_cap" (0)  dense tile layout, one-walk build: entries of the list that carries the nonzeros with counts above 15 to the
  *                       overflow part (0: max(4 M, nnz / 64)); a matrix with more of them is built by the two-walk form instead.
  *   "tile_emit_staged" (1)  dense tile layout, diagnostic: 0 makes the emission of the record streams search its per-visit tables in global

@@ -710,6 +710,14 @@ class Comm:
         buf = (ctypes.c_uint8 * Comm.ID_BYTES).from_buffer_copy(uid)
         _check(_lib.scanrs_comm_create(buf, ctypes.c_uint32(rank), ctypes.c_uint32(world), ctypes.byref(self._c)))
 
+    def info(self) -> dict:
+        """`scanrs_comm_info`: ranks / this rank as RCCL itself counts them (ncclCommCount, ncclCommUserRank) and the sum all-reduces
+        that went through this communicator so far."""
+        n, r = ctypes.c_uint32(), ctypes.c_uint32()
+        calls, nbytes = ctypes.c_uint64(), ctypes.c_uint64()
+        _check(_lib.scanrs_comm_info(self._c, ctypes.byref(n), ctypes.byref(r), ctypes.byref(calls), ctypes.byref(nbytes)))
+        return {"rccl_nranks": int(n.value), "rccl_rank": int(r.value), "allreduce_calls": int(calls.value), "allreduce_bytes": int(nbytes.value)}
+
     def close(self):
         if getattr(self, "_c", None) is not None and self._c:
             _lib.scanrs_comm_free(self._c)
@@ -900,7 +908,7 @@ def host_sym_eig_topk(a, k):
 
 
 EXPORTED_SYMBOLS = [
-    "scanrs_last_error", "scanrs_device_available", "scanrs_version", "scanrs_mat_create", "scanrs_mat_create_unsorted", "scanrs_mat_create_device", "scanrs_mat_create_adaptive", "scanrs_knn", "scanrs_find_nn",
+    "scanrs_comm_info", "scanrs_last_error", "scanrs_device_available", "scanrs_version", "scanrs_mat_create", "scanrs_mat_create_unsorted", "scanrs_mat_create_device", "scanrs_mat_create_adaptive", "scanrs_knn", "scanrs_find_nn",
     "scanrs_mat_free", "scanrs_mat_view", "scanrs_mat_t", "scanrs_mat_shape", "scanrs_mat_nnz", "scanrs_mat_storage",
     "scanrs_mat_reset_map", "scanrs_mat_compose_scale_axis", "scanrs_mat_apply", "scanrs_mat_set_offset",
     "scanrs_mat_center", "scanrs_mat_scale", "scanrs_mat_scale_and_center", "scanrs_mat_sum_axis_u32",

@@ -34,6 +34,8 @@ struct Rccl {
     int (*CommDestroy)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;    // optional (scanrs_comm_info)
+    int (*CommUserRank)(void *, int *) = nullptr; // optional
 };
 Rccl &rccl() {
     static Rccl r;
@@ -62,6 +64,9 @@ Rccl &rccl() {
         } syms[] = {{(void **)&r.GetUniqueId, "ncclGetUniqueId"}, {(void **)&r.CommInitRank, "ncclCommInitRank"},
                     {(void **)&r.CommDestroy, "ncclCommDestroy"}, {(void **)&r.AllReduce, "ncclAllReduce"},
                     {(void **)&r.GetErrorString, "ncclGetErrorString"}};
+        r.CommCount = (int (*)(void *, int *))dlsym(r.h, "ncclCommCount");
+        r.CommUserRank = (int (*)(void *, int *))dlsym(r.h, "ncclCommUserRank");
+        (void)dlerror();
         for (auto &sy : syms) {
             *sy.slot = dlsym(r.h, sy.name);
             if (!*sy.slot && r.err.empty()) {
@@ -129,6 +134,7 @@ struct LocalGroup {
 
 struct scanrs_comm {
     uint32_t rank = 0, world = 1;
+    uint64_t n_allreduce = 0, allreduce_bytes = 0; // what went through this communicator (scanrs_comm_info)
     void *nccl = nullptr;                        // multi-process form
     std::shared_ptr<scanrs::LocalGroup> local;   // single-process form
 };
@@ -139,6 +145,8 @@ void launch_local_allreduce(hipStream_t s, void *const *bufs, uint32_t world, ui
 
 void comm_allreduce(Storage &st, scanrs_comm *c, void *d, uint64_t count, int dtype) {
     if (count == 0) return;
+    c->n_allreduce++;
+    c->allreduce_bytes += count * 8u;
     if (c->nccl) {
         Rccl &r = rccl();
         nccl_check(r.AllReduce(d, d, (size_t)count, dtype == 0 ? NCCL_FLOAT64 : NCCL_UINT64, NCCL_SUM, c->nccl, st.stream), "ncclAllReduce");
@@ -202,6 +210,35 @@ int scanrs_comm_create(const uint8_t *id, uint32_t rank, uint32_t world, scanrs_
         c->world = world;
         nccl_check(rccl().CommInitRank(&c->nccl, (int)world, u, (int)rank), "ncclCommInitRank"); // on the calling thread's current device
         *out = c.release();
+        return SCANRS_OK;
+    } catch (const Failure &e) {
+        return e.code;
+    }
+}
+
+// What the transport itself says about the group (bench.py prints it: the driver's scaling record can then show that RCCL saw all N
+// ranks): ranks and this rank as RCCL counts them (ncclCommCount / ncclCommUserRank; the single-process form: its own group), and
+// the sum all-reduces that went through so far.
+int scanrs_comm_info(scanrs_comm *c, uint32_t *nranks, uint32_t *rank, uint64_t *n_allreduce, uint64_t *allreduce_bytes) {
+    try {
+        if (!c) fail(SCANRS_ERR_ARGUMENT, "null communicator");
+        uint32_t n = c->world, r_ = c->rank;
+        if (c->nccl) {
+            Rccl &r = rccl();
+            int v = 0;
+            if (r.CommCount) {
+                nccl_check(r.CommCount(c->nccl, &v), "ncclCommCount");
+                n = (uint32_t)v;
+            }
+            if (r.CommUserRank) {
+                nccl_check(r.CommUserRank(c->nccl, &v), "ncclCommUserRank");
+                r_ = (uint32_t)v;
+            }
+        }
+        if (nranks) *nranks = n;
+        if (rank) *rank = r_;
+        if (n_allreduce) *n_allreduce = c->n_allreduce;
+        if (allreduce_bytes) *allreduce_bytes = c->allreduce_bytes;
         return SCANRS_OK;
     } catch (const Failure &e) {
         return e.code;
