@@ -52,6 +52,7 @@ WSRC = os.environ.get("GEN_WSRC") or "stream"  # where a position's weight comes
 TAB = WSRC in ("tabo", "tabi")
 SYNC = os.environ.get("GEN_SYNC") or "bar"  # how the 8 waves of an item hand ring buffers to one another: bar = one s_barrier per visit; cnt = readiness / release counters in LDS (table forms only, see sync_* below)
 CNT = SYNC == "cnt"
+ONCE = (os.environ.get("GEN_ONCE") or "0") != "0"  # barrier form: a visit's tile is staged by its FIRST round only (the default re-stages it in every round of the visit so that one vmcnt count fits every boundary; a visit of more than 4 chunks then moves its 38 KB twice)
 assert SYNC in ("bar", "cnt") and (not CNT or WSRC in ("tabo", "tabi"))
 SPIN_MAX = int(os.environ.get("GEN_SPIN_MAX") or (1 << 22))  # polls of a counter before a wave gives up waiting (no hang on a bug: the result is then wrong and the parity tests say so)
 assert WSRC in ("stream", "tabo", "tabi")
@@ -528,11 +529,18 @@ def gen():
             if CNT:
                 if b == NB - 4:
                     stage_block("b")
+            elif ONCE:
+                if b == NB - 4:
+                    a("s_bitcmp1_b32 s28, 8")
+                    a("s_cbranch_scc0 LONCEX%=")
+                    for i_ in range(5):
+                        dma(i_, o)
+                    a("LONCEX%=:")
             elif b >= NB - 4 and not DMA_TOP:
                 dma(b - (NB - 4), o)
             if b + 2 < NB:
                 batch_AL(b + 2, o)
-        if not DMA_TOP and not CNT:
+        if not DMA_TOP and not CNT and not ONCE:
             dma(4, o)
 
     def rotate():
@@ -621,6 +629,14 @@ def gen():
             a(f"ds_read_b32 v31, v31 offset:{CNT_READY}")
             # the next round's weights and records; every staging load but the five of THIS round - which only a visit's first round has
             a("s_bitcmp1_b32 s28, 8")
+            a("s_cbranch_scc0 LV0%=")
+            a("s_waitcnt vmcnt(5)")
+            a("s_branch LV1%=")
+            a("LV0%=:")
+            a("s_waitcnt vmcnt(0)")
+            a("LV1%=:")
+        elif ONCE:
+            a("s_bitcmp1_b32 s28, 8")                    # only a visit's first round has five staging loads behind the next round's weights
             a("s_cbranch_scc0 LV0%=")
             a("s_waitcnt vmcnt(5)")
             a("s_branch LV1%=")
