@@ -674,6 +674,111 @@ static void jacobi_svd_tall(std::vector<double> A, size_t rows, int n, std::vect
     }
 }
 
+// Rayleigh-Ritz when requested components reach the numerical rank of the projection T and T is SHARDED (or too large to take to
+// the host): the reference's svddc on T (bk_svd.rs:105,134; rand_svd.rs:96,118) still returns accurate small singular values
+// and a complete orthonormal set, and so must this (round 5 refused with SCANRS_ERR_NUMERICAL). Everything is decided from
+// all-reduced Gram matrices, which every rank holds bit for bit - all ranks take the same branches and meet in the same
+// collectives - in LEVELS: the eigenvectors of G = T^T T with w_j > 1e-12 w_1 are taken as they are (the accuracy the regular path
+// has); the rest of the spectrum is looked at again through T B, B = the complement's basis, recomputed from T itself so that
+// its Gram matrix is accurate at ITS scale; directions whose eigenvalue lies below the rounding floor of T (1e-28 w_1) are exact
+// zeros: sigma = 0, the S-side vectors any orthonormal completion inside the complement, the T-side vectors a fixed pseudo-random
+// function of (global row, column) made orthogonal to the columns found (two projections) and to each other (CholeskyQR). One
+// CholeskyQR over all k T-side columns polishes what sigma_1 / sigma_j lost.
+static void ritz_deficient_by_levels(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint64_t ds, const double *T, uint32_t ldt, uint64_t dt, bool t_sharded,
+                                     uint32_t k, const std::vector<double> &G0, double *dS, double *dT, uint32_t ldk, double *hSigma) {
+    Tick tk("ritz: rank-deficient projection on a sharded side, by levels of the reduced Gram matrix");
+    std::vector<double> B((size_t)q * q, 0.0); // q x m, row-major: the current complement's orthonormal basis (level 0: the identity)
+    for (uint32_t i = 0; i < q; i++) B[(size_t)i * q + i] = 1.0;
+    uint32_t m = q, done = 0;
+    std::vector<double> Gm = G0, E((size_t)q * k, 0.0), Es((size_t)q * k, 0.0);
+    double w_first = 0.0;
+    std::vector<double> w, Z;
+    for (int level = 0; level < 4 && done < k && m > 0; level++) {
+        w.assign(m, 0.0);
+        Z.assign((size_t)m * m, 0.0);
+        for (uint32_t i = 0; i < m; i++)
+            for (uint32_t j = i + 1; j < m; j++) {
+                const double a = 0.5 * (Gm[(size_t)i * m + j] + Gm[(size_t)j * m + i]);
+                if (!std::isfinite(a)) fail(SCANRS_ERR_NUMERICAL, "Rayleigh-Ritz: non-finite Gram matrix");
+                Gm[(size_t)i * m + j] = Gm[(size_t)j * m + i] = a;
+            }
+        if (!sym_eig(Gm.data(), (int)m, w.data(), Z.data())) fail(SCANRS_ERR_NUMERICAL, "eigensolver did not converge");
+        if (level == 0) w_first = w[0];
+        if (!(w[0] > 1e-28 * w_first) || !(w_first > 0.0)) break; // what is left is rounding noise of T: exact zeros from here on
+        uint32_t r = 0;
+        while (r < m && w[r] > 1e-12 * w[0] && w[r] > 1e-28 * w_first) r++;
+        const uint32_t take = std::min(k - done, r);
+        for (uint32_t j = 0; j < take; j++) { // E[:, done + j] = B Z[:, j]
+            const double sig = std::sqrt(w[j]);
+            hSigma[done + j] = sig;
+            for (uint32_t i = 0; i < q; i++) {
+                double a = 0.0;
+                for (uint32_t t = 0; t < m; t++) a += B[(size_t)i * m + t] * Z[(size_t)t * m + j];
+                E[(size_t)i * k + done + j] = a;
+                Es[(size_t)i * k + done + j] = a / sig;
+            }
+        }
+        done += take;
+        if (done == k || r == m) break;
+        // the complement of the directions this level resolved: B <- B Z[:, r:], its projection recomputed from T
+        const uint32_t m2 = m - r;
+        std::vector<double> B2((size_t)q * m2);
+        for (uint32_t i = 0; i < q; i++)
+            for (uint32_t j = 0; j < m2; j++) {
+                double a = 0.0;
+                for (uint32_t t = 0; t < m; t++) a += B[(size_t)i * m + t] * Z[(size_t)t * m + r + j];
+                B2[(size_t)i * m2 + j] = a;
+            }
+        B.swap(B2);
+        m = m2;
+        const uint32_t ldm = even_up(m);
+        double *T2 = c.dev("ritz_lvl_t", (size_t)dt * ldm);
+        gemm_hostw(c, T, ldt, q, B, m, dt, 1.0, 0.0, T2, ldm, "ritz_lvl_b");
+        gram_host(c, T2, ldm, m, T2, ldm, m, dt, t_sharded, Gm);
+        w.clear();
+    }
+    const uint32_t nz = k - done; // exact zeros
+    if (nz) {
+        // S side: any orthonormal vectors of the complement that were not taken. If the last level was decomposed (w non-empty) its
+        // eigenvectors beyond the taken ones, else the complement's basis itself.
+        for (uint32_t j = 0; j < nz; j++) {
+            hSigma[done + j] = 0.0;
+            for (uint32_t i = 0; i < q; i++) {
+                double a = 0.0;
+                if (!w.empty()) {
+                    const uint32_t col = std::min<uint32_t>(m - 1u, (uint32_t)(m - nz + j)); // the smallest eigenvalues' directions: never among the taken ones (taken + nz <= m)
+                    for (uint32_t t = 0; t < m; t++) a += B[(size_t)i * m + t] * Z[(size_t)t * m + col];
+                } else {
+                    a = B[(size_t)i * m + std::min<uint32_t>(m - 1u, j)];
+                }
+                E[(size_t)i * k + done + j] = a;
+                Es[(size_t)i * k + done + j] = 0.0;
+            }
+        }
+    }
+    double *dE = c.dev("ritz_e", (size_t)q * k);
+    c.h2d(dE, E.data(), E.size());
+    launch_gemm_nn(c.st, Q, ldq, q, dE, k, k, ds, 1.0, 0.0, nullptr, 0, dS, ldk);
+    double *dEs = c.dev("ritz_es", (size_t)q * k);
+    c.h2d(dEs, Es.data(), Es.size());
+    launch_gemm_nn(c.st, T, ldt, q, dEs, k, k, dt, 1.0, 0.0, nullptr, 0, dT, ldk); // (the zero columns of Es leave zero columns)
+    if (nz) {
+        const uint64_t row0 = t_sharded ? c.st.shard.outer_begin : 0;
+        const uint32_t ldr = even_up(nz);
+        double *R = c.dev("ritz_lvl_r", (size_t)dt * ldr), *Rtmp = c.dev("ritz_lvl_rtmp", (size_t)dt * ldr);
+        launch_fill_hash(c.st, R, ldr, dt, row0, 0, nz, 0x71a2d3c5ull + k);
+        for (int pass = 0; pass < 2 && done; pass++) { // R -= U1 (U1^T R), U1 = the columns found
+            std::vector<double> C;
+            gram_host(c, dT, ldk, done, R, ldr, nz, dt, t_sharded, C);
+            gemm_hostw(c, dT, ldk, done, C, nz, dt, -1.0, 1.0, R, ldr, "ritz_lvl_c");
+        }
+        orth_cholqr(c, R, Rtmp, ldr, nz, dt, t_sharded, nullptr, 0, false);
+        launch_copy_cols(c.st, R, ldr, dT + done, ldk, dt, nz);
+    }
+    double *ptmp = c.dev("ritz_lvl_ptmp", (size_t)dt * ldk);
+    orth_cholqr(c, dT, ptmp, ldk, k, dt, t_sharded, nullptr, 0, false); // polish
+}
+
 // Rayleigh-Ritz finish shared by svd_bk and svd_rand: given an orthonormal Q on side S (dimension ds,
 // q columns), T = op(Q) on the other side (dimension dt), return the top-k triplets.
 //   side_S_vectors = Q * E, side_T_vectors = T * E * Sigma^-1, sigma = sqrt(eig(T^T T)).
@@ -702,8 +807,19 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
     // is still accurate and orthonormal; the Gram route is not. Small problems go through a one-sided Jacobi SVD of T on
     // the host; large ones are refused rather than answered with zero or inaccurate vectors.
     if (!(w[k - 1] > 1e-12 * w[0]) || !(w[0] > 0.0)) {
-        if (t_sharded || (double)dt * q > 3.0e7)
-            fail(SCANRS_ERR_NUMERICAL, "requested singular values reach the numerical rank of the projection (sigma_%u / sigma_1 < 1e-6)", k);
+        if (t_sharded || (double)dt * q > 3.0e7) {
+            ritz_deficient_by_levels(c, Q, ldq, q, ds, T, ldt, dt, t_sharded, k, G, dS, dT, ldk, hSigma);
+            if (hS) download_panel(c, dS, ldk, ds, k, hS);
+            if (hT) download_panel(c, dT, ldk, dt, k, hT);
+            c.sync();
+            c.st.pca_dev.k = k;
+            c.st.pca_dev.ld_u = c.st.pca_dev.ld_v = ldk;
+            c.st.pca_dev.u = dS;
+            c.st.pca_dev.rows_u = ds;
+            c.st.pca_dev.v = dT;
+            c.st.pca_dev.rows_v = dt;
+            return;
+        }
         Tick tk("ritz: host Jacobi SVD of T (rank-deficient)");
         std::vector<double> hTm((size_t)dt * q), Uj, Sj, Vj;
         download_panel(c, T, ldt, dt, q, hTm.data());
