@@ -93,12 +93,23 @@ def wreg(p):
     return f"v[{W0 + 2 * c}:{W0 + 2 * c + 1}]"
 
 
+# timing experiment (wrong results): the positions p with p % 4 in SHARE do not read their panel row but use the row registers of the
+# position in front of them - what the stream would cost if that share of the nonzeros found its row already in registers (a wave's
+# nonzeros that name the same panel row: 61 % of them have such a partner at 32 cells x 3 %)
+SHARE = {int(x) for x in (os.environ.get("GEN_SHARE") or "").split(",") if x}
+RB = BP - len(SHARE)  # row reads per batch
+
+
 def batch_AL(b, out):
     for j in range(BP):
         p = b * BP + j
+        if j in SHARE:
+            continue
         out.append(f"v_mad_u32_u16 {ad(p)}, {rec(p)}, v37, v36 op_sel:[1,0,0,0]")
     for j in range(BP):
         p = b * BP + j
+        if j in SHARE:
+            continue
         out.append(f"ds_read_b128 {xq(p)}, {ad(p)}")
 
 
@@ -111,8 +122,9 @@ def batch_F(b, out, tail=False):
         else:
             out.append(f"s_set_gpr_idx_idx {r}")
         q = p % 16
-        out.append(f"v_fmac_f64_dpp v[{ACC0}:{ACC0 + 1}], {wreg(p)}, {xr(p, 0)} row_newbcast:{q} row_mask:0xf bank_mask:0xf")
-        out.append(f"v_fmac_f64_dpp v[{ACC0 + 2}:{ACC0 + 3}], {wreg(p)}, {xr(p, 1)} row_newbcast:{q} row_mask:0xf bank_mask:0xf")
+        ps = p - 1 if j in SHARE else p  # (experiment: the row of the position in front)
+        out.append(f"v_fmac_f64_dpp v[{ACC0}:{ACC0 + 1}], {wreg(p)}, {xr(ps, 0)} row_newbcast:{q} row_mask:0xf bank_mask:0xf")
+        out.append(f"v_fmac_f64_dpp v[{ACC0 + 2}:{ACC0 + 3}], {wreg(p)}, {xr(ps, 1)} row_newbcast:{q} row_mask:0xf bank_mask:0xf")
     out.append("s_set_gpr_idx_off")
 
 
@@ -515,7 +527,7 @@ def gen():
         for b in range(NB):
             a(f"LS{b}%=:")
             last = b == NB - 1
-            a(f"s_waitcnt lgkmcnt({BP})" if not last else "s_waitcnt lgkmcnt(0)")
+            a(f"s_waitcnt lgkmcnt({RB})" if not last else "s_waitcnt lgkmcnt(0)")
             if last:
                 # the last batch names its accumulators through copies, so that slot 3 can be reloaded before its FMAs instead of behind them
                 for j_ in range(BP):
@@ -1036,7 +1048,7 @@ def gen_flow():
             a(f"s_cbranch_scc0 LTK{j}%=")
             a(f"LTKR{j}%=:")
         last = b == NB - 1
-        a(f"s_waitcnt lgkmcnt({BP})" if not last else "s_waitcnt lgkmcnt(0)")
+        a(f"s_waitcnt lgkmcnt({RB})" if not last else "s_waitcnt lgkmcnt(0)")
         if b % BPC == FL_GUARD_BATCHES - 2 and "t" not in FSKIP:
             # phase B of a tick in front of this chunk: its counter read lies behind this batch's rows and in front of the next one's, the
             # wait above has covered it; the rows of the batch after the next are issued below, behind the check
