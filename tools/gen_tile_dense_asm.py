@@ -899,22 +899,31 @@ def flow_tick_a(out, tag):
         a(f"LC{tag}0%=:")
         a("s_waitcnt vmcnt(0)")
         a(f"LC{tag}X%=:")
-    flow_div6(out, "s13", "s14", "s31", "s30")      # q, b
-    a("s_lshl_b32 s15, s14, 2")
-    a("s_add_u32 s15, s15, s19")                    # P[b]
-    a("v_mov_b32 v33, s15")
-    a("s_mov_b64 exec, 1")
-    a(f"ds_add_u32 v33, v34 offset:{FL_P}")         # this wave is past K(v)
-    a("s_mov_b64 exec, -1")
-    a("s_sub_u32 s15, s15, 4")                      # P[(v - 1) % 6]: the counter in front, or the last one
-    a("s_add_u32 s16, s19, 20")
-    a("s_cmp_eq_u32 s14, 0")
-    a("s_cselect_b32 s15, s16, s15")
-    a("s_cselect_b32 s16, 0, 1")
-    a("v_mov_b32 v32, s15")
-    a(f"ds_read_b32 v32, v32 offset:{FL_P}")
-    a("s_add_u32 s13, s13, s16")                    # (v - 1) / 6 + 1 = q + 1, or q when b = 0 (0 for v = 0: nothing to wait for)
-    a("s_lshl_b32 s13, s13, 3")
+    if "m" in FSKIP:  # timing experiment: no address / threshold arithmetic (what a tick would cost with that work done in the shadow of the FMAs in front of it)
+        a("v_mov_b32 v33, s19")
+        a("s_mov_b64 exec, 1")
+        a(f"ds_add_u32 v33, v34 offset:{FL_P}")
+        a("s_mov_b64 exec, -1")
+        a("v_mov_b32 v32, s19")
+        a(f"ds_read_b32 v32, v32 offset:{FL_P}")
+        a("s_mov_b32 s13, 0")
+    else:
+        flow_div6(out, "s13", "s14", "s31", "s30")      # q, b
+        a("s_lshl_b32 s15, s14, 2")
+        a("s_add_u32 s15, s15, s19")                    # P[b]
+        a("v_mov_b32 v33, s15")
+        a("s_mov_b64 exec, 1")
+        a(f"ds_add_u32 v33, v34 offset:{FL_P}")         # this wave is past K(v)
+        a("s_mov_b64 exec, -1")
+        a("s_sub_u32 s15, s15, 4")                      # P[(v - 1) % 6]: the counter in front, or the last one
+        a("s_add_u32 s16, s19, 20")
+        a("s_cmp_eq_u32 s14, 0")
+        a("s_cselect_b32 s15, s16, s15")
+        a("s_cselect_b32 s16, 0, 1")
+        a("v_mov_b32 v32, s15")
+        a(f"ds_read_b32 v32, v32 offset:{FL_P}")
+        a("s_add_u32 s13, s13, s16")                    # (v - 1) / 6 + 1 = q + 1, or q when b = 0 (0 for v = 0: nothing to wait for)
+        a("s_lshl_b32 s13, s13, 3")
     # this wave's KBs of tile v + 2: chunks wave, wave + 8, ... below the tile's end - s17 of them, 3 at 100 columns (4 for wave 0); the first form
     # issued 4 from every wave, the surplus rewriting the tile's last KB: 32 loads for 25 KB (s12 / s32 / s33 / s100: the chunks' offsets
     # inside a tile; v29 / v30 / v31 / v35: the same + 16 x lane)
