@@ -52,6 +52,8 @@ WSRC = os.environ.get("GEN_WSRC") or "stream"  # where a position's weight comes
 TAB = WSRC in ("tabo", "tabi")
 SYNC = os.environ.get("GEN_SYNC") or "bar"  # how the 8 waves of an item hand ring buffers to one another: bar = one s_barrier per visit; cnt = readiness / release counters in LDS (table forms only, see sync_* below)
 CNT = SYNC == "cnt"
+ALFIRST = (os.environ.get("GEN_ALFIRST") or "1") != "0"  # a round issues the row reads of its first two batches BEFORE it spreads its weights and starts the next round's loads: that work (45 instructions) then runs beside the reads' latency instead of in front of it - 0.5 ms per pass (round 6: 14.4 / 15.7 -> 13.9 / 15.2 on one box); 0: the round-5 order. No effect on the flow loop (its rounds have no barrier in front of them to line the waves up)
+ALFIRST = ALFIRST and not CNT  # (the counter form's round top carries a label and an early poll of its own: left in the round-5 order)
 ONCE = (os.environ.get("GEN_ONCE") or "0") != "0"  # barrier form: a visit's tile is staged by its FIRST round only (the default re-stages it in every round of the visit so that one vmcnt count fits every boundary; a visit of more than 4 chunks then moves its 38 KB twice)
 assert SYNC in ("bar", "cnt") and (not CNT or WSRC in ("tabo", "tabi"))
 SPIN_MAX = int(os.environ.get("GEN_SPIN_MAX") or (1 << 22))  # polls of a counter before a wave gives up waiting (no hang on a bug: the result is then wrong and the parity tests say so)
@@ -587,8 +589,9 @@ def gen():
         a("LROUND%=:")
         if STAMP:
             a("s_memtime s[2:3]")
-        spread_weights()
-        top()
+        if not ALFIRST:
+            spread_weights()
+            top()
         nch = "s29"
         if CNT:
             a("s_and_b32 s30, s28, 0xff")
@@ -602,6 +605,9 @@ def gen():
         a(f"s_cmp_eq_u32 {nch}, 1")
         a("s_cbranch_scc1 LPRO3%=")
         # an empty round (a visit nobody has work in yet: the first two of a part)
+        if ALFIRST:
+            spread_weights()
+            top()
         for c in range(4):
             reload_slot(c, o)
         if CNT:
@@ -614,11 +620,17 @@ def gen():
         # prologues: the slots this round does not enter, then the rows of its first two batches
         for c in (3, 2, 1, 0):
             a(f"LPRO{c}%=:")
-            for cc in range(c):
-                reload_slot(cc, o)
+            if not ALFIRST:
+                for cc in range(c):
+                    reload_slot(cc, o)
             batch_AL(BPC * c, o)
             batch_AL(BPC * c + 1, o)
-            if c != 0:
+            if ALFIRST:
+                spread_weights()
+                top()
+                for cc in range(c):  # (behind top(): it says where the next round's slots come from)
+                    reload_slot(cc, o)
+            if c != 0 or ALFIRST:
                 a(f"s_branch LS{BPC * c}%=")
         batches()
         # ---- boundary ----
@@ -826,16 +838,16 @@ def flow_div6(out, q, r, x, tmp):
 
 
 def flow_gather(out, vs_from_header):
-    """v[26:27] <- the table entries of the 64 records in v28 (temporaries v56-v58: row registers, idle at a round's top). tabi: a
+    """v[26:27] <- the table entries of the 64 records in v28 (temporaries: v28 itself, v32 / v33 - a tick's registers, idle at a round's top). tabi: a
     round's records name tiles vs - 2 .. vs + 3 (vs = the tile the round's first tick opens; at most 4 ticks per round), 6 consecutive
     ones, so the ring buffer (ring row / 32) says which: with u = vs - 2 = 6 q + m, buffer b holds tile 6 q + b when b >= m and
     6 (q + 1) + b otherwise. vs_from_header: the NEXT round's (s31 + the ticks of the current one); else the current s31 (entry)."""
     a = out.append
     if WSRC == "tabo":
-        a("v_and_b32 v56, 0xfc, v28")               # 4 x slot
-        a("v_bfe_u32 v58, v28, 8, 8")               # count
-        a("v_lshlrev_b32 v58, 3, v58")
-        a("v_lshl_add_u32 v56, v56, 5, v58")        # slot x 128 + count x 8
+        a("v_and_b32 v32, 0xfc, v28")               # 4 x slot
+        a("v_bfe_u32 v28, v28, 8, 8")               # count (the records are done with: in place)
+        a("v_lshlrev_b32 v28, 3, v28")
+        a("v_lshl_add_u32 v32, v32, 5, v28")        # slot x 128 + count x 8
     else:
         if vs_from_header:
             a("s_bfe_u32 s30, s28, 0x40008")
@@ -847,17 +859,17 @@ def flow_gather(out, vs_from_header):
         flow_div6(out, "m0", "s30", "s30", "vcc_lo")  # q, m
         a("s_mul_i32 m0, m0, 0x600")                # 192 q rows, in bytes
         a("s_lshl_b32 s30, s30, 21")                # (32 m) << 16: first ring row of buffer m, as a record
-        a("v_bfe_u32 v58, v28, 8, 8")               # count
-        a("v_mul_lo_u32 v58, v58, s101")            # plane
-        a("v_lshrrev_b32 v56, 13, v28")             # ring row x 8
-        a("v_mov_b32 v57, 0x600")
+        a("v_lshrrev_b32 v32, 13, v28")             # ring row x 8
+        a("v_mov_b32 v33, 0x600")
         a("v_cmp_gt_u32 vcc, s30, v28")             # a buffer below m: the ring's next turn
-        a("v_cndmask_b32 v57, 0, v57, vcc")
-        a("v_add3_u32 v56, v56, v58, v57")
-        a("v_add_u32 v56, m0, v56")
-    a("v_add_co_u32 v56, vcc, v38, v56")
-    a("v_addc_co_u32 v57, vcc, 0, v39, vcc")
-    a("global_load_dwordx2 v[26:27], v[56:57], off")
+        a("v_cndmask_b32 v33, 0, v33, vcc")
+        a("v_bfe_u32 v28, v28, 8, 8")               # count (the records are done with: in place)
+        a("v_mul_lo_u32 v28, v28, s101")            # plane
+        a("v_add3_u32 v32, v32, v28, v33")
+        a("v_add_u32 v32, m0, v32")
+    a("v_add_co_u32 v32, vcc, v38, v32")
+    a("v_addc_co_u32 v33, vcc, 0, v39, vcc")
+    a("global_load_dwordx2 v[26:27], v[32:33], off")
 
 
 def flow_spin(out, tag):
@@ -1033,11 +1045,16 @@ def gen_flow():
     a("v_mov_b32 v34, 1")                        # (what a tick adds to a counter)
     a("s_waitcnt vmcnt(0)")                      # (round 0's records as a vector; the caller's two tiles)
     flow_gather(o, vs_from_header=False)         # weights of round 0
+    a("v_subrev_u32 v33, s12, v29")              # (the gather used v33)
+    a("v_lshrrev_b32 v33, 2, v33")               # 4 x lane
     a("global_load_dword v28, v33, s[20:21]")    # the records of round 1
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")
     a("s_barrier")                               # the only one: it publishes the preset counters, the row of zeros and the first two tiles
 
     a("LROUND%=:")
+    if ALFIRST:
+        batch_AL(0, o)
+        batch_AL(1, o)
     tab_spread(o)
     a("s_add_u32 s29, s29, 1")
     a("s_load_dword s34, s[22:23], 0x4")         # the next round's header
@@ -1045,8 +1062,9 @@ def gen_flow():
     a("v_subrev_u32 v33, s12, v29")              # 16 x lane
     a("v_lshrrev_b32 v33, 2, v33")               # 4 x lane
     a("global_load_dword v28, v33, s[20:21] offset:256")  # the records of the round after it (this load also pulls them into L2 for their scalar loads)
-    batch_AL(0, o)
-    batch_AL(1, o)
+    if not ALFIRST:
+        batch_AL(0, o)
+        batch_AL(1, o)
     for b in range(NB):
         a(f"LS{b}%=:")
         j = b // BPC
