@@ -53,6 +53,7 @@ TAB = WSRC in ("tabo", "tabi")
 SYNC = os.environ.get("GEN_SYNC") or "bar"  # how the 8 waves of an item hand ring buffers to one another: bar = one s_barrier per visit; cnt = readiness / release counters in LDS (table forms only, see sync_* below)
 CNT = SYNC == "cnt"
 ALFIRST = (os.environ.get("GEN_ALFIRST") or "1") != "0"  # a round issues the row reads of its first two batches BEFORE it spreads its weights and starts the next round's loads: that work (45 instructions) then runs beside the reads' latency instead of in front of it - 0.5 ms per pass (round 6: 14.4 / 15.7 -> 13.9 / 15.2 on one box); 0: the round-5 order. No effect on the flow loop (its rounds have no barrier in front of them to line the waves up)
+ROTFIRST = (os.environ.get("GEN_ROTFIRST") or "0") != "0" and not CNT  # experiment: the boundary's register rotation (and its wait for the next round's records) in FRONT of the visit's barrier instead of behind it
 ALFIRST = ALFIRST and not CNT  # (the counter form's round top carries a label and an early poll of its own: left in the round-5 order)
 ONCE = (os.environ.get("GEN_ONCE") or "0") != "0"  # barrier form: a visit's tile is staged by its FIRST round only (the default re-stages it in every round of the visit so that one vmcnt count fits every boundary; a visit of more than 4 chunks then moves its 38 KB twice)
 assert SYNC in ("bar", "cnt") and (not CNT or WSRC in ("tabo", "tabi"))
@@ -689,6 +690,13 @@ def gen():
             a("s_add_u32 s30, s30, s19")
             a(f"s_add_u32 s29, s30, {CNT_READY}")
             a("LNS%=:")
+        if ROTFIRST:
+            rotate()
+            a("s_bitcmp1_b32 s28, 8")
+            a("s_cbranch_scc0 LROUND%=")
+            advance()
+            stamp_barrier_end()
+            a("s_branch LROUND%=")
         a("s_bitcmp1_b32 s34, 8")
         a("s_cbranch_scc0 LNB%=")
         if CNT:
