@@ -89,7 +89,7 @@ void stage_mark(const char *what, long a, long b) {
     r.b = b;
     r.t = std::chrono::steady_clock::now();
     if (trace_level() != 2) return;
-    fprintf(stderr, "[scanrs stage] %s %ld %ld\n", what, a, b);
+    fprintf(stderr, "[scanrs stage] %.3f %s %ld %ld\n", std::chrono::duration<double, std::milli>(r.t.time_since_epoch()).count(), what, a, b);
     fflush(stderr);
 }
 double sync_timeout_s() { return g_sync_timeout_s.load(std::memory_order_relaxed); }
@@ -1918,7 +1918,8 @@ static void prefetch_for_pca(scanrs_mat *m) {
 }
 
 int scanrs_normalize(scanrs_mat *m, int normalization, const uint32_t *size_factors) {
-    return guard([&] { // normalize / normalize_with_size_factor, scan-rs/src/normalization.rs:46-102
+    return guard([&] {
+        stage_mark("normalize enter"); // normalize / normalize_with_size_factor, scan-rs/src/normalization.rs:46-102
         if (!m) fail(SCANRS_ERR_ARGUMENT, "null handle");
         const bool pca_next = normalization >= SCANRS_NORM_CELLRANGER && normalization <= SCANRS_NORM_LOG_TRANSFORM;
         if (pca_next && m->st->side_build == 1) prefetch_for_pca(m); // 1: beside the normalisation passes; 2: right behind them

@@ -799,6 +799,7 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
         if (!sym_eig_topk(G.data(), (int)q, (int)k, w.data(), Z.data()))
             fail(SCANRS_ERR_NUMERICAL, "eigensolver did not converge");
     }
+    stage_mark("ritz eig done");
     const uint32_t ldk = even_up(k);
     double *dS = c.dev("ritz_s", (size_t)ds * ldk);
     double *dT = c.dev("ritz_t", (size_t)dt * ldk);
@@ -945,6 +946,7 @@ static int pca_bk_impl(scanrs_mat *m, uint32_t k, double k_multiplier, uint32_t 
                        const scanrs_snoop *snoop, double *u, double *s, double *v, bool device_factor) {
     Tick tk_all("bk: total");
     Ctx c(m);
+    stage_mark("bk setup");
     // work is queued far ahead of the device here: whatever ends this call early (cancellation, a numerical failure) waits for
     // both streams before the scratch buffers change hands
     struct Drain {
