@@ -32,13 +32,14 @@ __global__ void ref_kernel(const double *X, uint32_t ldx, uint32_t n, const doub
 template <int NT>
 static void run(const double *X, uint32_t ldx, uint32_t n, const double *Wt, uint32_t n_pad, uint32_t m, uint64_t rows, double *Out, uint32_t ldo, hipStream_t s) {
     const uint64_t per_wg = 4ull * 16 * SKD_MT;
-    hipLaunchKernelGGL(gemm_skinny_direct_kernel<NT>, dim3((unsigned)((rows + per_wg - 1) / per_wg)), dim3(256), 0, s, X, ldx, n, Wt, n_pad, m, rows, 1.0, 0.0,
+    hipLaunchKernelGGL(gemm_skinny_direct_kernel<NT>, dim3((unsigned)((rows + per_wg - 1) / per_wg), (m + 16 * NT - 1) / (16 * NT)), dim3(256), 0, s, X, ldx, n, Wt, n_pad, m, rows, 1.0, 0.0,
                        nullptr, 0, Out, ldo, nullptr);
 }
 int main(int argc, char **argv) {
     const uint64_t rows = argc > 1 ? strtoull(argv[1], 0, 10) : 1000000;
     const uint32_t n = argc > 2 ? atoi(argv[2]) : 500, m = argc > 3 ? atoi(argv[3]) : 50;
-    const uint32_t ldx = (n + 1) & ~1u, ldo = (m + 1) & ~1u, n_pad = (n + 15) / 16 * 16, nt = (m + 15) / 16, m_pad = nt * 16;
+    const uint32_t ldx = argc > 4 ? atoi(argv[4]) : ((n + 1) & ~1u), ldo = (m + 1) & ~1u, n_pad = (n + 15) / 16 * 16;
+    const uint32_t groups = (m + 63) / 64, nt = ((m + 15) / 16 + groups - 1) / groups, m_pad = nt * 16 * groups;
     double *X, *W, *Wt, *Out, *Ref;
     CK(hipMalloc(&X, rows * ldx * 8));
     CK(hipMalloc(&W, (size_t)n * m * 8));

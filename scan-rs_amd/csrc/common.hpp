@@ -375,6 +375,7 @@ struct Storage {
     int col_moments = 1;                  // per-axis sums of a log-normalized map from the copy whose OUTER vectors are summed over (per-cell table + LDS fixed-point scatter) when eligible; 0: always the ordinary pass
     int device_factor = 1;                // svd_bk: CholeskyQR factors and the coefficient bookkeeping on the device, no host round trip per orthonormalisation (0: host)
     unsigned d2h_threads = 4;             // host threads that empty the pinned ring of a large result download
+    int gemm_direct = 1;                  // dense X W with results of <= 128 columns: operands straight from memory into the MFMA registers (0: the LDS-tiled kernels)
     double reuse_cmax = 1e5;              // svd_bk: coefficient bound above which a projection column is recomputed directly
     int materialize = 1;                  // keep the map prefix's values per nonzero on the short-outer copy (SCANRS_MATERIALIZE=0: off)
     ~Storage();
@@ -468,6 +469,9 @@ bool gram_tiled_ok(uint32_t n, uint32_t m, uint64_t rows);
 bool gemm_tiled_ok(uint32_t n, uint32_t m, uint64_t rows);
 void launch_gram_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *Y, uint32_t ldy, uint32_t m,
                        uint64_t rows, double *C);
+bool gemm_direct_ok(const double *X, uint32_t ldx, uint32_t n, uint32_t m, uint64_t rows);
+void launch_gemm_direct(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *W, uint32_t ldw, uint32_t m, uint64_t rows,
+                        double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo);
 void launch_gemm_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *W, uint32_t ldw, uint32_t m,
                        uint64_t rows, double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo);
 void launch_copy_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows, uint32_t l);

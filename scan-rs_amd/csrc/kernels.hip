@@ -2163,6 +2163,10 @@ void launch_gemm_nn(Storage &st, const double *X, uint32_t ldx, uint32_t n, cons
                     uint32_t ldo) {
     if (rows == 0 || m == 0) return;
     if (ldx & 1u) fail(SCANRS_ERR_ARGUMENT, "gemm: ldx must be even");
+    if (st.gemm_direct && gemm_direct_ok(X, ldx, n, m, rows)) {
+        launch_gemm_direct(st, X, ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
+        return;
+    }
     const bool side = st.dense_side_no_lds && ((st.aux_stream && st.stream == st.aux_stream) || (st.aux2_stream && st.stream == st.aux2_stream));
     if (!side && gemm_tiled_ok(n, m, rows)) {
         launch_gemm_tiled(st, X, ldx, n, W, ldw, m, rows, alpha, beta, Cin, ldc, Out, ldo);
