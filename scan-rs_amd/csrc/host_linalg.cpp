@@ -451,7 +451,8 @@ bool sym_eig_topk(const double *a_in, int n, int k, double *w, double *z) {
     constexpr int VS = 4;
     const int T_env = global_options().eig_threads >= 4 ? 4 : (global_options().eig_threads >= 2 ? 2 : 1);
     // measured on the MI355X host (256 cores): n = 1000: 48.6 -> 31 ms with 4 threads; n = 500: 6.1 -> 7.8 ms (the 2 MB matrix
-    // lives in one core's L2 and the three barriers per step cost more than the split saves) -> team from n = 768 on
+    // lives in one core's L2 and the three barriers per step cost more than the split saves; round 6, another box: 6.9 -> 9.8 (2 threads) /
+    // 11.5 (4)) -> team from n = 768 on
     int T = (n >= 768 && std::thread::hardware_concurrency() >= 8) ? T_env : 1;
     HostTeam *pool = T > 1 ? HostTeam::acquire(T) : nullptr;
     if (!pool) T = 1;
@@ -784,27 +785,69 @@ bool sym_eig_topk(const double *a_in, int n, int k, double *w, double *z) {
         for (int i = 0; i < n; i++) xj[i] = x[i];
     }
     lap("inverse iteration");
-    // back-transform: Z = H_0 H_1 ... H_{n-3} X, all k vectors at once in the n x k output layout (row i = entry i
-    // of every vector): per reflector one k-wide sum of scaled rows and one k-wide update of each row
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < k; j++) z[(size_t)i * k + j] = X[(size_t)j * n + i];
-    std::vector<double> sk(k);
-    for (int kk = n - 3; kk >= 0; kk--) {
-        if (tau[kk] == 0.0) continue;
-        const double *vk = V.data() + (size_t)kk * n;
-        double *__restrict__ ss = sk.data();
-        for (int j = 0; j < k; j++) ss[j] = 0.0;
-        for (int i = kk + 1; i < n; i++) {
-            const double *__restrict__ zi = z + (size_t)i * k;
-            const double vi = vk[i];
-            for (int j = 0; j < k; j++) ss[j] += vi * zi[j];
+    // back-transform: Z = H_0 H_1 ... H_{n-3} X. Every vector goes through the reflectors on its own (a dot product and an update per
+    // reflector, both over contiguous arrays), so the k vectors are dealt over a team of up to four host threads when there is enough of
+    // them to pay for waking it (1.27 -> 0.45 ms at n = 500, k = 50 on the MI355X host); the arithmetic of a vector does not depend on
+    // who runs it, nor on how many run: results are identical with and without the team.
+    {
+        auto back = [&](int j0, int j1) {
+            // four vectors at a time share the pass over a reflector
+            for (int jb = j0; jb < j1; jb += 4) {
+                const int nv = std::min(4, j1 - jb);
+                double *xs[4];
+                for (int t = 0; t < 4; t++) xs[t] = X.data() + (size_t)(jb + std::min(t, nv - 1)) * n;
+                for (int kk = n - 3; kk >= 0; kk--) {
+                    const double tk_ = tau[kk];
+                    if (tk_ == 0.0) continue;
+                    const double *__restrict__ vk = V.data() + (size_t)kk * n;
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    {
+#pragma clang fp reassociate(on)
+                        for (int i = kk + 1; i < n; i++) {
+                            const double vi = vk[i];
+                            s0 += vi * xs[0][i];
+                            s1 += vi * xs[1][i];
+                            s2 += vi * xs[2][i];
+                            s3 += vi * xs[3][i];
+                        }
+                    }
+                    s0 *= tk_, s1 *= tk_, s2 *= tk_, s3 *= tk_;
+                    if (nv == 4) {
+                        for (int i = kk + 1; i < n; i++) {
+                            const double vi = vk[i];
+                            xs[0][i] -= vi * s0;
+                            xs[1][i] -= vi * s1;
+                            xs[2][i] -= vi * s2;
+                            xs[3][i] -= vi * s3;
+                        }
+                    } else {
+                        const double ss[4] = {s0, s1, s2, s3};
+                        for (int t = 0; t < nv; t++)
+                            for (int i = kk + 1; i < n; i++) xs[t][i] -= vk[i] * ss[t];
+                    }
+                }
+            }
+        };
+        const int groups = (k + 3) / 4; // units of four vectors
+        int Tb = 1;
+        if ((size_t)n * k >= 16384 && groups >= 2 && std::thread::hardware_concurrency() >= 8)
+            Tb = std::min(global_options().eig_threads >= 4 ? 4 : (global_options().eig_threads >= 2 ? 2 : 1), groups);
+        HostTeam *team = Tb > 1 ? HostTeam::acquire(Tb) : nullptr;
+        if (!team) Tb = 1;
+        auto share = [&](int t) { // thread t: groups [g0, g1)
+            const int g0 = (int)((long)groups * t / Tb), g1 = (int)((long)groups * (t + 1) / Tb);
+            back(g0 * 4, std::min(k, g1 * 4));
+        };
+        if (team) {
+            team->start(Tb, [&](int t) { share(t); });
+            share(0);
+            team->join();
+            team->release();
+        } else {
+            back(0, k);
         }
-        for (int j = 0; j < k; j++) ss[j] *= tau[kk];
-        for (int i = kk + 1; i < n; i++) {
-            double *__restrict__ zi = z + (size_t)i * k;
-            const double vi = vk[i];
-            for (int j = 0; j < k; j++) zi[j] -= vi * ss[j];
-        }
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < k; j++) z[(size_t)i * k + j] = X[(size_t)j * n + i];
     }
     lap("back-transform");
     return true;
