@@ -743,6 +743,8 @@ bool sym_eig_topk(const double *a_in, int n, int k, double *w, double *z) {
             x[i] = ((double)(rng >> 11) / 9007199254740992.0) - 0.5;
         }
         double *xj = X.data() + (size_t)j * n;
+        int q_lo = j;
+        while (q_lo > 0 && std::fabs(d[q_lo - 1] - d[j]) <= 3e-2 * tnorm) q_lo--;
         for (int it = 0; it < 5; it++) {
             // solve L U y = P x
             for (int i = 0; i < n - 1; i++) {
@@ -752,9 +754,13 @@ bool sym_eig_topk(const double *a_in, int n, int k, double *w, double *z) {
             x[n - 1] /= dd[n - 1];
             if (n >= 2) x[n - 2] = (x[n - 2] - du[n - 2] * x[n - 1]) / dd[n - 2];
             for (int i = n - 3; i >= 0; i--) x[i] = (x[i] - du[i] * x[i + 1] - du2[i] * x[i + 2]) / dd[i];
-            // orthogonalise against the vectors already accepted (twice), normalise
+            // orthogonalise against the accepted vectors whose eigenvalue lies within 3e-2 |T| of this one (twice), normalise. Inverse
+            // iteration leaves a component eps |T| / |w_i - w_j| of a converged neighbour i in vector j: beyond that distance it is
+            // below 1e-14 by itself (4e-13 at the residual bound of the test below) (LAPACK's dstein draws the line at 1e-3 |T|); the eigenvalues are sorted, so the neighbours are
+            // the vectors q_lo .. j-1. (Round 6: against ALL accepted vectors this loop was 1.0 of the 1.3 ms of the 50 vectors of a
+            // 500-row problem.)
             for (int rep = 0; rep < 2; rep++)
-                for (int q2 = 0; q2 < j; q2++) {
+                for (int q2 = q_lo; q2 < j; q2++) {
                     const double *xq = X.data() + (size_t)q2 * n;
                     double dot = 0.0;
                     {

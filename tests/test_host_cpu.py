@@ -313,6 +313,31 @@ def test_host_sym_eig_topk(sa):
     assert np.max(np.abs(g @ z - z * w)) < 1e-12 * ws[0]
 
 
+def test_host_sym_eig_topk_vectors_stay_orthonormal_across_the_reorthogonalisation_window(sa):
+    """Inverse iteration re-orthogonalises a vector only against the accepted ones within 3e-2 |T| of its eigenvalue (host_linalg.cpp):
+    spectra whose gaps sit just above and just below that window, near-double eigenvalues, a decaying and a nearly flat spectrum must
+    all come back orthonormal to rounding with small residuals."""
+    rng = np.random.default_rng(3)
+    n, k = 400, 60
+    spectra = [
+        1e6 * (1 - 0.31 * np.arange(n) / n),
+        1e6 * np.cumprod(np.full(n, 1 / 1.032)),
+        np.concatenate([1e6 * (1 - 0.0305 * np.arange(30)), 1e3 * rng.random(n - 30)]),
+        np.concatenate([np.repeat(1e6 * (1 - 0.05 * np.arange(15)), 2) * (1 + 1e-9 * rng.random(30)), rng.random(n - 30)]),
+        1e4 * rng.random(n) ** 6,
+        np.linspace(1.0, 0.97, n) * 1e5,
+    ]
+    for lam in spectra:
+        lam = np.sort(np.abs(lam))[::-1]
+        q = np.linalg.qr(rng.standard_normal((n, n)))[0]
+        g = (q * lam) @ q.T
+        g = (g + g.T) / 2
+        w, z = sa.host_sym_eig_topk(g, k)
+        assert np.max(np.abs(w - lam[:k])) < 1e-13 * lam[0]
+        assert np.max(np.abs(z.T @ z - np.eye(k))) < 1e-13
+        assert np.max(np.abs(g @ z - z * w)) < 1e-13 * lam[0]
+
+
 def test_host_sym_eig_topk_bisection_edge_cases(sa):
     """k <= n / 4 takes the k largest eigenvalues by bisection on Sturm counts (host_linalg.cpp): exactly repeated values,
     indefinite matrices, a diagonal and a zero matrix, the smallest sizes the branch sees."""
