@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "host_team.hpp"
 
 namespace scanrs {
 
@@ -263,20 +264,32 @@ static void download_panel_staged(Ctx &c, const double *d, uint32_t ld, uint64_t
     std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[n_chunks]);
     for (size_t i = 0; i < n_chunks; i++) done[i].store(0, std::memory_order_relaxed);
     auto chunk_rows = [&](size_t i) { return std::min<uint64_t>(slot_rows, rows - (uint64_t)i * slot_rows); };
-    std::vector<std::thread> workers;
-    for (unsigned t = 0; t < T; t++)
-        workers.emplace_back([&, t] {
-            for (size_t i = t; i < n_chunks; i += T) {
-                while (ready.load(std::memory_order_acquire) <= i) {
-                    if (stop.load(std::memory_order_relaxed)) return;
-                    std::this_thread::yield();
-                }
-                memcpy((char *)h + (size_t)i * slot_rows * row_bytes, stage + (i % NS) * slot_rows * row_bytes, chunk_rows(i) * row_bytes);
-                done[i].store(1, std::memory_order_release);
+    auto worker = [&](unsigned t) {
+        for (size_t i = t; i < n_chunks; i += T) {
+            while (ready.load(std::memory_order_acquire) <= i) {
+                if (stop.load(std::memory_order_relaxed)) return;
+                std::this_thread::yield();
             }
-        });
+            memcpy((char *)h + (size_t)i * slot_rows * row_bytes, stage + (i % NS) * slot_rows * row_bytes, chunk_rows(i) * row_bytes);
+            done[i].store(1, std::memory_order_release);
+        }
+    };
+    // the parked host team if nobody else has it (creating a thread costs 0.1-3 ms, four of them per download and two downloads per
+    // PCA: round 6), fresh threads otherwise (a second shard's download at the same time)
+    HostTeam *team = HostTeam::acquire((int)T + 1);
+    std::vector<std::thread> workers;
+    if (team)
+        team->start((int)T + 1, [&](int t) { worker((unsigned)t - 1u); });
+    else
+        for (unsigned t = 0; t < T; t++) workers.emplace_back([&, t] { worker(t); });
     auto join_all = [&] {
+        if (team) {
+            team->join();
+            team->release();
+            team = nullptr;
+        }
         for (auto &w : workers) w.join();
+        workers.clear();
         for (auto &e : ev) (void)hipEventDestroy(e);
     };
     try {
@@ -882,6 +895,13 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
     double *dE = c.dev("ritz_e", (size_t)q * k);
     c.h2d(dE, E.data(), E.size());
     launch_gemm_nn(c.st, Q, ldq, q, dE, k, k, ds, 1.0, 0.0, nullptr, 0, dS, ldk);
+    hipEvent_t ev_s = nullptr; // the S-side factor is in place
+    SCANRS_HIP(hipEventCreateWithFlags(&ev_s, hipEventDisableTiming));
+    struct EvS {
+        hipEvent_t e;
+        ~EvS() { (void)hipEventDestroy(e); }
+    } ev_s_guard{ev_s};
+    SCANRS_HIP(hipEventRecord(ev_s, c.s));
     double *dEs = c.dev("ritz_es", (size_t)q * k);
     c.h2d(dEs, Es.data(), Es.size());
     // The T-side factor (10^6 x 50 at the headline size: a 2.5 ms GEMM, then 400 MB to the host) in row blocks: the copy of a finished block
@@ -914,11 +934,17 @@ static void ritz_finish(Ctx &c, const double *Q, uint32_t ldq, uint32_t q, uint6
         hipStream_t cs = c.st.aux2();
         int waited = -1;
         try {
+            if (hS) { // the short side first, on the copy stream: it travels while the GEMM blocks of the long side run
+                SCANRS_HIP(hipStreamWaitEvent(cs, ev_s, 0));
+                if (ds * (uint64_t)k * 8 >= (8u << 20))
+                    download_panel_staged(c, dS, ldk, ds, k, hS, cs);
+                else
+                    SCANRS_D2H_2D(hS, dS, (size_t)ldk * 8, (size_t)k * 8, ds, cs);
+            }
             download_panel_staged(c, dT, ldk, dt, k, hT, cs, [&](uint64_t r0, uint64_t r1) {
                 const int need = (int)((r1 - 1) / blk);
                 while (waited < need) SCANRS_HIP(hipStreamWaitEvent(cs, bev[++waited], 0));
             });
-            if (hS) download_panel(c, dS, ldk, ds, k, hS);
             c.sync();
         } catch (...) {
             for (int i = 0; i < n_blk; i++) (void)hipEventDestroy(bev[i]);
