@@ -194,7 +194,9 @@ CurrentHandle::CurrentHandle(const Storage *st, bool waits_only) : prev(tl_handl
 CurrentHandle::~CurrentHandle() { tl_handle = prev; }
 
 // Poll `query` (hipSuccess: done, hipErrorNotReady: not yet, anything else: a device error) until the deadline. Spins for the
-// first 200 us — the waits on the solvers' critical path end within that — then sleeps 20 us, then 200 us per round.
+// first 200 us, then sleeps 20 us per round (about 70 us with the kernel's timer slack), 200 us per round once a second has passed.
+// (Until round 6 the long rounds began after 5 ms: svd_bk's waits for the coefficients' verdict, the projection and the Gram matrix last
+// 15-35 ms with the device idle until the host reacts — half a round of 250 us lost at each.)
 template <typename Q>
 static hipError_t poll_until(Q &&query, double timeout_s, double *waited_s) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -209,7 +211,7 @@ static hipError_t poll_until(Q &&query, double timeout_s, double *waited_s) {
         if (el < 200e-6)
             std::this_thread::yield();
         else
-            std::this_thread::sleep_for(std::chrono::microseconds(el < 5e-3 ? 20 : 200));
+            std::this_thread::sleep_for(std::chrono::microseconds(el < 1.0 ? 20 : 200));
     }
 }
 // "auto scanrs_mat_sync(scanrs_mat *)::(anonymous class)::operator()() const" -> "scanrs_mat_sync": most waits sit inside the lambda
