@@ -329,16 +329,23 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const double *__restri
 //   info[0] = max |G - I| of this pass, info[1] = shift used
 // check_only: the last queued pass only tests convergence.
 constexpr uint32_t CHOL_NMAX = 128;
-constexpr uint32_t CHOL_TD = 32;              // threads per dimension: 32 x 32 = 1024 threads, 16 waves (4 per SIMD)
-constexpr int CHOL_E = CHOL_NMAX / CHOL_TD;    // entries per thread and dimension: thread (ty, tx) owns (ty + 32 a, tx + 32 b)
+#ifndef SCANRS_CHOL_TD
+#define SCANRS_CHOL_TD 32
+#endif
+// threads per dimension: 32 x 32 = 1024 threads, 16 waves (4 per SIMD). (16 x 16 = 256 threads, SCANRS_CHOL_TD=16, was built to keep the
+// step out of the queue behind the long grids of short workgroups on the projection stream — in a kernel trace it waits 0.5-1.2 ms for a
+// CU to empty, profiles/r06e_timeline.txt 134.9 / 166.95 / 199.7 — but runs 314 instead of 200 us at n = 100, and the untraced step is
+// the same: 203.2 / 203.5 against 202.8 / 203.0 ms, A/B on one box.)
+constexpr uint32_t CHOL_TD = SCANRS_CHOL_TD;
+constexpr int CHOL_E = CHOL_NMAX / CHOL_TD;    // entries per thread and dimension: thread (ty, tx) owns (ty + TD a, tx + TD b)
 // The matrix lives in REGISTERS (cyclic 32 x 32 distribution, 4 x 4 entries per thread, compile-time indices); a step
 // broadcasts one row (and, for the inverse, one column) through LDS and every thread applies the rank-1 update to its own
 // entries: two barriers and a few dozen instructions per step. (An LDS-resident version with per-entry read-modify-write
 // loops ran 290 us at n = 100, bound by LDS latency; 256 threads with 8 x 8 entries each ran as long — one wave per SIMD
 // issues its ~500 instructions per step back to back.)
-__global__ __launch_bounds__(1024) void chol_rinv_kernel(const double *__restrict__ G, uint32_t n, double rows, int pass, int check_only,
+__global__ __launch_bounds__(CHOL_TD * CHOL_TD) void chol_rinv_kernel(const double *__restrict__ G, uint32_t n, double rows, int pass, int check_only,
                                                         int *__restrict__ ctl, double *__restrict__ Rinv, double *__restrict__ info) {
-    __shared__ double rowbuf[CHOL_NMAX], colbuf[CHOL_NMAX], red[3 * 1024];
+    __shared__ double rowbuf[CHOL_NMAX], colbuf[CHOL_NMAX], red[3 * CHOL_TD * CHOL_TD];
     const uint32_t tid = threadIdx.x, nt = blockDim.x, ty = tid / CHOL_TD, tx = tid % CHOL_TD;
     // rows of this wave in row block a: wy0 + 32 a and wy0 + 1 + 32 a (a wave is two rows of the thread grid) — uniform tests skip whole blocks
     const uint32_t wy0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6)) * (64u / CHOL_TD);
@@ -506,7 +513,7 @@ bool chol_rinv_ok(uint32_t n) { return n >= 1 && n <= CHOL_NMAX; }
 void launch_chol_rinv(Storage &st, const double *G, uint32_t n, uint64_t rows, int pass, bool check_only, int *ctl, double *Rinv, double *info) {
     if (!chol_rinv_ok(n)) fail(SCANRS_ERR_ARGUMENT, "device Cholesky: n out of range");
     if (st.prof.on) st.prof.begin(st.stream, "chol_rinv", (double)n * n * 16.0);
-    hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(1024), 0, st.stream, G, n, (double)rows, pass, check_only ? 1 : 0, ctl, Rinv, info);
+    hipLaunchKernelGGL(chol_rinv_kernel, dim3(1), dim3(CHOL_TD * CHOL_TD), 0, st.stream, G, n, (double)rows, pass, check_only ? 1 : 0, ctl, Rinv, info);
     if (st.prof.on) st.prof.end(st.stream);
     SCANRS_HIP(hipGetLastError());
 }
