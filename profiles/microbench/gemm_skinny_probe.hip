@@ -39,7 +39,8 @@ int main(int argc, char **argv) {
     const uint64_t rows = argc > 1 ? strtoull(argv[1], 0, 10) : 1000000;
     const uint32_t n = argc > 2 ? atoi(argv[2]) : 500, m = argc > 3 ? atoi(argv[3]) : 50;
     const uint32_t ldx = argc > 4 ? atoi(argv[4]) : ((n + 1) & ~1u), ldo = (m + 1) & ~1u, n_pad = (n + 15) / 16 * 16;
-    const uint32_t groups = (m + 63) / 64, nt = ((m + 15) / 16 + groups - 1) / groups, m_pad = nt * 16 * groups;
+    const uint32_t gcols = argc > 5 ? atoi(argv[5]) : 64; // columns per group (multiple of 16, <= 112)
+    const uint32_t groups = (m + gcols - 1) / gcols, nt = ((m + 15) / 16 + groups - 1) / groups, m_pad = nt * 16 * groups;
     double *X, *W, *Wt, *Out, *Ref;
     CK(hipMalloc(&X, rows * ldx * 8));
     CK(hipMalloc(&W, (size_t)n * m * 8));
@@ -62,7 +63,10 @@ int main(int argc, char **argv) {
         case 1: run<1>(x, ldx, n, Wt, n_pad, m, nr, o, ldo, 0); break;
         case 2: run<2>(x, ldx, n, Wt, n_pad, m, nr, o, ldo, 0); break;
         case 3: run<3>(x, ldx, n, Wt, n_pad, m, nr, o, ldo, 0); break;
-        default: run<4>(x, ldx, n, Wt, n_pad, m, nr, o, ldo, 0); break;
+        case 4: run<4>(x, ldx, n, Wt, n_pad, m, nr, o, ldo, 0); break;
+        case 5: run<5>(x, ldx, n, Wt, n_pad, m, nr, o, ldo, 0); break;
+        case 6: run<6>(x, ldx, n, Wt, n_pad, m, nr, o, ldo, 0); break;
+        default: run<7>(x, ldx, n, Wt, n_pad, m, nr, o, ldo, 0); break;
         }
     };
     for (int form = 0; form < 2; form++) {

@@ -588,14 +588,17 @@ void launch_gram_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, c
 
 // Results of up to 128 columns (svd_bk's panels: b = 2 k <= 128 for k <= 64; the Ritz factors) with rows of X aligned for 16-byte
 // loads: straight from memory into the MFMA operands, one or two column groups (dense_skinny.inc). Measured against the LDS-tiled
-// kernels (profiles/microbench/gemm_skinny_probe.hip): 10^6 x 500 -> 50: 1.50 ms (2.5); 10^6 x 400 -> 100: 2.34 (3.6); 33 k x 400 -> 100:
+// kernels (profiles/microbench/gemm_skinny_probe.hip): 10^6 x 500 -> 50: 1.50 ms (2.5); 10^6 x 400 -> 100: 2.08 (3.6); 33 k x 400 -> 100:
 // 0.11 (0.29); 33 k x 100 -> 100: 0.045 (0.06-0.13).
 bool gemm_direct_ok(const double *X, uint32_t ldx, uint32_t n, uint32_t m, uint64_t rows) {
     return m >= 1u && m <= 128u && n >= 16u && rows >= 64u && ldx % 2u == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0;
 }
 void launch_gemm_direct(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *W, uint32_t ldw, uint32_t m, uint64_t rows,
                         double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo) {
-    const uint32_t n_pad = (n + 15u) / 16u * 16u, groups = (m + 63u) / 64u, nt = ((m + 15u) / 16u + groups - 1u) / groups, m_pad = nt * 16u * groups;
+    // up to 112 columns in ONE group (7 MFMA column tiles per wave, X read once: 10^6 x 400 -> 100 in 2.08 ms against 2.40 in two groups of
+    // 64); 113-128 columns in two groups
+    const uint32_t n_pad = (n + 15u) / 16u * 16u, groups = m <= 112u ? 1u : (m + 63u) / 64u, nt = ((m + 15u) / 16u + groups - 1u) / groups,
+                   m_pad = nt * 16u * groups;
     double *Wt = st.scratch.get<double>(st.skey("skinny_wt"), (size_t)n_pad * m_pad);
     if (st.prof.on) st.prof.begin(st.stream, "gemm_skinny_mfma_f64", (double)rows * (n + m) * 8.0 + (double)n * m * 8.0);
     hipLaunchKernelGGL(skinny_wt_kernel, dim3((n_pad * m_pad + 255u) / 256u), dim3(256), 0, st.stream, W, ldw, n, m, n_pad, m_pad, Wt, st.skip_flag);
@@ -607,7 +610,10 @@ void launch_gemm_direct(Storage &st, const double *X, uint32_t ldx, uint32_t n, 
     case 1: SCANRS_SKD_LAUNCH(1); break;
     case 2: SCANRS_SKD_LAUNCH(2); break;
     case 3: SCANRS_SKD_LAUNCH(3); break;
-    default: SCANRS_SKD_LAUNCH(4); break;
+    case 4: SCANRS_SKD_LAUNCH(4); break;
+    case 5: SCANRS_SKD_LAUNCH(5); break;
+    case 6: SCANRS_SKD_LAUNCH(6); break;
+    default: SCANRS_SKD_LAUNCH(7); break;
     }
 #undef SCANRS_SKD_LAUNCH
     if (st.prof.on) st.prof.end(st.stream);
