@@ -2113,6 +2113,57 @@ void launch_row_reduce(Storage &st, SparseCopy &cp, const DevMap &map, int mode,
 }
 
 // Xc (optional): a compact copy of X's first l columns in rows of ldc, written from the same read (l even: the lanes move column pairs)
+// C = X^T y for ONE vector y (rows x 1, stride ldy) and up to 128 columns of X: IRLBA's re-orthogonalisation dots (irlba.rs:19-22,
+// 131-134, 10^6 x <= 70 against one Lanczos vector). The 32 x 32 MFMA tiles of gram_kernel spend 31 of 32 columns on padding there and
+// load 16 lanes x 8 B per row (0.6-0.8 ms per call at 10^6 rows); here a lane owns columns lane and lane + 64, a wave walks rows
+// r0 + wave, + 4, ... of its block's slice (a row of X = one coalesced read, y[r] one broadcast load), eight rows in flight; the four
+// waves' sums meet in LDS in wave order, the blocks' partials are added in block order by gram_finish_kernel: deterministic.
+__global__ __launch_bounds__(256) void gram_vec_kernel(const double *__restrict__ X, uint32_t ldx, uint32_t n, const double *__restrict__ y, uint32_t ldy,
+                                                       uint64_t rows, uint64_t rows_per_block, double *__restrict__ slab, const int *__restrict__ skip) {
+    if (skip && *skip) return;
+    __shared__ double part[3][128];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    const bool a0 = lane < n, a1 = lane + 64u < n;
+    double acc0 = 0.0, acc1 = 0.0;
+    uint64_t i = r0 + wave;
+    for (; i + 28u < r1; i += 32u) {
+        double x0[8], x1[8], yv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const double *xr = X + (i + 4u * u) * ldx;
+            x0[u] = a0 ? xr[lane] : 0.0;
+            x1[u] = a1 ? xr[lane + 64u] : 0.0;
+            yv[u] = y[(i + 4u * u) * ldy];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            acc0 = fma(x0[u], yv[u], acc0);
+            acc1 = fma(x1[u], yv[u], acc1);
+        }
+    }
+    for (; i < r1; i += 4u) {
+        const double *xr = X + i * ldx;
+        const double yv = y[i * ldy];
+        acc0 = fma(a0 ? xr[lane] : 0.0, yv, acc0);
+        acc1 = fma(a1 ? xr[lane + 64u] : 0.0, yv, acc1);
+    }
+    if (wave > 0) {
+        part[wave - 1][lane] = acc0;
+        part[wave - 1][lane + 64u] = acc1;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 0; w < 3; w++) {
+            acc0 += part[w][lane];
+            acc1 += part[w][lane + 64u];
+        }
+        double *dst = slab + (size_t)blockIdx.x * n;
+        if (a0) dst[lane] = acc0;
+        if (a1) dst[lane + 64u] = acc1;
+    }
+}
+
 void launch_weighted_colsum(Storage &st, const double *B, uint32_t rank, const double *X, uint32_t ldx, uint64_t n,
                             uint32_t l, double *w, uint32_t ldw, double *Xc, uint32_t ldc) {
     if (rank == 0 || l == 0) return;
@@ -2131,6 +2182,18 @@ void launch_weighted_colsum(Storage &st, const double *B, uint32_t rank, const d
 void launch_gram(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *Y, uint32_t ldy, uint32_t m,
                  uint64_t rows, double *C) {
     if (n == 0 || m == 0) return;
+    if (m == 1u && n <= 128u && rows >= 4096u && !st.skip_flag) { // one vector against a narrow panel: the streaming form (gram_vec_kernel)
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>(1024, (rows + 255) / 256);
+        const uint64_t rpb = (rows + blocks - 1) / blocks;
+        double *slab = st.scratch.get<double>(st.skey("gram_slab"), (size_t)blocks * n);
+        ProfScope ps(st, "gram_vec_f64", (double)rows * (n + 1) * 8.0);
+        hipLaunchKernelGGL(gram_vec_kernel, dim3(blocks), dim3(256), 0, st.stream, X, ldx, n, Y, ldy, rows, rpb, slab, st.skip_flag);
+        // (the blocks' partials in block order, four groups of 64 threads with eight loads in flight each: the plain ordered loop of
+        // gram_finish_kernel walks 1 024 partials one load at a time)
+        hipLaunchKernelGGL(weighted_colsum_finish_kernel, grid1((uint64_t)n, 64), dim3(256), 0, st.stream, slab, blocks, 1u, n, C, n);
+        SCANRS_HIP(hipGetLastError());
+        return;
+    }
     // work queued on a side stream runs beside the persistent tile kernel of a sparse pass, which holds all of every CU's LDS: a
     // kernel that needs LDS waits for the end of the pass; the register-only MFMA kernels below fit the registers the tile kernel leaves
     const bool side = st.dense_side_no_lds && ((st.aux_stream && st.stream == st.aux_stream) || (st.aux2_stream && st.stream == st.aux2_stream));
