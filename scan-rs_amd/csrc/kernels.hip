@@ -2251,6 +2251,26 @@ void launch_gemm_nn(Storage &st, const double *X, uint32_t ldx, uint32_t n, cons
     SCANRS_HIP(hipGetLastError());
 }
 
+// one column with a scalar that arrives as a kernel argument (IRLBA's normalisations and three-term updates, irlba.rs:137-160: the
+// scalar used to travel as a 1 x 1 matrix through a pageable upload and a synchronisation per call):
+//   MODE 0: dst[r] = src[r] * alpha        MODE 1: dst[r] = src[r] * alpha + dst[r]  (product rounded, then the sum: what the GEMM form gave)
+template <int MODE>
+__global__ void col_scalar_kernel(double *dst, uint32_t ldd, const double *src, uint32_t lds, uint64_t rows, double alpha) { // (dst may be src)
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const double t = __dmul_rn(src[r * lds], alpha);
+    dst[r * ldd] = MODE == 0 ? t : __dadd_rn(t, dst[r * ldd]);
+}
+void launch_col_scale(Storage &st, double *dst, uint32_t ldd, const double *src, uint32_t lds, uint64_t rows, double alpha) {
+    if (rows == 0) return;
+    hipLaunchKernelGGL(col_scalar_kernel<0>, grid1(rows, 256), dim3(256), 0, st.stream, dst, ldd, src, lds, rows, alpha);
+    SCANRS_HIP(hipGetLastError());
+}
+void launch_col_axpy(Storage &st, double *y, uint32_t ldy, const double *x, uint32_t ldx, uint64_t rows, double alpha) {
+    if (rows == 0) return;
+    hipLaunchKernelGGL(col_scalar_kernel<1>, grid1(rows, 256), dim3(256), 0, st.stream, y, ldy, x, ldx, rows, alpha);
+    SCANRS_HIP(hipGetLastError());
+}
 void launch_copy_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows,
                       uint32_t l) {
     if (rows == 0 || l == 0) return;

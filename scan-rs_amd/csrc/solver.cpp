@@ -1463,11 +1463,13 @@ int pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, ui
 
 // ---- IRLBA (scan-rs/src/dim_red/irlba.rs:71-215), vectors on the device, small B on the host -----------------
 // y <- y - X (X^T y) for the first j columns of X (rows x ldx); irlba.rs:19-22
+// (the dots stay on the device: nobody on the host reads them — until round 6 they made a round trip per call)
 static void orthog_dev(Ctx &c, double *y, const double *X, uint32_t ldx, uint32_t j, uint64_t rows, bool sharded) {
     if (j == 0) return;
-    std::vector<double> dotv;
-    gram_host(c, X, ldx, j, y, 2, 1, rows, sharded, dotv);
-    gemm_hostw(c, X, ldx, j, dotv, 1, rows, -1.0, 1.0, y, 2, "irlba_w");
+    double *dC = c.dev("irlba_dots", j);
+    launch_gram(c.st, X, ldx, j, y, 2, 1, rows, dC);
+    if (sharded) allreduce_f64(c.st, dC, j);
+    launch_gemm_nn(c.st, X, ldx, j, dC, 1, 1, rows, -1.0, 1.0, y, 2, y, 2);
 }
 static double norm_dev(Ctx &c, const double *y, uint64_t rows, bool sharded) {
     std::vector<double> g;
@@ -1480,10 +1482,7 @@ static double invcheck(double x) { // irlba.rs:25-33
 }
 // dst[:, col] (ld) <- alpha * src (ld 2)
 static void set_col(Ctx &c, double *dst, uint32_t ld, uint32_t col, const double *src, uint64_t rows, double alpha) {
-    std::vector<double> a(1, alpha);
-    double *dW = c.dev("irlba_a", 1);
-    c.h2d(dW, a.data(), 1);
-    launch_gemm_nn(c.st, src, 2, 1, dW, 1, 1, rows, 1.0, 0.0, nullptr, 0, dst + col, ld);
+    launch_col_scale(c.st, dst + col, ld, src, 2, rows, alpha);
 }
 static void get_col(Ctx &c, const double *src, uint32_t ld, uint32_t col, double *dst, uint64_t rows) {
     launch_copy_cols(c.st, src + col, ld, dst, 2, rows, 1);
@@ -1602,11 +1601,7 @@ int pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t maxit, const doub
             get_col(c, W, ldm, j, wv, M);
             mat_apply(m, true, wv, 2, 1, F, 2); // F = W[:, j]^T A
             mprod++;
-            { // F -= V[:, j] * s
-                std::vector<double> a(1, -sn);
-                get_col(c, V, ldm, j, vv, N);
-                gemm_hostw(c, vv, 2, 1, a, 1, N, 1.0, 1.0, F, 2, "irlba_w");
-            }
+            launch_col_axpy(c.st, F, 2, V + j, ldm, N, -sn); // F -= V[:, j] * s
             orthog_dev(c, F, V, ldm, j + 1, N, sh_n);
             fnorm = norm_dev(c, F, N, sh_n);
             const double finv = invcheck(fnorm);
@@ -1619,12 +1614,7 @@ int pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t maxit, const doub
                 B[(size_t)j * m_b + j + 1] = fnorm;
                 mat_apply(m, false, F, 2, 1, wv, 2); // A V[:, j+1] (the reference computes it twice, irlba.rs:152,155)
                 mprod += 1;
-                {
-                    std::vector<double> a(1, -fnorm);
-                    double *wj = c.dev("ir_wj", (size_t)M * 2);
-                    get_col(c, W, ldm, j, wj, M);
-                    gemm_hostw(c, wj, 2, 1, a, 1, M, 1.0, 1.0, wv, 2, "irlba_w");
-                }
+                launch_col_axpy(c.st, wv, 2, W + j, ldm, M, -fnorm); // - W[:, j] * |F|
                 orthog_dev(c, wv, W, ldm, j + 1, M, sh_m);
                 sn = norm_dev(c, wv, M, sh_m);
                 sinv = invcheck(sn);
