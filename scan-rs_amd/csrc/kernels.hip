@@ -596,6 +596,12 @@ __global__ __launch_bounds__(256) void spmv2d_kernel(const uint64_t *__restrict_
 // too big for one LDS and, gathered from L2, costs one 64-line vector-memory instruction per 64 nonzeros. It is cut into
 // <= 144 KB parts (whole bounds tiles); a 16-wave workgroup stages one part in LDS, walks its share of the outer vectors
 // through it (ds_read_b64 gathers), and carries the partial sums through `out` between parts.
+// VM: where a nonzero's value comes from — 0 the lazy chain, 1 the materialized values, 2 the row table. (A template, not a runtime test:
+// with the test inside the unrolled load loop the compiler waited for every stride's loads before it issued the next stride's.)
+#ifndef SCANRS_SPMV_SU
+#define SCANRS_SPMV_SU 8
+#endif
+template <int VM>
 __global__ __launch_bounds__(1024) void spmv_lds_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
                                                         const uint32_t *__restrict__ values, const uint32_t *__restrict__ bounds,
                                                         uint32_t nb, uint32_t tiles_per_part, uint32_t n_parts, uint64_t n_outer,
@@ -604,7 +610,14 @@ __global__ __launch_bounds__(1024) void spmv_lds_kernel(const uint64_t *__restri
                                                         const double *__restrict__ off_a, uint32_t rank,
                                                         const double *__restrict__ off_w, uint32_t ldw,
                                                         const double *__restrict__ fvals, int fstart) {
+    constexpr bool use_tab = VM == 2;
+    constexpr int SU = SCANRS_SPMV_SU; // strides of 64 nonzeros in flight per trip: the walk is bound by the requests it keeps in flight, not by bytes
     extern __shared__ double xs[];
+    // use_tab: every link of the map depends on the count and the OUTER position only (what is left of every reference normalisation on
+    // the cell-major copy once mat_apply has moved the per-gene scale into the vector): a wave evaluates its row's chain at counts
+    // 1 .. 15 once per part and every nonzero is a lookup by its own count — 8 bytes per nonzero (index + count) instead of the
+    // 12 of the materialized values, and no 8 bytes per nonzero of them resident (round 6; col_moments_kernel's idea)
+    __shared__ double row_tab[16][8][8]; // [wave][row of the batch][count - 1]
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint64_t r0 = (uint64_t)blockIdx.x * rows_per_block, r1 = min(n_outer, r0 + rows_per_block);
     const uint32_t part_len = tiles_per_part << BT_SHIFT;
@@ -615,30 +628,49 @@ __global__ __launch_bounds__(1024) void spmv_lds_kernel(const uint64_t *__restri
         for (uint32_t i = threadIdx.x; i < glen; i += 1024u) xs[i] = X[(g0 + i) * ldx];
         __syncthreads();
         const uint32_t b0 = p * tiles_per_part, b1 = min(nb, b0 + tiles_per_part);
-        for (uint64_t row = r0 + wave; row < r1; row += 16u) {
+        for (uint64_t row_b = r0 + wave; row_b < r1; row_b += 16u * 8u) {
+          if (use_tab) { // the chain at counts 1 .. 8 of the batch's eight rows, one evaluation for all 64 (a table per row and part cost more than the walk)
+              const uint64_t trow = row_b + 16u * (lane >> 3);
+              row_tab[wave][lane >> 3][lane & 7u] = trow < r1 ? eval_map(map, (lane & 7u) + 1u, (uint32_t)trow, 0u) : 0.0;
+          }
+          for (uint32_t t = 0; t < 8u; t++) {
+            const uint64_t row = row_b + 16u * t;
+            if (row >= r1) break;
             const uint32_t *__restrict__ bd = bounds + row * (nb + 1);
             const uint32_t o0 = bd[b0], len = bd[b1] - o0;
             const uint64_t base = indptr[row] + o0;
             const RowMap rm = row_map(map, (uint32_t)row);
             double s0 = 0.0;
-            for (uint32_t q0 = lane; q0 < len; q0 += 64u * SCAN_U) {
-                uint32_t g[SCAN_U], vv[SCAN_U];
-                double fv[SCAN_U];
-                bool ok[SCAN_U];
+            for (uint32_t q0 = lane; q0 < len; q0 += 64u * SU) {
+                uint32_t g[SU], vv[SU];
+                double fv[SU];
+                bool ok[SU];
 #pragma unroll
-                for (int u = 0; u < SCAN_U; u++) {
+                for (int u = 0; u < SU; u++) {
                     const uint32_t q = q0 + 64u * u;
                     ok[u] = q < len;
                     const uint64_t e = base + (ok[u] ? q : len - 1u);
                     g[u] = indices[e];
-                    if (fvals) // the mapped values, materialized: no logarithm per nonzero per product
+                    if (VM == 1) // the mapped values, materialized: no logarithm per nonzero per product
                         fv[u] = fvals[e];
                     else
                         vv[u] = values[e];
                 }
 #pragma unroll
-                for (int u = 0; u < SCAN_U; u++) {
-                    const double f = fvals ? eval_map_from(map, fstart, fv[u], (uint32_t)row, g[u]) : eval_map(map, rm, vv[u], (uint32_t)row, g[u]);
+                for (int u = 0; u < SU; u++) {
+                    double f;
+                    if (VM == 1)
+                        f = eval_map_from(map, fstart, fv[u], (uint32_t)row, g[u]);
+                    else if (use_tab) {
+                        f = row_tab[wave][t][min(vv[u] - 1u, 7u)];
+                        // (a wave-uniform branch around the chain: as a select the compiler evaluates the logarithm for every nonzero)
+#ifndef SCANRS_SPMV_TAB_NOSLOW
+                        if (__builtin_amdgcn_ballot_w64(ok[u] && vv[u] - 1u >= 8u) != 0ull) {
+                            if (vv[u] - 1u >= 8u) f = eval_map(map, rm, vv[u], (uint32_t)row, g[u]);
+                        }
+#endif
+                    } else
+                        f = eval_map(map, rm, vv[u], (uint32_t)row, g[u]);
                     s0 = ok[u] ? fma(f, xs[g[u] - (uint32_t)g0], s0) : s0;
                 }
             }
@@ -649,6 +681,7 @@ __global__ __launch_bounds__(1024) void spmv_lds_kernel(const uint64_t *__restri
                     for (uint32_t q = 0; q < rank; q++) s0 += off_a[row * rank + q] * off_w[(size_t)q * ldw];
                 out[row * ldo] = s0;
             }
+          }
         }
     }
 }
@@ -1988,18 +2021,33 @@ void launch_spmm_f64(Storage &st, SparseCopy &cp, const DevMap &map, const doubl
             const uint32_t tiles_per_part = (uint32_t)(((cp.n_inner + n_parts - 1) / n_parts + (1u << BT_SHIFT) - 1) >> BT_SHIFT);
             const size_t shmem = ((size_t)tiles_per_part << BT_SHIFT) * 8;
             // per device, and handles of one process may live on different devices: set on every use (a cheap call)
-            SCANRS_HIP(hipFuncSetAttribute((const void *)spmv_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+
             int dev = 0, n_cu = 256;
             (void)hipGetDevice(&dev);
             (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
             const uint32_t n_blocks = (uint32_t)std::min<uint64_t>((uint64_t)n_cu * 4u, (cp.n_outer + 15) / 16);
             const uint64_t rows_per_block = (cp.n_outer + n_blocks - 1) / n_blocks;
             const int fstart = fvals_prefix_len(map);
-            const double *fv = fvals_wanted_for_alu(st, cp, map, fstart) ? ensure_fvals(st, cp, map, fstart) : nullptr;
+            // a chain of the count and the outer position alone: looked up by count from a table the wave makes per row — no materialized values
+            bool outer_only = st.spmv_row_table != 0 && map.n > 0 && map_is_simple(map);
+            for (int i = 0; i < map.n && outer_only; i++) outer_only = map.ops[i].kind != OP_SCALE_AXIS || map.ops[i].a_outer;
+            const double *fv = (!outer_only && fvals_wanted_for_alu(st, cp, map, fstart)) ? ensure_fvals(st, cp, map, fstart) : nullptr;
             ProfScope ps(st, "spmv_lds_kernel/long-outer", (double)cp.nnz * (fv ? 12.0 : 8.0) + (double)(cp.n_outer + 1) * 8.0 + (double)(cp.n_inner + cp.n_outer) * 8.0);
-            hipLaunchKernelGGL(spmv_lds_kernel, dim3(n_blocks), dim3(1024), shmem, st.stream, cp.indptr.p, cp.indices.p, cp.values.p, cp.bounds.p, nb,
-                               tiles_per_part, n_parts, cp.n_outer, rows_per_block, map, X, ldx, cp.n_inner, out, ldo, off_a, rank, off_w, ldw, fv,
-                               fstart);
+#define SCANRS_SPMV_LDS(VM)                                                                                                                       \
+    do {                                                                                                                                          \
+        /* per device, and handles of one process may live on different devices: set on every use (a cheap call); beside 8 KB of static LDS */    \
+        SCANRS_HIP(hipFuncSetAttribute((const void *)spmv_lds_kernel<VM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));                \
+        hipLaunchKernelGGL(spmv_lds_kernel<VM>, dim3(n_blocks), dim3(1024), shmem, st.stream, cp.indptr.p, cp.indices.p, cp.values.p, cp.bounds.p, \
+                           nb, tiles_per_part, n_parts, cp.n_outer, rows_per_block, map, X, ldx, cp.n_inner, out, ldo, off_a, rank, off_w, ldw, fv, \
+                           fstart);                                                                                                               \
+    } while (0)
+            if (outer_only)
+                SCANRS_SPMV_LDS(2);
+            else if (fv)
+                SCANRS_SPMV_LDS(1);
+            else
+                SCANRS_SPMV_LDS(0);
+#undef SCANRS_SPMV_LDS
             SCANRS_HIP(hipGetLastError());
             return;
         }
