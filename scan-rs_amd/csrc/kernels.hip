@@ -596,11 +596,11 @@ __global__ __launch_bounds__(256) void spmv2d_kernel(const uint64_t *__restrict_
 // too big for one LDS and, gathered from L2, costs one 64-line vector-memory instruction per 64 nonzeros. It is cut into
 // <= 144 KB parts (whole bounds tiles); a 16-wave workgroup stages one part in LDS, walks its share of the outer vectors
 // through it (ds_read_b64 gathers), and carries the partial sums through `out` between parts.
-// VM: where a nonzero's value comes from — 0 the lazy chain, 1 the materialized values, 2 the row table. (A template, not a runtime test:
-// with the test inside the unrolled load loop the compiler waited for every stride's loads before it issued the next stride's.)
 #ifndef SCANRS_SPMV_SU
 #define SCANRS_SPMV_SU 8
 #endif
+// VM: where a nonzero's value comes from — 0 the lazy chain, 1 the materialized values, 2 the row table. (A template, not a runtime test:
+// with the test inside the unrolled load loop the compiler waited for every stride's loads before it issued the next stride's.)
 template <int VM>
 __global__ __launch_bounds__(1024) void spmv_lds_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
                                                         const uint32_t *__restrict__ values, const uint32_t *__restrict__ bounds,
@@ -697,7 +697,9 @@ __global__ __launch_bounds__(1024) void spmv_lds_kernel(const uint64_t *__restri
 //   MODE 0: sum of f * x[inner] (Ix1 product)
 // Value of a nonzero: fvals given -> chain from link `fstart` on applied to fvals[p]; else, with `lazy_scale`, the chain's
 // first link is an inner-indexed ScaleAxis whose array is staged as well (`sa`); else the plain lazy chain.
-template <int MODE>
+// FV: the nonzero's value is read from `fvals` (1) or made from its count (0) — a template parameter for the same reason as in
+// spmv_lds_kernel: a runtime test inside the unrolled load loop made the compiler wait for each stride's loads in turn
+template <int MODE, int FV>
 __global__ __launch_bounds__(1024) void slice_walk_kernel(const uint64_t *__restrict__ indptr, const uint32_t *__restrict__ indices,
                                                           const uint32_t *__restrict__ values, const double *__restrict__ fvals, int fstart,
                                                           const uint32_t *__restrict__ bounds, uint32_t nb, uint32_t tiles_per_slice,
@@ -705,6 +707,7 @@ __global__ __launch_bounds__(1024) void slice_walk_kernel(const uint64_t *__rest
                                                           uint32_t n_groups, DevMap map, int lazy_scale, const double *__restrict__ X,
                                                           uint32_t ldx, double *__restrict__ slab, double *__restrict__ fout) {
     extern __shared__ double sl[];
+    constexpr int SU = MODE == 0 ? SCANRS_SPMV_SU : SCAN_U; // (the product keeps eight strides in flight; the moments pass carries more state per stride)
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t slice = blockIdx.x, group = blockIdx.y;
     const uint64_t c0 = (uint64_t)slice * tiles_per_slice << BT_SHIFT;
@@ -728,25 +731,25 @@ __global__ __launch_bounds__(1024) void slice_walk_kernel(const uint64_t *__rest
         const uint64_t base = indptr[row] + o0;
         const RowMap rm = row_map(map, row);
         double s = 0.0, s2 = 0.0;
-        for (uint32_t p0 = lane; p0 < len; p0 += 64u * SCAN_U) {
-            uint32_t g[SCAN_U], vv[SCAN_U];
-            double fv[SCAN_U];
-            bool ok[SCAN_U];
+        for (uint32_t p0 = lane; p0 < len; p0 += 64u * SU) {
+            uint32_t g[SU], vv[SU];
+            double fv[SU];
+            bool ok[SU];
 #pragma unroll
-            for (int u = 0; u < SCAN_U; u++) {
+            for (int u = 0; u < SU; u++) {
                 const uint32_t p = p0 + 64u * u;
                 ok[u] = p < len;
                 const uint64_t q = base + (ok[u] ? p : len - 1u);
                 g[u] = indices[q];
-                if (fvals)
+                if (FV)
                     fv[u] = fvals[q];
                 else
                     vv[u] = values[q];
             }
 #pragma unroll
-            for (int u = 0; u < SCAN_U; u++) {
+            for (int u = 0; u < SU; u++) {
                 double f;
-                if (fvals)
+                if (FV)
                     f = eval_map_from(map, fstart, fv[u], row, g[u]);
                 else if (lazy_scale)
                     f = eval_map_from(map, 1, sa[g[u] - cbase] * (double)vv[u], row, g[u]);
@@ -1691,11 +1694,19 @@ static void launch_slice_walk(Storage &st, SparseCopy &cp, const DevMap &map, co
     const size_t shmem = (size_t)std::max(1u, arrays) * ((size_t)tps << BT_SHIFT) * 8;
     double *slab = st.scratch.get<double>("slice_slab", (size_t)n_slices * cp.n_outer * (MODE == 1 ? 2 : 1));
     // per device, and handles of one process may live on different devices: set on every use (a cheap call)
-    SCANRS_HIP(hipFuncSetAttribute((const void *)slice_walk_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     ProfScope ps(st, label, bytes);
-    hipLaunchKernelGGL((slice_walk_kernel<MODE>), dim3(n_slices, n_groups), dim3(1024), shmem, st.stream, cp.indptr.p, cp.indices.p,
-                       cp.values.p, fvals, fstart, cp.bounds.p, nb, tps, cp.n_outer, cp.n_inner, ordered ? cp.order.p : nullptr, n_groups, map,
-                       lazy_scale ? 1 : 0, X, ldx, slab, fout);
+#define SCANRS_SLICE_WALK(FV)                                                                                                                      \
+    do {                                                                                                                                           \
+        SCANRS_HIP(hipFuncSetAttribute((const void *)slice_walk_kernel<MODE, FV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));         \
+        hipLaunchKernelGGL((slice_walk_kernel<MODE, FV>), dim3(n_slices, n_groups), dim3(1024), shmem, st.stream, cp.indptr.p, cp.indices.p,        \
+                           cp.values.p, fvals, fstart, cp.bounds.p, nb, tps, cp.n_outer, cp.n_inner, ordered ? cp.order.p : nullptr, n_groups, map, \
+                           lazy_scale ? 1 : 0, X, ldx, slab, fout);                                                                                \
+    } while (0)
+    if (fvals)
+        SCANRS_SLICE_WALK(1);
+    else
+        SCANRS_SLICE_WALK(0);
+#undef SCANRS_SLICE_WALK
     hipLaunchKernelGGL((slice_reduce_kernel<MODE>), grid1(cp.n_outer, 256), dim3(256), 0, st.stream, slab, n_slices, cp.n_outer, out_a, ld_a,
                        out_b, off_a, rank, off_w, ldw);
     SCANRS_HIP(hipGetLastError());
