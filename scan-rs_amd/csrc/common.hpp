@@ -475,6 +475,8 @@ void launch_gemm_direct(Storage &st, const double *X, uint32_t ldx, uint32_t n, 
                         double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo);
 void launch_gemm_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *W, uint32_t ldw, uint32_t m,
                        uint64_t rows, double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo);
+void launch_col_scale_dev(Storage &st, double *dst, uint32_t ldd, const double *src, uint32_t lds, uint64_t rows, const double *nsq);
+void launch_col_axpy_dev(Storage &st, double *y, uint32_t ldy, const double *x, uint32_t ldx, uint64_t rows, const double *nsq);
 void launch_col_scale(Storage &st, double *dst, uint32_t ldd, const double *src, uint32_t lds, uint64_t rows, double alpha);
 void launch_col_axpy(Storage &st, double *y, uint32_t ldy, const double *x, uint32_t ldx, uint64_t rows, double alpha);
 void launch_copy_cols(Storage &st, const double *src, uint32_t lds, double *dst, uint32_t ldd, uint64_t rows, uint32_t l);

@@ -2320,6 +2320,27 @@ __global__ void col_scalar_kernel(double *dst, uint32_t ldd, const double *src, 
     const double t = __dmul_rn(src[r * lds], alpha);
     dst[r * ldd] = MODE == 0 ? t : __dadd_rn(t, dst[r * ldd]);
 }
+// the same with the scalar taken from device memory as the SQUARE of a norm (a 1 x 1 Gram matrix left where the Gram kernel wrote it):
+//   MODE 0: dst[r] = src[r] * invcheck(sqrt(*nsq))  (irlba.rs:25-33: 1 / x above 2 eps, else 0)    MODE 1: dst[r] = src[r] * (-sqrt(*nsq)) + dst[r]
+template <int MODE>
+__global__ void col_scalar_dev_kernel(double *dst, uint32_t ldd, const double *src, uint32_t lds, uint64_t rows, const double *__restrict__ nsq) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const double nrm = __dsqrt_rn(*nsq);
+    const double alpha = MODE == 0 ? (nrm > 2.0 * 2.220446049250313e-16 ? __ddiv_rn(1.0, nrm) : 0.0) : -nrm;
+    const double t = __dmul_rn(src[r * lds], alpha);
+    dst[r * ldd] = MODE == 0 ? t : __dadd_rn(t, dst[r * ldd]);
+}
+void launch_col_scale_dev(Storage &st, double *dst, uint32_t ldd, const double *src, uint32_t lds, uint64_t rows, const double *nsq) {
+    if (rows == 0) return;
+    hipLaunchKernelGGL(col_scalar_dev_kernel<0>, grid1(rows, 256), dim3(256), 0, st.stream, dst, ldd, src, lds, rows, nsq);
+    SCANRS_HIP(hipGetLastError());
+}
+void launch_col_axpy_dev(Storage &st, double *y, uint32_t ldy, const double *x, uint32_t ldx, uint64_t rows, const double *nsq) {
+    if (rows == 0) return;
+    hipLaunchKernelGGL(col_scalar_dev_kernel<1>, grid1(rows, 256), dim3(256), 0, st.stream, y, ldy, x, ldx, rows, nsq);
+    SCANRS_HIP(hipGetLastError());
+}
 void launch_col_scale(Storage &st, double *dst, uint32_t ldd, const double *src, uint32_t lds, uint64_t rows, double alpha) {
     if (rows == 0) return;
     hipLaunchKernelGGL(col_scalar_kernel<0>, grid1(rows, 256), dim3(256), 0, st.stream, dst, ldd, src, lds, rows, alpha);

@@ -1588,40 +1588,51 @@ int pca_irlba(scanrs_mat *m, uint32_t nu, double tol, uint32_t maxit, const doub
     }
     double fnorm = 0.0;
     std::vector<double> resid(m_b);
+    // Squares of the norms of a restart cycle, on the device: ns[j] = |w_j|^2 (B's diagonal), nf[j] = |F_j|^2 (its superdiagonal). The
+    // recurrence takes them from there (col_scalar_dev_kernel) and the host reads all of them once per cycle, when it builds B — until
+    // round 6 every norm was a Gram kernel, a copy and a synchronisation with the device idle in between, two per Lanczos step.
+    double *ns = c.dev("ir_ns", m_b), *nf = c.dev("ir_nf", m_b);
+    std::vector<double> h_ns(m_b), h_nf(m_b);
+    auto norm_sq_dev = [&](const double *y, uint64_t rows, bool sharded, double *slot) {
+        launch_gram(c.st, y, 2, 1, y, 2, 1, rows, slot);
+        if (sharded) allreduce_f64(c.st, slot, 1);
+    };
     while (it < maxit) {
         if (it > 0) j = k;
+        const uint32_t j_first = j;
         get_col(c, V, ldm, j, vv, N);
         mat_apply(m, false, vv, 2, 1, wv, 2); // W[:, j] = A V[:, j]
         mprod++;
         if (it > 0) orthog_dev(c, wv, W, ldm, j, M, sh_m); // irlba.rs:131-134 (assigned to column k == j)
-        double sn = norm_dev(c, wv, M, sh_m);
-        double sinv = invcheck(sn);
-        set_col(c, W, ldm, j, wv, M, sinv);
+        norm_sq_dev(wv, M, sh_m, ns + j);
+        launch_col_scale_dev(c.st, W + j, ldm, wv, 2, M, ns + j);
         while (j < m_b) {
             get_col(c, W, ldm, j, wv, M);
             mat_apply(m, true, wv, 2, 1, F, 2); // F = W[:, j]^T A
             mprod++;
-            launch_col_axpy(c.st, F, 2, V + j, ldm, N, -sn); // F -= V[:, j] * s
+            launch_col_axpy_dev(c.st, F, 2, V + j, ldm, N, ns + j); // F -= V[:, j] * s
             orthog_dev(c, F, V, ldm, j + 1, N, sh_n);
-            fnorm = norm_dev(c, F, N, sh_n);
-            const double finv = invcheck(fnorm);
-            set_col(c, F, 2, 0, F, N, finv); // F *= finv (in place through the scale path)
-            if (j == m_b - 1) {
-                B[(size_t)j * m_b + j] = sn;
-            } else {
-                set_col(c, V, ldm, j + 1, F, N, 1.0);
-                B[(size_t)j * m_b + j] = sn;
-                B[(size_t)j * m_b + j + 1] = fnorm;
+            norm_sq_dev(F, N, sh_n, nf + j);
+            launch_col_scale_dev(c.st, F, 2, F, 2, N, nf + j); // F *= 1 / |F| (in place)
+            if (j + 1 < m_b) {
+                launch_copy_cols(c.st, F, 2, V + j + 1, ldm, N, 1);
                 mat_apply(m, false, F, 2, 1, wv, 2); // A V[:, j+1] (the reference computes it twice, irlba.rs:152,155)
                 mprod += 1;
-                launch_col_axpy(c.st, wv, 2, W + j, ldm, M, -fnorm); // - W[:, j] * |F|
+                launch_col_axpy_dev(c.st, wv, 2, W + j, ldm, M, nf + j); // - W[:, j] * |F|
                 orthog_dev(c, wv, W, ldm, j + 1, M, sh_m);
-                sn = norm_dev(c, wv, M, sh_m);
-                sinv = invcheck(sn);
-                set_col(c, W, ldm, j + 1, wv, M, sinv);
+                norm_sq_dev(wv, M, sh_m, ns + j + 1);
+                launch_col_scale_dev(c.st, W + j + 1, ldm, wv, 2, M, ns + j + 1);
             }
             j++;
         }
+        // the cycle's norms, one look: B[j][j] = |w_j|, B[j][j+1] = |F_j| (irlba.rs:147-160)
+        c.d2h(h_ns.data() + j_first, ns + j_first, m_b - j_first);
+        c.d2h(h_nf.data() + j_first, nf + j_first, m_b - j_first);
+        for (uint32_t jj = j_first; jj < m_b; jj++) {
+            B[(size_t)jj * m_b + jj] = std::sqrt(h_ns[jj]);
+            if (jj + 1 < m_b) B[(size_t)jj * m_b + jj + 1] = std::sqrt(h_nf[jj]);
+        }
+        fnorm = std::sqrt(h_nf[m_b - 1]);
         small_svd(B, (int)m_b, Us, Ss, Vts);
         for (uint32_t i = 0; i < m_b; i++) resid[i] = fnorm * Us[(size_t)(m_b - 1) * m_b + i];
         smax = Ss[0] > smax ? Ss[0] : smax;
