@@ -348,8 +348,8 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *   "d2h_threads" (4)   host threads that empty the pinned ring of a large result download
  *   "spmv_row_table" (1) Ix1 products over many short outer vectors (IRLBA's A v on the cell-major copy): a map that depends on the count
  *                       and the outer position alone is looked up by count from a table made per vector (0: values materialized per nonzero)
- *   "gemm_direct" (1)   dense panel products with results of up to 128 columns read their operands straight from memory into the
- *                       MFMA registers (0: the LDS-tiled kernels)
+ *   "gemm_direct" (1)   dense panel products X W read their operands straight from memory into the MFMA registers
+ *                       (0: the LDS-tiled kernels)
  *   "reuse_cmax" (1e5)  svd_bk: coefficient bound above which a projection column is recomputed directly
  *   "side_build" (1)    scanrs_normalize starts a helper thread (own stream) that builds what the PCA behind it needs: the first
  *                       product's tile layout, the transposed copy of the matrix and the second orientation's layout, in that

@@ -376,7 +376,7 @@ struct Storage {
     int device_factor = 1;                // svd_bk: CholeskyQR factors and the coefficient bookkeeping on the device, no host round trip per orthonormalisation (0: host)
     unsigned d2h_threads = 4;             // host threads that empty the pinned ring of a large result download
     int spmv_row_table = 1;               // Ix1 products over many short outer vectors: a map of the count and the outer position alone is looked up from a per-vector table instead of materialized per nonzero (0: materialized values)
-    int gemm_direct = 1;                  // dense X W with results of <= 128 columns: operands straight from memory into the MFMA registers (0: the LDS-tiled kernels)
+    int gemm_direct = 1;                  // dense X W: operands straight from memory into the MFMA registers (0: the LDS-tiled kernels)
     double reuse_cmax = 1e5;              // svd_bk: coefficient bound above which a projection column is recomputed directly
     int materialize = 1;                  // keep the map prefix's values per nonzero on the short-outer copy (SCANRS_MATERIALIZE=0: off)
     ~Storage();

@@ -586,12 +586,13 @@ void launch_gram_tiled(Storage &st, const double *X, uint32_t ldx, uint32_t n, c
 
 #include "dense_skinny.inc"
 
-// Results of up to 128 columns (svd_bk's panels: b = 2 k <= 128 for k <= 64; the Ritz factors) with rows of X aligned for 16-byte
-// loads: straight from memory into the MFMA operands, one or two column groups (dense_skinny.inc). Measured against the LDS-tiled
+// X W with rows of X aligned for 16-byte loads: straight from memory into the MFMA operands (dense_skinny.inc) — one column group up to
+// 112 result columns (svd_bk's panels, the Ritz factors), groups of 64 beyond (svd_rand's 500-column CholeskyQR applications:
+// 10^6 x 500 -> 500 in 11.3 ms = 44 TF against 22 ms through the LDS tiles; groups of 112 there: 12.5 ms). Measured against the LDS-tiled
 // kernels (profiles/microbench/gemm_skinny_probe.hip): 10^6 x 500 -> 50: 1.50 ms (2.5); 10^6 x 400 -> 100: 2.08 (3.6); 33 k x 400 -> 100:
 // 0.11 (0.29); 33 k x 100 -> 100: 0.045 (0.06-0.13).
 bool gemm_direct_ok(const double *X, uint32_t ldx, uint32_t n, uint32_t m, uint64_t rows) {
-    return m >= 1u && m <= 128u && n >= 16u && rows >= 64u && ldx % 2u == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0;
+    return m >= 1u && m <= 4096u && n >= 16u && rows >= 64u && ldx % 2u == 0 && (reinterpret_cast<uintptr_t>(X) & 15u) == 0;
 }
 void launch_gemm_direct(Storage &st, const double *X, uint32_t ldx, uint32_t n, const double *W, uint32_t ldw, uint32_t m, uint64_t rows,
                         double alpha, double beta, const double *Cin, uint32_t ldc, double *Out, uint32_t ldo) {
