@@ -276,7 +276,7 @@ static void download_panel_staged(Ctx &c, const double *d, uint32_t ld, uint64_t
     };
     // the parked host team if nobody else has it (creating a thread costs 0.1-3 ms, four of them per download and two downloads per
     // PCA: round 6), fresh threads otherwise (a second shard's download at the same time)
-    HostTeam *team = HostTeam::acquire((int)T + 1);
+    HostTeam *team = T <= 8u ? HostTeam::acquire((int)T + 1) : nullptr; // (the team's threads are never destroyed: not for a caller that asks for hundreds)
     std::vector<std::thread> workers;
     if (team)
         team->start((int)T + 1, [&](int t) { worker((unsigned)t - 1u); });
@@ -1466,7 +1466,7 @@ int pca_rand(scanrs_mat *m, uint32_t k, double l_multiplier, uint32_t n_iter, ui
 // (the dots stay on the device: nobody on the host reads them — until round 6 they made a round trip per call)
 static void orthog_dev(Ctx &c, double *y, const double *X, uint32_t ldx, uint32_t j, uint64_t rows, bool sharded) {
     if (j == 0) return;
-    double *dC = c.dev("irlba_dots", j);
+    double *dC = c.dev("irlba_dots", std::max<uint32_t>(j, 128u)); // (one size for the whole run: j grows by one per step)
     launch_gram(c.st, X, ldx, j, y, 2, 1, rows, dC);
     if (sharded) allreduce_f64(c.st, dC, j);
     launch_gemm_nn(c.st, X, ldx, j, dC, 1, 1, rows, -1.0, 1.0, y, 2, y, 2);
