@@ -346,6 +346,8 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *                       device (no host round trip per orthonormalisation; falls back to the host path by itself when a
  *                       factorization does not converge within the queued passes); 0: host factorizations
  *   "d2h_threads" (4)   host threads that empty the pinned ring of a large result download
+ *   "tile_spare_cus" (1) the persistent tile kernel launches as many workgroups as its number of item rounds needs (3 977 equal items:
+ *                       16 rounds on 256 workgroups and on 249); the CUs left over serve the side streams during the pass (0: one per CU)
  *   "spmv_row_table" (1) Ix1 products over many short outer vectors (IRLBA's A v on the cell-major copy): a map that depends on the count
  *                       and the outer position alone is looked up by count from a table made per vector (0: values materialized per nonzero)
  *   "gemm_direct" (1)   dense panel products X W read their operands straight from memory into the MFMA registers

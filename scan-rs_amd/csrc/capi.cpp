@@ -2279,6 +2279,8 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
         } else if (k == "sync_timeout_s") { // process-wide (the waits have no handle): same as scanrs_set_global_option
             if (!(value > 0.0) || !std::isfinite(value)) fail(SCANRS_ERR_ARGUMENT, "sync_timeout_s must be a positive number of seconds");
             set_sync_timeout_s(value);
+        } else if (k == "tile_spare_cus") {
+            st.tile_spare_cus = value != 0.0;
         } else if (k == "spmv_row_table") {
             st.spmv_row_table = value != 0.0;
         } else if (k == "gemm_direct") {

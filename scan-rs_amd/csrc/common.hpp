@@ -375,6 +375,7 @@ struct Storage {
     int col_moments = 1;                  // per-axis sums of a log-normalized map from the copy whose OUTER vectors are summed over (per-cell table + LDS fixed-point scatter) when eligible; 0: always the ordinary pass
     int device_factor = 1;                // svd_bk: CholeskyQR factors and the coefficient bookkeeping on the device, no host round trip per orthonormalisation (0: host)
     unsigned d2h_threads = 4;             // host threads that empty the pinned ring of a large result download
+    int tile_spare_cus = 1;               // the persistent tile kernel launches only as many workgroups as its number of item rounds needs; the CUs left over serve the side streams during the pass (0: a workgroup on every CU)
     int spmv_row_table = 1;               // Ix1 products over many short outer vectors: a map of the count and the outer position alone is looked up from a per-vector table instead of materialized per nonzero (0: materialized values)
     int gemm_direct = 1;                  // dense X W: operands straight from memory into the MFMA registers (0: the LDS-tiled kernels)
     double reuse_cmax = 1e5;              // svd_bk: coefficient bound above which a projection column is recomputed directly

@@ -1735,7 +1735,15 @@ void launch_spmm_tiles(Storage &st, SparseCopy &cp, const DevMap &map, const dou
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     const uint32_t wgg = (uint32_t)((tl.n_groups + TL_NW - 1) / TL_NW);
     const uint32_t n_items = wgg * sh.n_parts;
-    const uint32_t grid = std::min<uint32_t>(n_items, (uint32_t)n_cu);
+    // As many workgroups as the same number of item rounds needs, not as many as there are CUs: 3 977 items of equal size take 16 rounds on
+    // 256 workgroups (the last one 47 % empty) and 16 rounds on 249 — and the 7 CUs left over run the side streams' small kernels (the
+    // Gram-Schmidt chain of the previous Krylov block) DURING the pass instead of behind it, where a workgroup per CU left them no room
+    // (option "tile_spare_cus" 0: one workgroup per CU)
+    uint32_t grid = std::min<uint32_t>(n_items, (uint32_t)n_cu);
+    if (st.tile_spare_cus && grid == (uint32_t)n_cu) {
+        const uint32_t rounds = (n_items + grid - 1u) / grid;
+        grid = std::max<uint32_t>((n_items + rounds - 1u) / rounds, grid - grid / 16u); // (never more than a sixteenth of the CUs)
+    }
     const uint64_t part_stride = std::max<uint64_t>(tl.n_slots, 1) * (uint64_t)ldc; // partial sums per slot, in compact rows of ldc columns
     double *pbuf = st.scratch.get<double>("tile_parts", (size_t)sh.n_parts * part_stride);
     double *ovout = nullptr;

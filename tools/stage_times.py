@@ -1,5 +1,5 @@
 """Host-side stage markers of one steady-state step (SCANRS_TRACE=2 prints one line per marker with a steady-clock time stamp and
-synchronises nothing): where the calling thread is at which time. usage: stage_times.py [cells] [steps]"""
+synchronises nothing): where the calling thread is at which time. usage: stage_times.py [cells] [steps] [option=value ...]"""
 import os, subprocess, sys, time
 if os.environ.get("STAGE_CHILD") != "1":
     env = dict(os.environ, STAGE_CHILD="1", SCANRS_TRACE="2")
@@ -29,6 +29,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 dev = torch.device("cuda", 0)
 ip, ix, vv = synth_counts_torch(cells, 33_000, 0.03, 0, dev)
 m = sa.AdaptiveMat.from_device(33_000, cells, sa.CSC, ip.data_ptr(), ix.data_ptr(), vv.data_ptr())
+for a in sys.argv[3:]:  # handle options: name=value
+    m.set_option(a.split('=')[0], float(a.split('=')[1]))
 bk = sa.BkSvd()
 r, c = m.shape()
 out_u, out_v = np.zeros((r, 50)), np.zeros((c, 50))
