@@ -375,8 +375,11 @@ int scanrs_mat_set_spmm_path(scanrs_mat *m, int path);
  *                       as long as the most loaded of the item's 8 waves needs for the tile that leaves the ring, and the accumulator of
  *                       a record is selected at run time (VGPR index mode): about 1.05 record positions per nonzero and no overflow
  *                       beyond the vectors too sparse to own a slot; 0 = the round-4 form, tile_k fixed positions per (slot, visit)
- *   "tile_sort_slots" (1)  dense tile layout: the slots take their places (workgroup item, wave, accumulator) in the order of their load,
- *                       heaviest first, so that the 8 waves of an item carry about the same number of records per visit (0: vector order)
+ *   "tile_sort_slots" (2)  dense tile layout: 2 = the slots, sorted by load, are DEALT over the waves' groups (rank k -> group k mod n, accumulator
+ *                       k div n): every group holds one slot of every load stratum, so the 8 waves of an item carry the same number of records
+ *                       per visit AND all items of a part move through the panel's tiles at the same pace (a tile stays in L2 between the
+ *                       first and the last workgroup that stages it: gene-major pass 15.5 -> 13.7 ms); 1 = 32 consecutive ranks per group
+ *                       (rounds 5-6: equal waves, but items of very different load); 0 = vector order
  *   "tile_one_walk" (1)  dense tile layout: 1 = built in ONE walk over the matrix (the (group, part) blocks of the tile-sorted record
  *                       list start at the prefix sums of their capacities, found by binary searches; counts above 15 leave through
  *                       a bounded list); 0 = a counting walk and a filling walk. The same layout bit for bit.

@@ -2228,7 +2228,7 @@ int scanrs_mat_set_option(scanrs_mat *m, const char *key, double value) {
         } else if (k == "tile_dense") {
             st.tile_dense = value != 0.0;
         } else if (k == "tile_sort_slots") {
-            st.tile_sort_slots = value != 0.0;
+            st.tile_sort_slots = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0);
         } else if (k == "tile_flow") {
             st.tile_flow = value != 0.0;
         } else if (k == "tile_wtab" || k == "tile_fold") {

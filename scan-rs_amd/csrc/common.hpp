@@ -344,7 +344,7 @@ struct Storage {
     int tile_build_one_pass = 1;          // wave-level layout builder: records and overflow in ONE walk over the matrix + a compaction (0: counting pass, then fill pass)
     int tile_weights_wide = 1;            // weight refresh of a unit-mode layout: four positions per thread with wide loads / stores (0: one position per thread)
     int tile_dense = 1;                   // tile layout of the default shape: 1 = dense record streams, accumulators picked through VGPR index mode (round 5, tiles_dense.inc); 0 = fixed positions per (slot, visit) (round 4)
-    int tile_sort_slots = 1;              // dense tile layout: slots placed in the order of their load (0: in vector order)
+    int tile_sort_slots = 2;              // dense tile layout: 2 = the slots sorted by load and DEALT over the groups (every group one slot of every load stratum: equal items, lockstep through the panel's tiles), 1 = consecutive ranks per group, 0 = vector order
     int tile_emit_staged = 1;             // dense tile layout: the stream emission keeps its tables in LDS (0: searches them in global memory, the form for parts of > 4 000 tiles)
     int tile_flow = SCANRS_TILE_FLOW_DEFAULT;                    // dense tile layout with the map evaluated in the kernel: 1 = the FLOW form (tiles_flow.inc): tiles of 32 rows in a ring of 6, one record stream per wave cut into rounds of 64 positions whatever tiles they belong to, the ring handed over at ticks through counters in LDS; 0 = the round-5 form (one barrier per tile of 48 rows, a round per visit)
     int tile_wtab = 1;                    // dense tile layout, folded separable map: the product kernel gathers a position's weight from the map's table by the record itself - the map evaluated inside the kernel, no weight stream (0: one f64 per position, refreshed per normalize)

@@ -848,6 +848,7 @@ struct TileLayout {
     DevBuf<uint64_t> cmeta;        // group << 32 | visit of a chunk (weight refresh)
     DevBuf<char> ditems;           // DenseItem per workgroup item
     DevBuf<uint32_t> rtab;         // rounds: chunks | first-of-visit << 8
+    int slot_mode = 0;             // dense: the "tile_sort_slots" form slot_order was built in (1 consecutive ranks per group, 2 dealt)
     DevBuf<uint32_t> slot_order;   // dense: the slot at place p of the layout (group p / 32, accumulator p % 32), slots sorted by load; empty: place = slot
     DevBuf<uint32_t> slot_pos;     // ... and the place of slot s
     DevBuf<double> w_place, w_inner; // dense, separable map: the weight's factor by place ([8] per place when the outer side owns the nonlinear links) / [8] per inner position otherwise
@@ -869,9 +870,10 @@ struct TileLayout {
         if (flow != tile_flow_wanted(st, cp)) return false;
         if (flow) { // (its own tile shape, whatever tile_t / tile_b say)
             const double want_x = st.tile_split ? st.tile_split_x : 0.0, want_min = st.tile_split ? st.tile_split_min : 0.0;
-            return (slot_order.n != 0) == (st.tile_sort_slots != 0 && n_slots > 1) && split_x == want_x && split_min == want_min;
+            return (slot_order.n != 0) == (st.tile_sort_slots != 0 && n_slots > 1) && (slot_order.n == 0 || slot_mode == st.tile_sort_slots) && split_x == want_x && split_min == want_min;
         }
         if (dense && (slot_order.n != 0) != (st.tile_sort_slots != 0 && n_slots > 1)) return false;
+        if (dense && slot_order.n != 0 && slot_mode != st.tile_sort_slots) return false;
         const bool splittable = st.tile_builder != 0 && sh.K == 2u && sh.B == 4u && sh.S == 32u && sh.T == 48u; // the wave-level builder's shape
         const double want_x = splittable && st.tile_split ? st.tile_split_x : 0.0, want_min = splittable && st.tile_split ? st.tile_split_min : 0.0;
         return sh.K == st.tile_k && sh.S == st.tile_s && sh.T == st.tile_t && sh.B == st.tile_b && sh.KU == (st.tile_k == 2u && st.tile_ku ? 1u : 0u) &&
