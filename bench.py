@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 LDS_PEAK_TBS = 150.0   # MI355X_MICROARCH.md, LDS: ds_read_b128 = 256 B/clk/CU, "aggregate with every CU streaming (~2.4 GHz): ~150 TB/s"
 LDS_SURVEY_TBS = 78.6  # SURVEY.md §8d's estimate (128 B/clk/CU x 256 CUs x 2.4 GHz), kept beside it
-PMC_PROFILE = "r06h_pmc_traffic.json"  # committed PMC passes (separate --pmc runs) the `traffic` field is read from
+PMC_PROFILE = "r06i_pmc_traffic.json"  # committed PMC passes (separate --pmc runs) the `traffic` field is read from
 KERNEL_SOURCES = ("scan-rs_amd/csrc/tiles.hip", "scan-rs_amd/csrc/tiles_dense.inc", "scan-rs_amd/csrc/tile_dense_body.inc", "scan-rs_amd/csrc/tile_dense_body_tabo.inc",
                   "scan-rs_amd/csrc/tile_dense_body_tabi.inc", "scan-rs_amd/csrc/kernels.hip",
                   "scan-rs_amd/csrc/device_map.hpp")
